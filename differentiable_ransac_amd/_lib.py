@@ -1,0 +1,81 @@
+"""ctypes binding of libdransac.so (C ABI declared in include/dransac.h).
+
+The library is the product: there is no Python/CPU fallback.  `lib()` raises if the shared
+object is missing or cannot be loaded; every wrapper raises `DransacError` on a non-zero status.
+torch is imported first so that the HIP runtime torch ships (same SONAME, libamdhip64.so.7) is the
+one the library binds to -- one runtime per process, shared streams and allocations.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_uint64, c_void_p
+from typing import Optional
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdransac.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dransac.h")
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class DransacError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DransacError(
+                f"{LIB_PATH} not found: build it with `python -m differentiable_ransac_amd.build` "
+                "(there is deliberately no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.dr_last_error.restype = c_char_p
+        _lib.dr_version.restype = c_int
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().dr_last_error().decode("utf-8", "replace")
+        raise DransacError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> c_void_p:
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise DransacError("libdransac operates on GPU tensors only (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise DransacError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def suffix(dtype: torch.dtype) -> str:
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise DransacError(f"unsupported dtype {dtype}: f32 and f64 only (SURVEY Q15)")
+
+
+def scalar(dtype: torch.dtype, v: float):
+    return c_float(v) if dtype == torch.float32 else c_double(v)
+
+
+def call(name: str, *args) -> None:
+    fn = getattr(lib(), name)
+    fn.restype = c_int
+    check(fn(*args), name)
+
+
+__all__ = ["lib", "check", "ptr", "stream", "suffix", "scalar", "call", "DransacError", "LIB_PATH", "HEADER_PATH",
+           "c_int", "c_uint64", "c_float", "c_double", "c_void_p"]

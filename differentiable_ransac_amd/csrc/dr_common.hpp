@@ -1,0 +1,89 @@
+// Shared helpers for the gfx950 kernels of libdransac.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dransac.h"
+
+namespace dr {
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return DR_ELAUNCH;
+  }
+  return DR_OK;
+}
+
+#define DR_REQUIRE(cond, msg)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::dr::set_error("%s: %s", __func__, msg); \
+      return DR_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+// ---- wave64 reductions (ds_swizzle/DPP chosen by the compiler from the xor pattern) ----
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+
+template <typename T>
+__device__ __forceinline__ bool is_finite(T x) {
+  return (x - x) == T(0);
+}
+
+// Philox4x32-10 (Salmon et al., SC'11).  Counter-based: the oracle-side restatement lives in
+// tests/ (numpy) so that in-kernel sampling is reproducible bit-for-bit on the integer side.
+struct Philox {
+  static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+    uint64_t p = (uint64_t)a * b;
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
+  }
+  __host__ __device__ static inline void gen(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t out[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      uint32_t h0, l0, h1, l1;
+      mulhilo(M0, c0, h0, l0);
+      mulhilo(M1, c2, h1, l1);
+      uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  }
+};
+
+// u32 -> Gumbel(0,1) sample, mirroring torch.distributions.Gumbel: u = tiny + r*(1-eps-tiny), r = u24 * 2^-24
+__device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
+  float r = (float)(bits >> 8) * 5.9604644775390625e-08f;  // [0,1)
+  float u = r * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f) + 1.17549435e-38f;
+  return -__logf(-__logf(u));
+}
+
+}  // namespace dr

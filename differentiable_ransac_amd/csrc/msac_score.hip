@@ -1,0 +1,250 @@
+// K4 -- MSAC soft-inlier scoring on the Sampson distance (reference: MSACScore.score,
+// scorings/msac_score.py:12-55) and K6 -- per-pair arg-max / best mask (ransac.py:111-120).
+//
+// Roofline: per pair bytes = 16N + 36M + 4M + M*N (bool masks are part of the
+// score() contract), flops = 39*M*N  =>  38 flop/B at C2: the kernel is f32-VALU bound, the
+// masks are the only HBM stream that matters.
+//
+// Mapping.  One 256-thread block = (pair p, tile of kModelsPerBlock models, chunk range of points).
+// A lane owns kPts = 8 CONSECUTIVE points held in VGPRs for the whole block lifetime (32 VGPRs),
+// so the inner loop touches no LDS and no vector memory except the 8-byte mask store: the model's
+// nine coefficients are wave-uniform and arrive through the scalar cache (s_load) into SGPRs,
+// which VALU instructions read for free.  Score partials are reduced inside the wave and summed
+// across the block's four waves through 1 KiB of LDS; with one chunk per pair (N <= 2048) the
+// result is stored directly, i.e. deterministically; larger N split over blocks use one
+// atomicAdd per (block, model).
+#include "dr_common.hpp"
+
+namespace dr {
+
+constexpr int kThreads = 256;
+constexpr int kPts = 8;                       // points per lane
+constexpr int kChunk = kThreads * kPts;       // 2048 points per block pass
+constexpr int kModelsPerBlock = 32;
+
+template <typename T>
+struct Pt4 { T x1, y1, x2, y2; };
+
+template <typename T>
+__device__ __forceinline__ T sampson_s(const T m[9], T x1, T y1, T x2, T y2, T inv_thr2) {
+  // a = M^T x2 ; b = M x1 (first two) ; r = x1 . a       (msac_score.py:33-39)
+  T a0 = fma(x2, m[0], fma(y2, m[3], m[6]));
+  T a1 = fma(x2, m[1], fma(y2, m[4], m[7]));
+  T a2 = fma(x2, m[2], fma(y2, m[5], m[8]));
+  T b0 = fma(x1, m[0], fma(y1, m[1], m[2]));
+  T b1 = fma(x1, m[3], fma(y1, m[4], m[5]));
+  T r = fma(x1, a0, fma(y1, a1, a2));
+  T jj = fma(a0, a0, fma(a1, a1, fma(b0, b0, b1 * b1)));
+  T d2 = (r * r) * fast_rcp(jj);
+  return fma(d2, inv_thr2, T(-1));  // s = d2/thr2 - 1 ; inlier <=> s < 0 ; soft score = max(-s, 0)
+}
+
+template <typename T, bool kMask>
+__global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restrict__ matches,
+                                                              const T *__restrict__ models,
+                                                              const T *__restrict__ thr, int M, int N,
+                                                              T *__restrict__ scores, uint8_t *__restrict__ masks,
+                                                              int chunks_per_block, int use_atomic) {
+  __shared__ T part[kThreads / kWave][kModelsPerBlock];
+  const int p = blockIdx.z;
+  const int m0 = blockIdx.x * kModelsPerBlock;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mcount = min(kModelsPerBlock, M - m0);
+  const T t = T(1.5) * thr[p];
+  const T inv_thr2 = T(1) / (t * t);
+  const T *mt = matches + (size_t)p * N * 4;
+  const T *md = models + ((size_t)p * M + m0) * 9;
+  const bool row_aligned = (N % 8) == 0;
+
+  for (int i = tid; i < (kThreads / kWave) * kModelsPerBlock; i += kThreads) (&part[0][0])[i] = T(0);
+  __syncthreads();
+
+  const int c_begin = blockIdx.y * chunks_per_block;
+  for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
+    const int n0 = c * kChunk + tid * kPts;
+    if (c * kChunk >= N) break;
+    T x1[kPts], y1[kPts], x2[kPts], y2[kPts];
+#pragma unroll
+    for (int j = 0; j < kPts; ++j) {
+      const int n = n0 + j;
+      if (n < N) {
+        if constexpr (sizeof(T) == 4) {
+          const float4 v = reinterpret_cast<const float4 *>(mt)[n];
+          x1[j] = v.x; y1[j] = v.y; x2[j] = v.z; y2[j] = v.w;
+        } else {
+          x1[j] = mt[4 * n]; y1[j] = mt[4 * n + 1]; x2[j] = mt[4 * n + 2]; y2[j] = mt[4 * n + 3];
+        }
+      } else {  // padding point: contributes exactly zero (s = +inf -> max(-s,0) = 0, mask = 0)
+        x1[j] = y1[j] = x2[j] = y2[j] = T(0);
+      }
+    }
+    const int nvalid = min(kPts, max(0, N - n0));
+
+    for (int ml = 0; ml < mcount; ++ml) {
+      T m[9];
+      bool finite = true;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        m[q] = md[ml * 9 + q];
+        finite = finite && is_finite(m[q]);
+      }
+      T acc = T(0);
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < kPts; ++j) {
+        T s = sampson_s<T>(m, x1[j], y1[j], x2[j], y2[j], inv_thr2);
+        const bool in = (j < nvalid) && (s < T(0));
+        acc += in ? -s : T(0);
+        if (kMask) {
+          if (j < 4) lo |= (uint32_t)in << (8 * j);
+          else hi |= (uint32_t)in << (8 * (j - 4));
+        }
+      }
+      if (!finite) { acc = T(0); lo = hi = 0; }
+      if (kMask && nvalid > 0) {
+        uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
+        if (row_aligned && nvalid == kPts) {
+          *reinterpret_cast<uint2 *>(row) = make_uint2(lo, hi);
+        } else {
+          for (int j = 0; j < nvalid; ++j) row[j] = (uint8_t)(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 1u);
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) part[wv][ml] += finite ? acc : (acc + T(NAN));
+    }
+  }
+  __syncthreads();
+  if (tid < mcount) {
+    T v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    T *dst = scores + (size_t)p * M + m0 + tid;
+    if (use_atomic) atomicAdd(dst, v);
+    else *dst = v;
+  }
+}
+
+// ---- K6: per-pair first arg-max over valid, non-NaN scores; recompute the winner's mask -------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void select_best_kernel(const T *__restrict__ matches,
+                                                               const T *__restrict__ models,
+                                                               const uint8_t *__restrict__ valid,
+                                                               const T *__restrict__ scores,
+                                                               const T *__restrict__ thr, int M, int N,
+                                                               int32_t *__restrict__ best_idx,
+                                                               T *__restrict__ best_score, T *__restrict__ best_model,
+                                                               uint8_t *__restrict__ best_mask,
+                                                               int32_t *__restrict__ inliers) {
+  __shared__ T s_val[kThreads / kWave];
+  __shared__ int s_idx[kThreads / kWave];
+  __shared__ int s_cnt[kThreads / kWave];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const T *sc = scores + (size_t)p * M;
+  const uint8_t *vd = valid ? valid + (size_t)p * M : nullptr;
+  T bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int m = tid; m < M; m += kThreads) {
+    T v = sc[m];
+    bool ok = (v == v) && (!vd || vd[m]);
+    if (ok && (v > bv || (v == bv && m < bi))) { bv = v; bi = m; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
+  __syncthreads();
+  bv = s_val[0]; bi = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / kWave; ++w)
+    if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+  const bool none = bi == 0x7fffffff;
+  T m[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) m[q] = none ? T(q % 4 == 0) : models[((size_t)p * M + bi) * 9 + q];
+  if (tid == 0) {
+    best_idx[p] = none ? -1 : bi;
+    best_score[p] = none ? T(0) : bv;
+    if (best_model)
+      for (int q = 0; q < 9; ++q) best_model[(size_t)p * 9 + q] = m[q];
+  }
+  const T t = T(1.5) * thr[p];
+  const T inv_thr2 = T(1) / (t * t);
+  int cnt = 0;
+  for (int n = tid; n < N; n += kThreads) {
+    const T *q = matches + ((size_t)p * N + n) * 4;
+    T s = sampson_s<T>(m, q[0], q[1], q[2], q[3], inv_thr2);
+    bool in = !none && (s < T(0));
+    if (best_mask) best_mask[(size_t)p * N + n] = in;
+    cnt += in;
+  }
+  cnt = wave_sum(cnt);
+  if (lane == 0) s_cnt[wv] = cnt;
+  __syncthreads();
+  if (tid == 0 && inliers) inliers[p] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+template <typename T>
+int msac_score_launch(const T *matches, const T *models, const T *thr, int P, int M, int N, T *scores,
+                      uint8_t *masks, hipStream_t st) {
+  const int tiles = (M + kModelsPerBlock - 1) / kModelsPerBlock;
+  const int chunks = (N + kChunk - 1) / kChunk;
+  // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip
+  int ny = 1;
+  const long base = (long)P * tiles;
+  if (chunks > 1 && base < 2048) ny = (int)min((long)chunks, (2048 + base - 1) / base);
+  const int cpb = (chunks + ny - 1) / ny;
+  ny = (chunks + cpb - 1) / cpb;
+  const int use_atomic = ny > 1;
+  if (use_atomic) {
+    if (hipMemsetAsync(scores, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
+  }
+  dim3 grid(tiles, ny, P);
+  if (masks)
+    hipLaunchKernelGGL((msac_score_kernel<T, true>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N, scores,
+                       masks, cpb, use_atomic);
+  else
+    hipLaunchKernelGGL((msac_score_kernel<T, false>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N, scores,
+                       masks, cpb, use_atomic);
+  return check_launch("msac_score_kernel");
+}
+
+}  // namespace dr
+
+extern "C" {
+
+int dr_msac_score_f32(const float *matches, const float *models, const float *thr, int P, int M, int N,
+                      float *scores, uint8_t *masks, void *stream) {
+  DR_REQUIRE(matches && models && thr && scores, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  return dr::msac_score_launch<float>(matches, models, thr, P, M, N, scores, masks, (hipStream_t)stream);
+}
+
+int dr_msac_score_f64(const double *matches, const double *models, const double *thr, int P, int M, int N,
+                      double *scores, uint8_t *masks, void *stream) {
+  DR_REQUIRE(matches && models && thr && scores, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  return dr::msac_score_launch<double>(matches, models, thr, P, M, N, scores, masks, (hipStream_t)stream);
+}
+
+int dr_select_best_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
+                       const float *thr, int P, int M, int N, int32_t *best_idx, float *best_score,
+                       float *best_model, uint8_t *best_mask, int32_t *inliers, void *stream) {
+  DR_REQUIRE(matches && models && scores && thr && best_idx && best_score, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0, "bad sizes");
+  hipLaunchKernelGGL((dr::select_best_kernel<float>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches,
+                     models, valid, scores, thr, M, N, best_idx, best_score, best_model, best_mask, inliers);
+  return dr::check_launch("select_best_kernel");
+}
+
+int dr_select_best_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,
+                       const double *thr, int P, int M, int N, int32_t *best_idx, double *best_score,
+                       double *best_model, uint8_t *best_mask, int32_t *inliers, void *stream) {
+  DR_REQUIRE(matches && models && scores && thr && best_idx && best_score, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0, "bad sizes");
+  hipLaunchKernelGGL((dr::select_best_kernel<double>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches,
+                     models, valid, scores, thr, M, N, best_idx, best_score, best_model, best_mask, inliers);
+  return dr::check_launch("select_best_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+/*
+ * dransac.h -- C ABI of libdransac.so, the MI355X (gfx950) implementation of the
+ * differentiable-RANSAC hot path (sampler -> minimal solver -> soft-inlier scoring).
+ *
+ * The reference (weitong8591/differentiable_ransac) has NO native boundary: its hot path is
+ * duck-typed Python objects consumed by RANSAC.__init__ (ransac.py:8-39).  Each entry point
+ * below therefore cites the reference *Python* interface it replaces; the Python plugin
+ * classes in differentiable_ransac_amd/ bind these symbols through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a contiguous row-major array, unless marked [host];
+ *   - P = image pairs, N = points per pair, B = hypotheses (minimal samples) per pair,
+ *     k = sample size, S = model slots per sample, M = models per pair (= B*S);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - return value: DR_OK (0) or a negative DR_E* code; dr_last_error() gives the message of
+ *     the last failure on the calling thread.  No entry point throws, aborts or allocates
+ *     device memory; scratch space is passed in by the caller where needed;
+ *   - *_f32 entry points take float I/O, *_f64 double I/O.  Minimal solvers always compute
+ *     in f64 internally (f64 FMA runs at the scalar-f32 rate on CDNA4) so that the f32 entry
+ *     points meet the 1e-4 model tolerance that the reference's own f32 path does not.
+ *   - numerically failed hypotheses never produce NaN: their slot is eye(3) and valid = 0
+ *     (the reference drops them, nister.py:154-157,365-366,400-405).
+ */
+#ifndef DRANSAC_H_
+#define DRANSAC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_OK 0
+#define DR_EINVAL (-1)  /* bad argument (null pointer, non-positive size, unsupported k) */
+#define DR_ELAUNCH (-2) /* HIP launch / runtime failure */
+#define DR_ENOTIMPL (-3)
+
+#define DR_ABI_VERSION 1
+
+int dr_version(void);
+const char *dr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  Gumbel-softmax top-k sampler     GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42
+ *
+ *   g[p,b,n] = (logits[p,n] + gumbel[p,b,n]) / tau ; y = softmax_n(g) ; idx = top-k_n(g).
+ *   gumbel == NULL  -> noise generated in-kernel: Philox4x32-10(key = seed, counter = (n/4, b, p, 0)),
+ *                      lane n%4, u = tiny + u24*(1-eps-tiny), gumbel = -log(-log u);
+ *   gumbel != NULL  -> explicit noise [P,B,N] (parity mode: index sets are bit-exact w.r.t. the reference).
+ *   Outputs: idx [P,B,k] int32, ASCENDING point index (= the order `points[samples != 0]` yields,
+ *   ransac.py:65); y_sel [P,B,k] = y at idx; lse [P,B] = log-sum-exp of g (so y = exp(g - lse));
+ *   optional dense outputs (API-faithful mode) y_soft [P,B,N], ret [P,B,N] = y_hard - y + y
+ *   (gumbel_sampler.py:38) and gumbel_out [P,B,N] (the noise that was used); NULL to skip.
+ *   logits == NULL  -> all-ones logits (gumbel_sampler.py:27-28).
+ * ------------------------------------------------------------------------------------------ */
+int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
+                           int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,
+                           float *gumbel_out, void *stream);
+int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B,
+                           int N, int k, int32_t *idx, double *y_sel, double *lse, double *y_soft, double *ret,
+                           double *gumbel_out, void *stream);
+
+/* Backward of sampler + gather (K1+K2).  a_sel [P,B,k] = dL/d(straight-through value at idx)
+ * (= <grad_sample, matches[idx]> + grad_weight, computed by dr_gather_bwd).  grad_logits [P,N] is
+ * OVERWRITTEN with (1/tau) * sum_b y*(a - sum_m y_m a_m).  Needs the forward's noise: pass the same
+ * gumbel pointer or the same seed. */
+int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
+                           int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
+                           void *stream);
+
+/* K1u  UniformSampler.batch_generate, samplers/uniform_sampler.py:15-19: idx ~ U{0..N-2}, with replacement.
+ * Philox4x32-10(key = seed, counter = (j, b, p, 1)). */
+int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  straight-through gather          RANSAC.__call__, ransac.py:58-65 (+ :73 weighted)
+ *   samples[p,b,j,:] = matches[p, idx[p,b,j], :] * st[p,b,j],  st = (1 - y_sel) + y_sel  (f32 rounding
+ *   of y_hard - y_soft + y_soft); y_sel == NULL -> st = 1 (uniform sampler, ransac.py:60).
+ *   c = 4 (two-view) or 6 (3-D).
+ * ------------------------------------------------------------------------------------------ */
+int dr_gather_fwd_f32(const float *matches, const int32_t *idx, const float *y_sel, int P, int N, int B, int k,
+                      int c, float *samples, void *stream);
+int dr_gather_fwd_f64(const double *matches, const int32_t *idx, const double *y_sel, int P, int N, int B, int k,
+                      int c, double *samples, void *stream);
+/* a_sel[p,b,j] = <grad_samples[p,b,j,:], matches[p,idx,:]> (+ grad_w[p,b,j] if non-NULL);
+ * grad_matches [P,N,c] (may be NULL) += grad_samples * st  (atomic; caller zeroes it). */
+int dr_gather_bwd_f32(const float *matches, const int32_t *idx, const float *y_sel, const float *grad_samples,
+                      const float *grad_w, int P, int N, int B, int k, int c, float *a_sel, float *grad_matches,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  minimal solvers.  samples [Bt,k,c] (Bt = total hypotheses = P*B, flattened), optional
+ *     per-point weights [Bt,k] (NULL = unweighted).  models [Bt,S,9] row-major 3x3 (rigid: [Bt,16]),
+ *     valid [Bt,S] uint8.
+ *
+ *   dr_solve_nister5     EssentialMatrixEstimatorNister.estimate_minimal_model, nister.py:69-408; S = 10;
+ *                        n >= 5 points per sample (n > 5 = the non-minimal fallback of nister.py:64-65);
+ *                        real roots only, ascending in z; unit Frobenius norm; unused slots = eye(3).
+ *   dr_solve_stewenius5  EssentialMatrixEstimator.estimate_minimal_model, stewenius.py:20-80; S = 10;
+ *                        unit Frobenius norm (the reference leaves LAPACK's eigenvector scale).
+ *   dr_solve_f8          FundamentalMatrixEstimatorNew normalize + estimate_non_minimal_model,
+ *                        fundamental_matrix_estimator.py:177-260; S = 1; n >= 8.
+ *   dr_solve_f7          7-point with the correct maths (reference degenerate, Q7/Q8); S = 4.
+ *   dr_solve_rigid       RigidTransformationSVDBasedSolver.estimate_model, rigid…:11-74; n >= 3, c = 6;
+ *                        models [Bt,16] = 4x4, also R [Bt,9], t [Bt,3], scale [Bt] (any may be NULL);
+ *                        flag != 0 reproduces the reference default (svd of cov^T cov, R ~ I, Q9).
+ * ------------------------------------------------------------------------------------------ */
+int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
+                         void *stream);
+int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, int n, double *models,
+                         uint8_t *valid, void *stream);
+int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
+int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
+int dr_solve_f8_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
+                    void *stream);
+int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n, double *models, uint8_t *valid,
+                    void *stream);
+int dr_solve_f7_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
+int dr_solve_f7_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
+int dr_solve_rigid_f32(const float *samples, const float *weights, int Bt, int n, int flag, float *models, float *R,
+                       float *t, float *scale, uint8_t *valid, void *stream);
+int dr_solve_rigid_f64(const double *samples, const double *weights, int Bt, int n, int flag, double *models,
+                       double *R, double *t, double *scale, uint8_t *valid, void *stream);
+
+/* Backward of the minimal solvers by implicit differentiation of the defining constraints at the
+ * returned model.  grad_models has the forward's model shape; grad_samples [Bt,k,c]
+ * is overwritten.  Invalid slots contribute nothing. */
+int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const uint8_t *valid,
+                             const float *grad_models, int Bt, float *grad_samples, void *stream);
+int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float *models, const float *grad_models,
+                        int Bt, int n, float *grad_samples, float *grad_weights, void *stream);
+int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const float *grad_models, int Bt, int n,
+                           int flag, float *grad_samples, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  MSAC soft-inlier scoring on the Sampson distance      MSACScore.score, scorings/msac_score.py:12-55
+ *   matches [P,N,4], models [P,M,9], thr [P] (the `threshold` argument per pair; the kernel applies
+ *   the (3/2 thr)^2 of msac_score.py:21).  scores [P,M]; masks [P,M,N] uint8 (torch.bool layout) or NULL.
+ *   Models with a non-finite coefficient get score = NaN and an all-false mask (what the reference's
+ *   arithmetic yields for them).
+ * ------------------------------------------------------------------------------------------ */
+int dr_msac_score_f32(const float *matches, const float *models, const float *thr, int P, int M, int N,
+                      float *scores, uint8_t *masks, void *stream);
+int dr_msac_score_f64(const double *matches, const double *models, const double *thr, int P, int M, int N,
+                      double *scores, uint8_t *masks, void *stream);
+/* dL/dmodels [P,M,9] from dL/dscores [P,M] (flows only through points with d2 < thr2). */
+int dr_msac_score_bwd_f32(const float *matches, const float *models, const float *thr, const float *grad_scores,
+                          int P, int M, int N, float *grad_models, void *stream);
+
+/* K4r squared residual of rigid models   RigidTransformationSVDBasedSolver.squared_residual, rigid…:76-89
+ *   pts [P,N,6] = (p,q); models [P,M,16] (4x4: q_hat = R p + t with the reference's row-vector descriptor
+ *   D = model[:3,:]^T, ransac.py:380); res_sum [P,M] = sum_n d2; masks [P,M,N] = d2 < threshold or NULL.
+ *   The reference's scalar mean is sum(res_sum)/(M*N), left to the caller. */
+int dr_rigid_residual_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
+                          float *res_sum, uint8_t *masks, void *stream);
+int dr_rigid_residual_f64(const double *pts, const double *models, double threshold, int P, int M, int N,
+                          double *res_sum, uint8_t *masks, void *stream);
+int dr_rigid_residual_bwd_f32(const float *pts, const float *models, const float *grad_res, int P, int M, int N,
+                              float *grad_models, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  train-mode best-of-S selection      RANSAC.__call__, ransac.py:87-96
+ *   chosen[p,b] = models[p,b,argmin_s ||models[p,b,s] - gt[p]||_F]; invalid slots (valid == 0) are
+ *   skipped; which [P*B] int32 (-1 when no slot is valid; chosen = eye(3) then).
+ * ------------------------------------------------------------------------------------------ */
+int dr_select_closest_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
+                          float *chosen, int32_t *which, void *stream);
+int dr_select_closest_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
+                          double *chosen, int32_t *which, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  test-mode selection      RANSAC.__call__, ransac.py:111-120
+ *   Per pair: best_idx = first arg-max of scores over valid models (NaN scores never win),
+ *   best_score, best_mask [P,N] uint8 recomputed for the winning model, inlier count.
+ *   valid may be NULL (all valid).
+ * ------------------------------------------------------------------------------------------ */
+int dr_select_best_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
+                       const float *thr, int P, int M, int N, int32_t *best_idx, float *best_score,
+                       float *best_model, uint8_t *best_mask, int32_t *inliers, void *stream);
+int dr_select_best_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,
+                       const double *thr, int P, int M, int N, int32_t *best_idx, double *best_score,
+                       double *best_model, uint8_t *best_mask, int32_t *inliers, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused (pair x hypothesis) drivers: K1 -> K2 -> K3 in ONE launch (sampling, gather and solve never
+ * touch HBM in between).  solver: 0 nister5, 1 stewenius5, 2 f8 (k = 8), 3 f7, 4 rigid (c = 6).
+ *   idx [P,B,k], y_sel [P,B,k], lse [P,B] as in K1; models [P,B,S,9|16]; valid [P,B,S].
+ * ------------------------------------------------------------------------------------------ */
+#define DR_SOLVER_NISTER5 0
+#define DR_SOLVER_STEWENIUS5 1
+#define DR_SOLVER_F8 2
+#define DR_SOLVER_F7 3
+#define DR_SOLVER_RIGID 4
+int dr_sample_solve_f32(int solver, const float *matches, const float *logits, const float *gumbel, uint64_t seed,
+                        float tau, int P, int N, int B, int32_t *idx, float *y_sel, float *lse, float *models,
+                        uint8_t *valid, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRANSAC_H_ */
