@@ -1,0 +1,471 @@
+// K1 -- Gumbel-softmax top-k straight-through sampler (reference: GumbelSoftmaxSampler.sample,
+// samplers/gumbel_sampler.py:25-42), K1u uniform sampler (uniform_sampler.py:15-19), K2 gather
+// (ransac.py:58-65) and the backward of K1+K2.
+//
+// The reference materialises five [B,N] tensors per call (repeat, noise, softmax, one-hot, ret).
+// Here one wave owns one (pair, hypothesis) row and never writes a [B,N] tensor unless the caller
+// asks for the API-faithful dense outputs:
+//   pass A  g = (logit + gumbel)/tau for the lane's 4-element groups (16-byte coalesced loads, or
+//           Philox4x32-10 in-kernel: one call = 4 elements), online soft-max (running max / sum)
+//           and the lane maximum; g is parked in LDS (4N bytes per wave) when it fits;
+//   select  T = k-th largest of the 64 lane maxima (k wave-max rounds) is a lower bound of the k-th
+//           largest element, so { g >= T } is a small superset of the top-k: it is compacted with
+//           ballots into <= 64 candidates, ranked by counting, and the winners are emitted in
+//           ASCENDING point index (the order `points[samples != 0]` produces, ransac.py:65);
+//           pathological rows (> 64 candidates: massive ties) take a k-round arg-max slow path.
+// HBM traffic in fused mode: 4N bytes of logits (L2-resident across the B rows of a pair) in,
+// B(8k+4) bytes out.
+#include "dr_common.hpp"
+
+namespace dr {
+
+constexpr int kRowsPerBlock = 4;   // one wave per row
+constexpr int kMaxK = 8;
+constexpr int kMaxCand = 64;
+
+template <typename T>
+struct GumbelArgs {
+  const T *logits;   // [P,N] or null (ones)
+  const T *gumbel;   // [P,B,N] or null (Philox)
+  uint64_t seed;
+  T tau;
+  int P, B, N, k;
+};
+
+template <typename T> __device__ __forceinline__ T gumbel_from_bits_t(uint32_t bits);
+template <> __device__ __forceinline__ float gumbel_from_bits_t<float>(uint32_t bits) { return gumbel_from_bits(bits); }
+template <> __device__ __forceinline__ double gumbel_from_bits_t<double>(uint32_t bits) {
+  double r = (double)bits * 2.3283064365386963e-10;  // 2^-32, [0,1)
+  double u = r * (1.0 - 2.220446049250313e-16 - 2.2250738585072014e-308) + 2.2250738585072014e-308;
+  return -log(-log(u));
+}
+
+// g values of the 4-element group q (elements 4q..4q+3) of row (p,b)
+template <typename T>
+__device__ __forceinline__ void load_group(const GumbelArgs<T> &a, int p, int b, int q, T g[4], T noise[4]) {
+  const int n0 = 4 * q;
+  if (a.gumbel) {
+    const T *src = a.gumbel + ((size_t)p * a.B + b) * a.N + n0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) noise[j] = (n0 + j < a.N) ? src[j] : T(0);
+  } else {
+    uint32_t r[4];
+    Philox::gen(a.seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) noise[j] = gumbel_from_bits_t<T>(r[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    T l = a.logits ? ((n0 + j < a.N) ? a.logits[(size_t)p * a.N + n0 + j] : T(0)) : T(1);
+    g[j] = (n0 + j < a.N) ? (l + noise[j]) / a.tau : -INFINITY;
+  }
+}
+
+template <typename T> __device__ __forceinline__ T exp_t(T x);
+template <> __device__ __forceinline__ float exp_t<float>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ double exp_t<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T log_t(T x);
+template <> __device__ __forceinline__ float log_t<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ double log_t<double>(double x) { return log(x); }
+
+template <typename T, bool kCache>
+__global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelArgs<T> a, int32_t *__restrict__ idx,
+                                                                        T *__restrict__ y_sel, T *__restrict__ lse_out,
+                                                                        T *__restrict__ y_soft, T *__restrict__ ret,
+                                                                        T *__restrict__ gumbel_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ int s_win[kRowsPerBlock][kMaxK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
+  const int groups = (a.N + 3) >> 2;
+  // LDS carve: per wave [cand_val 64][cand_idx 64] then (kCache) g cache [4*groups]
+  T *cand_val = reinterpret_cast<T *>(smem_raw) + (size_t)wv * kMaxCand;
+  int *cand_idx = reinterpret_cast<int *>(reinterpret_cast<T *>(smem_raw) + (size_t)kRowsPerBlock * kMaxCand) + wv * kMaxCand;
+  T *gcache = reinterpret_cast<T *>(reinterpret_cast<int *>(reinterpret_cast<T *>(smem_raw) + (size_t)kRowsPerBlock * kMaxCand) +
+                                    kRowsPerBlock * kMaxCand) + (size_t)wv * groups * 4;
+  if (b >= a.B) return;  // whole wave exits together (no block-level barrier is used below)
+  const size_t row = ((size_t)p * a.B + b);
+
+  // ---------------- pass A: online soft-max + lane maximum
+  T mx = -INFINITY, sm = T(0), lmax = -INFINITY;
+  for (int q = lane; q < groups; q += 64) {
+    T g[4], nz[4];
+    load_group<T>(a, p, b, q, g, nz);
+    if (kCache) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gcache[4 * q + j] = g[j];
+    }
+    if (gumbel_out) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * q + j < a.N) gumbel_out[row * a.N + 4 * q + j] = nz[j];
+    }
+    T gm = fmax(fmax(g[0], g[1]), fmax(g[2], g[3]));
+    lmax = fmax(lmax, gm);
+    if (gm > mx) { sm *= exp_t<T>(mx - gm); mx = gm; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm += exp_t<T>(g[j] - mx);
+  }
+  // wave-wide soft-max statistics
+  T wmx = wave_max(mx);
+  sm *= (mx == -INFINITY) ? T(0) : exp_t<T>(mx - wmx);
+  sm = wave_sum(sm);
+  const T lse = wmx + log_t<T>(sm);
+
+  // ---------------- threshold: k-th largest lane maximum
+  T v = lmax, thr = -INFINITY;
+  for (int r = 0; r < a.k; ++r) {
+    thr = wave_max(v);
+    unsigned long long who = __ballot(v == thr);
+    if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
+  }
+
+  // ---------------- pass B: compact candidates { g >= thr }
+  int ncand = 0;
+  for (int q0 = 0; q0 < groups; q0 += 64) {
+    const int q = q0 + lane;
+    T g[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (q < groups) {
+      if (kCache) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gcache[4 * q + j];
+      } else {
+        T nz[4];
+        load_group<T>(a, p, b, q, g, nz);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool c = g[j] >= thr;
+      unsigned long long bal = __ballot(c);
+      if (bal) {
+        const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+        if (c && pos < kMaxCand) { cand_val[pos] = g[j]; cand_idx[pos] = 4 * q + j; }
+        ncand += __popcll(bal);
+      }
+    }
+  }
+
+  // the candidate list is read across lanes below: order the LDS writes before the reads
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  int *winp = &s_win[wv][0];   // winners' point indices, ascending
+  if (ncand <= kMaxCand) {
+    const bool have = lane < ncand;
+    const T cv = have ? cand_val[lane] : -INFINITY;
+    const int ci = have ? cand_idx[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < ncand; ++j) {
+      const T ov = cand_val[j];
+      const int oi = cand_idx[j];
+      rank += (ov > cv) || (ov == cv && oi < ci);
+    }
+    const bool win = have && rank < a.k;
+    // position among winners by ascending index
+    unsigned long long wb = __ballot(win);
+    int pos = 0;
+    for (int j = 0; j < ncand; ++j) {
+      if ((wb >> j) & 1ull) pos += cand_idx[j] < ci;
+    }
+    if (win) {
+      idx[row * a.k + pos] = ci;
+      y_sel[row * a.k + pos] = exp_t<T>(cv - lse);
+      s_win[wv][pos] = ci;
+    }
+  } else {
+    // slow path: k rounds of (value desc, index asc) arg-max with exclusion of earlier winners
+    int won[kMaxK];
+    T wong[kMaxK];
+    for (int r = 0; r < a.k; ++r) {
+      T bv = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int q = lane; q < groups; q += 64) {
+        T g[4], nz[4];
+        load_group<T>(a, p, b, q, g, nz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 4 * q + j;
+          bool skip = n >= a.N;
+          for (int s = 0; s < r; ++s) skip = skip || (won[s] == n);
+          if (!skip && (g[j] > bv || (g[j] == bv && n < bi))) { bv = g[j]; bi = n; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        T ov = __shfl_xor(bv, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      won[r] = bi;
+      wong[r] = bv;
+    }
+    if (lane < a.k) {
+      int me = 0;
+      T mg = T(0);
+      for (int r = 0; r < a.k; ++r) if (r == lane) { me = won[r]; mg = wong[r]; }
+      int pos = 0;
+      for (int r = 0; r < a.k; ++r) pos += won[r] < me;
+      idx[row * a.k + pos] = me;
+      y_sel[row * a.k + pos] = exp_t<T>(mg - lse);
+      s_win[wv][pos] = me;
+    }
+  }
+  if (lane == 0) lse_out[row] = lse;
+
+  // ---------------- optional dense outputs (API-faithful mode)
+  if (y_soft || ret) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int mine[kMaxK];
+    for (int r = 0; r < kMaxK; ++r) mine[r] = r < a.k ? winp[r] : -1;
+    for (int q = lane; q < groups; q += 64) {
+      T g[4];
+      if (kCache) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gcache[4 * q + j];
+      } else {
+        T nz[4];
+        load_group<T>(a, p, b, q, g, nz);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = 4 * q + j;
+        if (n >= a.N) continue;
+        const T y = exp_t<T>(g[j] - lse);
+        bool sel = false;
+#pragma unroll
+        for (int r = 0; r < kMaxK; ++r) sel = sel || (mine[r] == n);
+        if (y_soft) y_soft[row * a.N + n] = y;
+        if (ret) ret[row * a.N + n] = ((sel ? T(1) : T(0)) - y) + y;   // gumbel_sampler.py:38
+      }
+    }
+  }
+}
+
+template <typename T>
+int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
+                      int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st) {
+  GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k};
+  const int groups = (N + 3) / 4;
+  const size_t base = (size_t)kRowsPerBlock * kMaxCand * (sizeof(T) + sizeof(int));
+  const size_t cache = (size_t)kRowsPerBlock * groups * 4 * sizeof(T);
+  dim3 grid((B + kRowsPerBlock - 1) / kRowsPerBlock, P);
+  dim3 block(kRowsPerBlock * 64);
+  if (base + cache <= 64 * 1024)
+    hipLaunchKernelGGL((gumbel_topk_kernel<T, true>), grid, block, base + cache, st, a, idx, y_sel, lse, y_soft, ret,
+                       gumbel_out);
+  else
+    hipLaunchKernelGGL((gumbel_topk_kernel<T, false>), grid, block, base, st, a, idx, y_sel, lse, y_soft, ret,
+                       gumbel_out);
+  return check_launch("gumbel_topk_kernel");
+}
+
+// ---- backward of K1 (+K2):  grad_logits[p,n] = (1/tau) sum_b y_bn (a_bn - sum_m y_bm a_bm), a non-zero only at idx
+template <typename T>
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const int32_t *__restrict__ idx,
+                                                         const T *__restrict__ lse, const T *__restrict__ a_sel,
+                                                         T *__restrict__ grad_logits) {
+  // one thread per 4-point group of pair p (one Philox call regenerates its noise); loops over the B rows,
+  // 256 at a time, whose k winners / a values / <y,a> are staged in LDS by the block.
+  const int p = blockIdx.y;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *s_dot = reinterpret_cast<T *>(smem_raw);               // [256]   sum_m y_m a_m per row
+  T *s_lse = s_dot + 256;
+  T *s_a = s_lse + 256;                                     // [256][kMaxK]
+  int *s_i = reinterpret_cast<int *>(s_a + 256 * kMaxK);    // [256][kMaxK]
+  const int groups = (a.N + 3) >> 2;
+  T l[4], acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = 4 * q + j;
+    l[j] = (n < a.N) ? (a.logits ? a.logits[(size_t)p * a.N + n] : T(1)) : T(0);
+  }
+  for (int b0 = 0; b0 < a.B; b0 += 256) {
+    const int nb = min(256, a.B - b0);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const size_t row = (size_t)p * a.B + b0 + threadIdx.x;
+      const T ls = lse[row];
+      T dot = T(0);
+      for (int j = 0; j < kMaxK; ++j) {
+        T av = T(0);
+        int i = -1;
+        if (j < a.k) {
+          i = idx[row * a.k + j];
+          av = a_sel[row * a.k + j];
+          // y at the selected index is recomputed from (logit, noise): y = exp(g - lse)
+          T nz;
+          if (a.gumbel) nz = a.gumbel[row * a.N + i];
+          else {
+            uint32_t r[4];
+            Philox::gen(a.seed, (uint32_t)(i >> 2), (uint32_t)(b0 + threadIdx.x), (uint32_t)p, 0u, r);
+            nz = gumbel_from_bits_t<T>(r[i & 3]);
+          }
+          const T li = a.logits ? a.logits[(size_t)p * a.N + i] : T(1);
+          dot += exp_t<T>((li + nz) / a.tau - ls) * av;
+        }
+        s_a[threadIdx.x * kMaxK + j] = av;
+        s_i[threadIdx.x * kMaxK + j] = i;
+      }
+      s_dot[threadIdx.x] = dot;
+      s_lse[threadIdx.x] = ls;
+    }
+    __syncthreads();
+    if (q < groups) {
+      for (int r = 0; r < nb; ++r) {
+        const int b = b0 + r;
+        T nz[4];
+        if (a.gumbel) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) nz[j] = (4 * q + j < a.N) ? a.gumbel[((size_t)p * a.B + b) * a.N + 4 * q + j] : T(0);
+        } else {
+          uint32_t rr[4];
+          Philox::gen(a.seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) nz[j] = gumbel_from_bits_t<T>(rr[j]);
+        }
+        const T ls = s_lse[r], dot = s_dot[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 4 * q + j;
+          const T y = exp_t<T>((l[j] + nz[j]) / a.tau - ls);
+          T an = T(0);
+#pragma unroll
+          for (int t = 0; t < kMaxK; ++t) an += (s_i[r * kMaxK + t] == n) ? s_a[r * kMaxK + t] : T(0);
+          acc[j] += y * (an - dot);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * q + j < a.N) grad_logits[(size_t)p * a.N + 4 * q + j] = acc[j] / a.tau;
+}
+
+// ---- K1u: uniform indices in [0, N-2]
+__global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_t *__restrict__ idx) {
+  const int p = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // over B*k
+  if (t >= B * k) return;
+  const int b = t / k, j = t % k;
+  uint32_t r[4];
+  Philox::gen(seed, (uint32_t)j, (uint32_t)b, (uint32_t)p, 1u, r);
+  const uint32_t span = (uint32_t)max(N - 1, 1);
+  idx[((size_t)p * B + b) * k + j] = (int32_t)(((uint64_t)r[0] * span) >> 32);
+}
+
+// ---- K2 gather forward / backward
+template <typename T>
+__global__ void gather_fwd_kernel(const T *__restrict__ matches, const int32_t *__restrict__ idx,
+                                  const T *__restrict__ y_sel, int N, int BK, int c, T *__restrict__ samples) {
+  const int p = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // over B*k
+  if (t >= BK) return;
+  const size_t e = (size_t)p * BK + t;
+  const int i = idx[e];
+  T st = T(1);
+  if (y_sel) { const T y = y_sel[e]; st = (T(1) - y) + y; }
+  const T *src = matches + ((size_t)p * N + i) * c;
+  T *dst = samples + e * c;
+  for (int d = 0; d < c; ++d) dst[d] = src[d] * st;
+}
+
+template <typename T>
+__global__ void gather_bwd_kernel(const T *__restrict__ matches, const int32_t *__restrict__ idx,
+                                  const T *__restrict__ y_sel, const T *__restrict__ grad_samples,
+                                  const T *__restrict__ grad_w, int N, int BK, int c, T *__restrict__ a_sel,
+                                  T *__restrict__ grad_matches) {
+  const int p = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= BK) return;
+  const size_t e = (size_t)p * BK + t;
+  const int i = idx[e];
+  T st = T(1);
+  if (y_sel) { const T y = y_sel[e]; st = (T(1) - y) + y; }
+  const T *m = matches + ((size_t)p * N + i) * c;
+  const T *g = grad_samples + e * c;
+  T dot = T(0);
+  for (int d = 0; d < c; ++d) dot += g[d] * m[d];
+  if (grad_w) dot += grad_w[e];
+  a_sel[e] = dot;
+  if (grad_matches)
+    for (int d = 0; d < c; ++d) atomicAdd(grad_matches + ((size_t)p * N + i) * c + d, g[d] * st);
+}
+
+}  // namespace dr
+
+extern "C" {
+
+#define DR_GUMBEL_CHECK()                                                          \
+  DR_REQUIRE(idx && y_sel && lse, "null output pointer");                          \
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535, "bad sizes");                  \
+  DR_REQUIRE(k >= 1 && k <= dr::kMaxK && k <= N, "k must be in [1, 8] and <= N");  \
+  DR_REQUIRE(tau > 0, "tau must be positive")
+
+int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
+                           int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,
+                           float *gumbel_out, void *stream) {
+  DR_GUMBEL_CHECK();
+  return dr::gumbel_fwd_launch<float>(logits, gumbel, seed, tau, P, B, N, k, idx, y_sel, lse, y_soft, ret, gumbel_out,
+                                      (hipStream_t)stream);
+}
+
+int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B,
+                           int N, int k, int32_t *idx, double *y_sel, double *lse, double *y_soft, double *ret,
+                           double *gumbel_out, void *stream) {
+  DR_GUMBEL_CHECK();
+  return dr::gumbel_fwd_launch<double>(logits, gumbel, seed, tau, P, B, N, k, idx, y_sel, lse, y_soft, ret,
+                                       gumbel_out, (hipStream_t)stream);
+}
+
+int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
+                           int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
+                           void *stream) {
+  DR_REQUIRE(idx && lse && a_sel && grad_logits, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
+  dr::GumbelArgs<float> a{logits, gumbel, seed, tau, P, B, N, k};
+  const size_t smem = sizeof(float) * (256 * 2 + 256 * dr::kMaxK) + sizeof(int) * 256 * dr::kMaxK;
+  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(((N + 3) / 4 + 255) / 256, P), dim3(256), smem,
+                     (hipStream_t)stream, a, idx, lse, a_sel, grad_logits);
+  return dr::check_launch("gumbel_bwd_kernel");
+}
+
+int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream) {
+  DR_REQUIRE(idx, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && k > 0 && N > 1 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL(dr::uniform_sample_kernel, dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, seed,
+                     B, k, N, idx);
+  return dr::check_launch("uniform_sample_kernel");
+}
+
+int dr_gather_fwd_f32(const float *matches, const int32_t *idx, const float *y_sel, int P, int N, int B, int k,
+                      int c, float *samples, void *stream) {
+  DR_REQUIRE(matches && idx && samples, "null pointer");
+  DR_REQUIRE(P > 0 && N > 0 && B > 0 && k > 0 && c > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
+                     matches, idx, y_sel, N, B * k, c, samples);
+  return dr::check_launch("gather_fwd_kernel");
+}
+
+int dr_gather_fwd_f64(const double *matches, const int32_t *idx, const double *y_sel, int P, int N, int B, int k,
+                      int c, double *samples, void *stream) {
+  DR_REQUIRE(matches && idx && samples, "null pointer");
+  DR_REQUIRE(P > 0 && N > 0 && B > 0 && k > 0 && c > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::gather_fwd_kernel<double>), dim3((B * k + 255) / 256, P), dim3(256), 0,
+                     (hipStream_t)stream, matches, idx, y_sel, N, B * k, c, samples);
+  return dr::check_launch("gather_fwd_kernel");
+}
+
+int dr_gather_bwd_f32(const float *matches, const int32_t *idx, const float *y_sel, const float *grad_samples,
+                      const float *grad_w, int P, int N, int B, int k, int c, float *a_sel, float *grad_matches,
+                      void *stream) {
+  DR_REQUIRE(matches && idx && grad_samples && a_sel, "null pointer");
+  DR_REQUIRE(P > 0 && N > 0 && B > 0 && k > 0 && c > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::gather_bwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
+                     matches, idx, y_sel, grad_samples, grad_w, N, B * k, c, a_sel, grad_matches);
+  return dr::check_launch("gather_bwd_kernel");
+}
+
+}  // extern "C"

@@ -54,3 +54,106 @@ def select_best(matches: torch.Tensor, models: torch.Tensor, scores: torch.Tenso
            ptr(scores.contiguous()), ptr(thr), c_int(P), c_int(M), c_int(N), ptr(best_idx), ptr(best_score),
            ptr(best_model), ptr(best_mask), ptr(inliers), stream())
     return best_idx, best_score, best_model, best_mask, inliers
+
+
+# ------------------------------------------------------------------------------------------ K1 / K1u / K2
+def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0,
+                gumbel: Optional[torch.Tensor] = None, seed: int = 0, N: Optional[int] = None,
+                dense: bool = False, want_noise: bool = False, device=None, dtype=torch.float32):
+    """K1 forward.  logits [P,N] (or None = all-ones, then pass N/device/dtype); gumbel [P,B,N] explicit
+    noise or None (in-kernel Philox keyed by `seed`).
+
+    Returns dict(idx [P,B,k] int32 ascending, y_sel [P,B,k], lse [P,B]) plus, when `dense`,
+    y_soft / ret [P,B,N], and when `want_noise`, gumbel [P,B,N] (the noise the kernel used)."""
+    if logits is not None:
+        logits = logits.contiguous()
+        P, N = logits.shape
+        device, dtype = logits.device, logits.dtype
+    else:
+        P = 1 if gumbel is None else gumbel.shape[0]
+        assert N is not None and device is not None
+    if gumbel is not None:
+        gumbel = gumbel.contiguous()
+        assert gumbel.shape == (P, B, N) and gumbel.dtype == dtype
+    idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
+    y_sel = torch.empty((P, B, k), device=device, dtype=dtype)
+    lse = torch.empty((P, B), device=device, dtype=dtype)
+    y_soft = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
+    ret = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
+    noise = torch.empty((P, B, N), device=device, dtype=dtype) if want_noise else None
+    L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", ptr(logits), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
+           L.scalar(dtype, tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(y_sel), ptr(lse), ptr(y_soft),
+           ptr(ret), ptr(noise), stream())
+    out = dict(idx=idx, y_sel=y_sel, lse=lse)
+    if dense:
+        out.update(y_soft=y_soft, ret=ret)
+    if want_noise:
+        out["gumbel"] = noise
+    return out
+
+
+def gumbel_topk_bwd(logits, gumbel, seed, tau, idx, lse, a_sel):
+    """grad_logits [P,N] from a_sel [P,B,k] (f32 only)."""
+    P, B, k = idx.shape
+    N = logits.shape[1]
+    grad = torch.empty_like(logits)
+    L.call("dr_gumbel_topk_bwd_f32", ptr(logits.contiguous()), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
+           L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(lse), ptr(a_sel.contiguous()),
+           ptr(grad), stream())
+    return grad
+
+
+def uniform_sample(P: int, B: int, k: int, N: int, seed: int, device) -> torch.Tensor:
+    """K1u: idx [P,B,k] int32 ~ U{0..N-2} (uniform_sampler.py:15-19 semantics)."""
+    idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
+    L.call("dr_uniform_sample", c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(k), c_int(N), ptr(idx),
+           stream())
+    return idx
+
+
+def gather(matches: torch.Tensor, idx: torch.Tensor, y_sel: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K2 forward: matches [P,N,c], idx [P,B,k] -> samples [P,B,k,c] (times the straight-through value)."""
+    P, N, c = matches.shape
+    _, B, k = idx.shape
+    out = torch.empty((P, B, k, c), device=matches.device, dtype=matches.dtype)
+    L.call(f"dr_gather_fwd_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(idx), ptr(y_sel), c_int(P),
+           c_int(N), c_int(B), c_int(k), c_int(c), ptr(out), stream())
+    return out
+
+
+def gather_bwd(matches, idx, y_sel, grad_samples, grad_w=None, want_grad_matches=False):
+    P, N, c = matches.shape
+    _, B, k = idx.shape
+    a_sel = torch.empty((P, B, k), device=matches.device, dtype=matches.dtype)
+    gm = torch.zeros_like(matches) if want_grad_matches else None
+    L.call("dr_gather_bwd_f32", ptr(matches.contiguous()), ptr(idx), ptr(y_sel), ptr(grad_samples.contiguous()),
+           ptr(None if grad_w is None else grad_w.contiguous()), c_int(P), c_int(N), c_int(B), c_int(k), c_int(c),
+           ptr(a_sel), ptr(gm), stream())
+    return a_sel, gm
+
+
+class SampleGather(torch.autograd.Function):
+    """K1+K2 fused at the autograd level: (matches [P,N,c], logits [P,N]) -> samples [P,B,k,c], weights [P,B,k].
+
+    Forward: dr_gumbel_topk_fwd + dr_gather_fwd (no [B,N] tensor is materialised).
+    Backward: dr_gather_bwd -> a_sel, dr_gumbel_topk_bwd -> grad_logits (f32)."""
+
+    @staticmethod
+    def forward(ctx, matches, logits, B, k, tau, gumbel, seed):
+        r = gumbel_topk(logits, B, k, tau, gumbel, seed)
+        samples = gather(matches, r["idx"], r["y_sel"])
+        ctx.save_for_backward(matches, logits, r["idx"], r["y_sel"], r["lse"], gumbel if gumbel is not None else
+                              torch.empty(0, device=logits.device))
+        ctx.cfg = (tau, seed, gumbel is not None)
+        ctx.mark_non_differentiable(r["idx"])
+        return samples, r["y_sel"], r["idx"]
+
+    @staticmethod
+    def backward(ctx, g_samples, g_w, _g_idx):
+        matches, logits, idx, y_sel, lse, gumbel = ctx.saved_tensors
+        tau, seed, has_noise = ctx.cfg
+        if logits.dtype != torch.float32:
+            raise L.DransacError("backward is implemented for f32 only")
+        a_sel, gm = gather_bwd(matches, idx, y_sel, g_samples, g_w, want_grad_matches=ctx.needs_input_grad[0])
+        gl = gumbel_topk_bwd(logits, gumbel if has_noise else None, seed, tau, idx, lse, a_sel)
+        return gm, gl, None, None, None, None, None
