@@ -49,9 +49,11 @@ __device__ __forceinline__ T wave_max(T v) {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 
+// NOTE: never test finiteness with (x - x) == 0: under -ffp-contract=fast the backend may fuse the producer
+// of x into the subtraction (fma(a, b, c - x)) and the "difference" is then a rounding residue, not zero.
 template <typename T>
 __device__ __forceinline__ bool is_finite(T x) {
-  return (x - x) == T(0);
+  return __builtin_isfinite(x);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11).  Counter-based: the oracle-side restatement lives in

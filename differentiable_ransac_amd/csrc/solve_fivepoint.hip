@@ -1,0 +1,562 @@
+// K3n / K3s -- five-point essential-matrix solvers.
+//   Nister:    EssentialMatrixEstimatorNister.estimate_minimal_model, nister.py:69-408
+//   Stewenius: EssentialMatrixEstimator.estimate_minimal_model,       stewenius.py:20-80
+//
+// One lane = one minimal sample, one 64-lane block per 64 samples; f64 arithmetic.  The 10x20
+// constraint matrix (and the 10x10 action matrix of Stewenius) needs pivot-dependent indexing and
+// lives in LDS (200 doubles per lane = 100 KiB per block, lane-minor => bank-conflict free);
+// everything else (null-space basis, B(z), the degree-10 polynomial, the roots) stays in VGPRs.
+// Where the reference runs a per-sample Python loop with LAPACK eigvals / inverse / qr, this is one
+// launch: Householder null space -> constraints -> Gauss-Jordan -> det B(z) -> real roots by
+// derivative-interlaced safeguarded Newton -> back-substitution.
+#include "solver_common.hpp"
+
+namespace dr {
+
+constexpr int kFiveWs = 200;   // doubles of LDS per lane (Nister: the 10x20 matrix)
+constexpr int kStewWs = 212;   // Stewenius: 10x20, then Hessenberg 10x10 (0..99) + La Budde polynomials (100..209)
+
+// ---- null-space basis ---------------------------------------------------------------------------------
+// minimal: Householder QR of the 5x9 system (registers).  nb[t][0..8], t = 0..3
+template <typename T>
+__device__ __forceinline__ void fivepoint_basis_minimal(const T *__restrict__ pts, const T *__restrict__ wts,
+                                                        double (&nb)[4][9]) {
+  double A[5][9];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const double w = wts ? (double)wts[r] : 1.0;
+    epipolar_row_5pt((double)pts[4 * r], (double)pts[4 * r + 1], (double)pts[4 * r + 2], (double)pts[4 * r + 3], w, A[r]);
+  }
+  null_space_qr<5>(A, nb);
+}
+
+// non-minimal (n > 5; nister.py:64-65 runs the minimal code on all points): the four eigenvectors of A^T A
+// with the smallest eigenvalues, by cyclic Jacobi in LDS.  Order: nb[0] <-> 4th smallest ... nb[3] <-> smallest,
+// which is the order torch.linalg.svd's Vh[-4:] has.
+template <typename T>
+__device__ void fivepoint_basis_nonminimal(const T *__restrict__ pts, const T *__restrict__ wts, int n,
+                                           const LaneWs &ws, double (&nb)[4][9]) {
+  LaneWs A{ws.base}, V{ws.base + 81 * 64};
+  for (int e = 0; e < 81; ++e) A[e] = 0.0;
+  for (int r = 0; r < n; ++r) {
+    double row[9];
+    const double w = wts ? (double)wts[r] : 1.0;
+    epipolar_row_5pt((double)pts[4 * r], (double)pts[4 * r + 1], (double)pts[4 * r + 2], (double)pts[4 * r + 3], w, row);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) A[i * 9 + j] += row[i] * row[j];
+  }
+  jacobi_eig_lds<9>(A, V);
+  unsigned used = 0;
+  for (int t = 3; t >= 0; --t) {  // t = 3 takes the smallest
+    int best = 0;
+    double bv = INFINITY;
+    for (int i = 0; i < 9; ++i) {
+      const double ev = A[i * 9 + i];
+      if (!((used >> i) & 1u) && ev < bv) { bv = ev; best = i; }
+    }
+    used |= 1u << best;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double v = V[i * 9 + best];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        if (tt == t) nb[tt][i] = v;
+    }
+  }
+}
+
+// entry polynomial (i,j) of E~(x,y,z) = x N0 + y N1 + z N2 + N3 is (N0..N3)[3j+i]  (nister.py:123, stewenius.py:53)
+__device__ __forceinline__ void basis_to_entries(const double (&nb)[4][9], double (&e)[3][3][4]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) e[i][j][t] = nb[t][3 * j + i];
+}
+
+template <typename T>
+__device__ __forceinline__ void write_identity(T *__restrict__ dst) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) dst[q] = T(q % 4 == 0 ? 1 : 0);
+}
+
+// Gauss-Newton refinement of (x, y, z) on the ten defining constraints 2EE^TE - tr(EE^T)E = 0, det E = 0 with
+// E = x N0 + y N1 + z N2 + N3.  The hidden-variable resultant (Nister) and the action-matrix eigen-problem
+// (Stewenius) can lose digits when roots cluster; the constraint system itself is well conditioned wherever
+// the essential matrix is, so two iterations restore full f64 accuracy (and are basis independent).
+__device__ __forceinline__ void essential_residual(const double (&E)[9], double (&r)[10]) {
+  double G[9];  // E E^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[3 * i + j] = E[3 * i] * E[3 * j] + E[3 * i + 1] * E[3 * j + 1] + E[3 * i + 2] * E[3 * j + 2];
+  const double tr = G[0] + G[4] + G[8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      r[3 * i + j] = 2.0 * (G[3 * i] * E[j] + G[3 * i + 1] * E[3 + j] + G[3 * i + 2] * E[6 + j]) - tr * E[3 * i + j];
+  r[9] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
+}
+
+__device__ __forceinline__ void polish_xyz(const double (&nb)[4][9], double &x, double &y, double &z) {
+#pragma unroll 1
+  for (int it = 0; it < 3; ++it) {
+    double E[9], r[10];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) E[q] = x * nb[0][q] + y * nb[1][q] + z * nb[2][q] + nb[3][q];
+    essential_residual(E, r);
+    double n0 = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
+    // directional derivatives along N0, N1, N2 by the exact polynomial identity D r[H] (r is cubic in E):
+    double J[3][10];
+    double EEt[9], EtE[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        EEt[3 * i + j] = E[3 * i] * E[3 * j] + E[3 * i + 1] * E[3 * j + 1] + E[3 * i + 2] * E[3 * j + 2];
+        EtE[3 * i + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+      }
+    const double tr = EEt[0] + EEt[4] + EEt[8];
+    const double cof[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
+                           E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
+                           E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double(&H)[9] = nb[k];
+      // A = H E^T (3x3), then D = 2(H EtE + (A + A^T)... ) expanded:  H E^T E + E H^T E + E E^T H
+      double HEt[9];
+      double trEHt = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          HEt[3 * i + j] = H[3 * i] * E[3 * j] + H[3 * i + 1] * E[3 * j + 1] + H[3 * i + 2] * E[3 * j + 2];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) trEHt += E[q] * H[q];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double t1 = H[3 * i] * EtE[j] + H[3 * i + 1] * EtE[3 + j] + H[3 * i + 2] * EtE[6 + j];          // H E^T E
+          const double t2 = HEt[i] * E[j] + HEt[3 + i] * E[3 + j] + HEt[6 + i] * E[6 + j];                       // E H^T E = (H E^T)^T E
+          const double t3 = EEt[3 * i] * H[j] + EEt[3 * i + 1] * H[3 + j] + EEt[3 * i + 2] * H[6 + j];          // E E^T H
+          J[k][3 * i + j] = 2.0 * (t1 + t2 + t3) - 2.0 * trEHt * E[3 * i + j] - tr * H[3 * i + j];
+        }
+      double dd = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
+      J[k][9] = dd;
+    }
+    // normal equations (3x3, symmetric) by Cramer
+    double a[3][3], g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      g[i] = 0;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) g[i] += J[i][q] * r[q];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        a[i][j] = 0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) a[i][j] += J[i][q] * J[j][q];
+      }
+    }
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    const double dx = (g[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (g[1] * a[2][2] - a[1][2] * g[2]) +
+                       a[0][2] * (g[1] * a[2][1] - a[1][1] * g[2])) / det;
+    const double dy = (a[0][0] * (g[1] * a[2][2] - a[1][2] * g[2]) - g[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * g[2] - g[1] * a[2][0])) / det;
+    const double dz = (a[0][0] * (a[1][1] * g[2] - g[1] * a[2][1]) - a[0][1] * (a[1][0] * g[2] - g[1] * a[2][0]) +
+                       g[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0])) / det;
+    const double nx = x - dx, ny = y - dy, nz = z - dz;
+    // accept only a step that does not increase the residual
+    double E2[9], r2[10], n1 = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) E2[q] = nx * nb[0][q] + ny * nb[1][q] + nz * nb[2][q] + nb[3][q];
+    essential_residual(E2, r2);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
+    if (n1 <= n0 && is_finite(n1)) { x = nx; y = ny; z = nz; }
+  }
+}
+
+// E = (x N0 + y N1 + z N2 + N3)/||.||, stored TRANSPOSED (nister.py:407): out[i][j] = E~_flat[3j+i]
+template <typename T>
+__device__ __forceinline__ void write_model(const double (&nb)[4][9], double x, double y, double z, T *__restrict__ dst) {
+  double f[9], n2 = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    f[q] = x * nb[0][q] + y * nb[1][q] + z * nb[2][q] + nb[3][q];
+    n2 += f[q] * f[q];
+  }
+  const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dst[3 * i + j] = (T)(f[3 * j + i] * inv);
+}
+
+// ---- Nister: B(z) from the reduced rows, det B(z), roots, back-substitution -----------------------------
+template <typename T>
+__device__ void nister_finish(const double (&nb)[4][9], const LaneWs &w, bool ok, T *__restrict__ models,
+                              uint8_t *__restrict__ valid, bool active) {
+  // reduced rows e..j = rows 4..9, right block columns 10..19 hold (x z^2, x z, x | y z^2, y z, y | z^3, z^2, z, 1)
+  // k = e - z f, l = g - z h, m = i - z j  ->  B(z) columns (x: deg 3, y: deg 3, 1: deg 4), ascending coefficients
+  double bx[3][4], by[3][4], b1[3][5];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double hi[10], lo[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      hi[c] = w[(4 + 2 * r) * 20 + 10 + c];
+      lo[c] = w[(5 + 2 * r) * 20 + 10 + c];
+    }
+    // hi = (a2 z^2 + a1 z + a0) with hi[0]=a2,hi[1]=a1,hi[2]=a0 ; minus z*(lo)
+    bx[r][0] = hi[2];          bx[r][1] = hi[1] - lo[2]; bx[r][2] = hi[0] - lo[1]; bx[r][3] = -lo[0];
+    by[r][0] = hi[5];          by[r][1] = hi[4] - lo[5]; by[r][2] = hi[3] - lo[4]; by[r][3] = -lo[3];
+    b1[r][0] = hi[9];          b1[r][1] = hi[8] - lo[9]; b1[r][2] = hi[7] - lo[8]; b1[r][3] = hi[6] - lo[7];
+    b1[r][4] = -lo[6];
+  }
+  // det = sum_r c2[r] * cofactor_r ; minors of columns (x,y): degree 6
+  double cs[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) cs[i] = 0;
+  auto minor_acc = [&](int a, int b, int r, double sgn) {
+    double mn[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) mn[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mn[i + j] += bx[a][i] * by[b][j] - bx[b][i] * by[a][j];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) cs[i + j] += sgn * mn[i] * b1[r][j];
+  };
+  minor_acc(1, 2, 0, 1.0);
+  minor_acc(0, 2, 1, -1.0);
+  minor_acc(0, 1, 2, 1.0);
+
+  double roots[10];
+  unsigned mask;
+  real_roots<10>(cs, roots, mask);
+  if (!ok) mask = 0;
+
+  int slot = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    if (!((mask >> i) & 1u)) continue;
+    const double z = roots[i];
+    // rows of B(z): (bx(z), by(z), b1(z)) . (x, y, 1) = 0 ; null vector = best-conditioned cross product
+    double rx[3], ry[3], r1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      rx[r] = ((bx[r][3] * z + bx[r][2]) * z + bx[r][1]) * z + bx[r][0];
+      ry[r] = ((by[r][3] * z + by[r][2]) * z + by[r][1]) * z + by[r][0];
+      r1[r] = (((b1[r][4] * z + b1[r][3]) * z + b1[r][2]) * z + b1[r][1]) * z + b1[r][0];
+    }
+    double bestn = -1, vx = 0, vy = 0, vw = 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 3; ++b) {
+        const double cx = ry[a] * r1[b] - r1[a] * ry[b];
+        const double cy = r1[a] * rx[b] - rx[a] * r1[b];
+        const double cw = rx[a] * ry[b] - ry[a] * rx[b];
+        const double nn = cw * cw;  // we divide by the w component: pick the largest
+        if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
+      }
+    const double x = vx / vw, y = vy / vw;
+    const bool good = is_finite(x) && is_finite(y);
+    double px = x, py = y, pz = z;
+    if (good) polish_xyz(nb, px, py, pz);
+    if (good && active) {
+      write_model<T>(nb, px, py, pz, models + 9 * slot);
+      valid[slot] = 1;
+    }
+    slot += good ? 1 : 0;
+  }
+  if (active) {
+    for (int s = slot; s < 10; ++s) {
+      write_identity<T>(models + 9 * s);
+      valid[s] = 0;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void nister5_kernel(const T *__restrict__ samples, const T *__restrict__ weights,
+                                                     int Bt, int n, T *__restrict__ models,
+                                                     uint8_t *__restrict__ valid) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x * 64 + lane;
+  const bool active = s < Bt;
+  const int sc = active ? s : Bt - 1;
+  LaneWs w{lds + lane};
+  const T *pts = samples + (size_t)sc * n * 4;
+  const T *wts = weights ? weights + (size_t)sc * n : nullptr;
+  double nb[4][9];
+  if (n == 5) fivepoint_basis_minimal<T>(pts, wts, nb);
+  else fivepoint_basis_nonminimal<T>(pts, wts, n, w, nb);
+  double e[3][3][4];
+  basis_to_entries(nb, e);
+  build_constraints<NisterOrder>(e, w, 1.0);
+  const bool ok = gauss_jordan_lds<10, 20>(w);
+  nister_finish<T>(nb, w, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active);
+}
+
+// ---- Stewenius ---------------------------------------------------------------------------------------------
+// Action matrix M (10x10): rows 0-5 <- reduced rows 0,1,2,4,5,7; M[6][0] = M[7][1] = M[8][3] = M[9][6] = -1
+// (stewenius.py:64-72).  M v = lambda v with v ~ (x^2, xy, y^2, xz, yz, z^2, x, y, z, 1), lambda = -x.
+// Eigenvalues: Householder-Hessenberg + La Budde's recurrence give the characteristic polynomial, whose real
+// roots come from the same root finder; the eigenvector follows from rows 0-5 of (M - lambda I) v = 0 with
+// the structural rows substituted (unknowns y^2, yz, z^2, y, z).
+template <typename T>
+__global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ samples, int Bt,
+                                                        T *__restrict__ models, uint8_t *__restrict__ valid) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x * 64 + lane;
+  const bool active = s < Bt;
+  const int sc = active ? s : Bt - 1;
+  LaneWs w{lds + lane};
+  double nb[4][9];
+  fivepoint_basis_minimal<T>(samples + (size_t)sc * 20, nullptr, nb);
+  double e[3][3][4];
+  basis_to_entries(nb, e);
+  build_constraints<GrevlexOrder>(e, w, 2.0);
+  bool ok = gauss_jordan_lds<10, 20>(w);
+
+  // G rows (right block) needed by the action matrix, kept in registers: g[r][c], r in {0,1,2,4,5,7}
+  double g[6][10];
+  {
+    const int src[6] = {0, 1, 2, 4, 5, 7};
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 10; ++c) g[r][c] = w[src[r] * 20 + 10 + c];
+  }
+  // H = action matrix in LDS (elements 0..99), reduce to upper Hessenberg by Householder similarity
+  LaneWs H{w.base};
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) H[r * 10 + c] = g[r][c];
+  for (int r = 6; r < 10; ++r)
+    for (int c = 0; c < 10; ++c) H[r * 10 + c] = 0.0;
+  H[6 * 10 + 0] = -1.0; H[7 * 10 + 1] = -1.0; H[8 * 10 + 3] = -1.0; H[9 * 10 + 6] = -1.0;
+  for (int k = 0; k < 8; ++k) {
+    double v[10];
+    double nrm2 = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      v[i] = (i > k) ? H[i * 10 + k] : 0.0;
+      nrm2 += v[i] * v[i];
+    }
+    double x0 = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) if (i == k + 1) x0 = v[i];
+    const double alpha = -dsign(sqrt(nrm2), x0);
+    const double v0 = x0 - alpha;
+    const double vtv = v0 * v0 + (nrm2 - x0 * x0);
+    const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) if (i == k + 1) v[i] = v0;
+    // H <- (I - beta v v^T) H (I - beta v v^T)
+    for (int c = 0; c < 10; ++c) {
+      double dot = 0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) dot += v[i] * H[i * 10 + c];
+      dot *= beta;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) if (i > k) H[i * 10 + c] -= dot * v[i];
+    }
+    for (int r = 0; r < 10; ++r) {
+      double dot = 0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) dot += H[r * 10 + i] * v[i];
+      dot *= beta;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) if (i > k) H[r * 10 + i] -= dot * v[i];
+    }
+  }
+  // La Budde: p_0 = 1, p_i(l) = (l - h_ii) p_{i-1} - sum_{m=1}^{i-1} h_{i-m,i} (prod_{j=i-m+1}^{i} h_{j,j-1}) p_{i-m-1}
+  // (1-based).  Coefficients ascending, P[i][0..i] stored in LDS elements 100 + i*11 ...
+  LaneWs P{w.base + 100 * 64};
+  for (int e2 = 0; e2 < 110; ++e2) P[e2] = 0.0;
+  P[0] = 1.0;  // p_0
+  for (int i = 1; i <= 9; ++i) {
+    // p_i for i = 1..9 kept in LDS; p_10 assembled in registers below
+    const double hii = H[(i - 1) * 10 + (i - 1)];
+    for (int t = 0; t <= i; ++t) {
+      const double up = (t > 0) ? P[(i - 1) * 11 + t - 1] : 0.0;
+      const double same = (t <= i - 1) ? P[(i - 1) * 11 + t] : 0.0;
+      P[i * 11 + t] = up - hii * same;
+    }
+    double prod = 1.0;
+    for (int m = 1; m <= i - 1; ++m) {
+      prod *= H[(i - m) * 10 + (i - m - 1)];  // h_{i-m+1, i-m} (1-based) = H[i-m][i-m-1] (0-based)
+      const double coef = H[(i - m - 1) * 10 + (i - 1)] * prod;  // h_{i-m, i}
+      for (int t = 0; t <= i - m - 1; ++t) P[i * 11 + t] -= coef * P[(i - m - 1) * 11 + t];
+    }
+  }
+  double cs[11];
+  {
+    const int i = 10;
+    const double hii = H[9 * 10 + 9];
+#pragma unroll
+    for (int t = 0; t <= 10; ++t) {
+      const double up = (t > 0) ? P[9 * 11 + t - 1] : 0.0;
+      const double same = (t <= 9) ? P[9 * 11 + t] : 0.0;
+      cs[t] = up - hii * same;
+    }
+    double prod = 1.0;
+    for (int m = 1; m <= i - 1; ++m) {
+      prod *= H[(i - m) * 10 + (i - m - 1)];
+      const double coef = H[(i - m - 1) * 10 + (i - 1)] * prod;
+#pragma unroll
+      for (int t = 0; t <= 10; ++t)
+        if (t <= i - m - 1) cs[t] -= coef * P[(i - m - 1) * 11 + t];
+    }
+  }
+  double roots[10];
+  unsigned mask;
+  real_roots<10>(cs, roots, mask);
+  if (!ok) mask = 0;
+
+  T *mdl = models + (size_t)sc * 90;
+  uint8_t *vld = valid + (size_t)sc * 10;
+  int slot = 0;
+  LaneWs K{w.base};  // 6 x 6 augmented system, reuses the Hessenberg area
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    if (!__any((mask >> i) & 1u)) continue;
+    const bool has = (mask >> i) & 1u;
+    const double lam = roots[i];
+    const double l2 = lam * lam;
+    // unknown order u = (v2, v4, v5, v7, v8) ; column 5 = right-hand side (minus the constant term)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double c2 = g[r][2], c4 = g[r][4], c5 = g[r][5];
+      double c7 = g[r][7] - lam * g[r][1];
+      double c8 = g[r][8] - lam * g[r][3];
+      double k0 = g[r][9] - lam * g[r][6] + l2 * g[r][0];
+      if (r == 0) k0 -= lam * l2;   // -lam * v0,  v0 = lam^2
+      if (r == 1) c7 += l2;          // -lam * v1,  v1 = -lam v7
+      if (r == 2) c2 -= lam;
+      if (r == 3) c8 += l2;          // -lam * v3,  v3 = -lam v8
+      if (r == 4) c4 -= lam;
+      if (r == 5) c5 -= lam;
+      K[r * 6 + 0] = c2; K[r * 6 + 1] = c4; K[r * 6 + 2] = c5; K[r * 6 + 3] = c7; K[r * 6 + 4] = c8; K[r * 6 + 5] = -k0;
+    }
+    // Gaussian elimination with partial pivoting over the 6 rows, 5 unknowns
+    bool solvable = true;
+    for (int col = 0; col < 5; ++col) {
+      int piv = col;
+      double best = fabs(K[col * 6 + col]);
+      for (int r = col + 1; r < 6; ++r) {
+        const double vv = fabs(K[r * 6 + col]);
+        if (vv > best) { best = vv; piv = r; }
+      }
+      if (!(best > 0)) solvable = false;
+      for (int c = 0; c < 6; ++c) {
+        const double a = K[piv * 6 + c], b = K[col * 6 + c];
+        K[piv * 6 + c] = b;
+        K[col * 6 + c] = a;
+      }
+      const double inv = best > 0 ? 1.0 / K[col * 6 + col] : 0.0;
+      for (int r = col + 1; r < 6; ++r) {
+        const double f = K[r * 6 + col] * inv;
+        for (int c = col; c < 6; ++c) K[r * 6 + c] -= f * K[col * 6 + c];
+      }
+    }
+    double u[5];
+#pragma unroll
+    for (int col = 4; col >= 0; --col) {
+      double acc = K[col * 6 + 5];
+#pragma unroll
+      for (int c = 4; c > col; --c) acc -= K[col * 6 + c] * u[c];
+      u[col] = acc / K[col * 6 + col];
+    }
+    const double x = -lam, y = u[3], z = u[4];
+    const bool good = has && solvable && is_finite(y) && is_finite(z);
+    double px = x, py = y, pz = z;
+    if (good) polish_xyz(nb, px, py, pz);
+    if (good && active) {
+      write_model<T>(nb, px, py, pz, mdl + 9 * slot);
+      vld[slot] = 1;
+    }
+    slot += good ? 1 : 0;
+  }
+  if (active) {
+    for (int q = slot; q < 10; ++q) {
+      write_identity<T>(mdl + 9 * q);
+      vld[q] = 0;
+    }
+  }
+}
+
+template <typename T>
+int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st) {
+  const size_t smem = sizeof(double) * kFiveWs * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nister5_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((nister5_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, n, models,
+                     valid);
+  return check_launch("nister5_kernel");
+}
+
+template <typename T>
+int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st) {
+  const size_t smem = sizeof(double) * kStewWs * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&stewenius5_kernel<T>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((stewenius5_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, Bt, models, valid);
+  return check_launch("stewenius5_kernel");
+}
+
+}  // namespace dr
+
+extern "C" {
+
+int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
+                         void *stream) {
+  DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(Bt > 0 && n >= 5, "need Bt > 0 and n >= 5 points per sample");
+  return dr::nister_launch<float>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
+}
+int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, int n, double *models,
+                         uint8_t *valid, void *stream) {
+  DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(Bt > 0 && n >= 5, "need Bt > 0 and n >= 5 points per sample");
+  return dr::nister_launch<double>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
+}
+int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream) {
+  DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream);
+}
+int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream) {
+  DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  return dr::stewenius_launch<double>(samples, Bt, models, valid, (hipStream_t)stream);
+}
+
+}  // extern "C"

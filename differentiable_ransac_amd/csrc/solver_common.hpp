@@ -1,0 +1,447 @@
+// Building blocks of the minimal solvers (K3).  One lane = one minimal sample; arithmetic in f64
+// (full-rate FMA on CDNA4, and the only way the f32 entry points meet the 1e-4 model tolerance:
+// the reference's own f32 five-point output is off by >1e-3 for 10 % of its solutions).
+//
+// Per-lane matrices that need run-time (pivot-dependent) indexing live in LDS in an
+// element-major / lane-minor layout: element e of lane l is at ws[e*64 + l].  Consecutive lanes
+// are 8 bytes apart, so every ds_read_b64/ds_write_b64 of a wave is bank-conflict free whatever
+// element index each lane uses (e*512 bytes is a multiple of the 256-byte bank row).
+#pragma once
+#include "dr_common.hpp"
+
+namespace dr {
+
+// view of one lane's slice of the block's LDS workspace
+struct LaneWs {
+  double *base;  // &ws[lane]
+  __device__ __forceinline__ double &operator[](int e) const { return base[e * 64]; }
+};
+
+__device__ __forceinline__ double dsign(double a, double b) { return b >= 0 ? fabs(a) : -fabs(a); }
+
+// ------------------------------------------------------------------------------------------------
+// Null space of a K x 9 matrix (rows = equations) by Householder QR of its transpose; registers only.
+// A[r][c] is overwritten.  nb[i] (i < 9-K) are orthonormal vectors spanning null(A) when rank A = K.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 - K][9]) {
+  double beta[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    // column j of A^T = row j of A, entries j..8
+    double nrm2 = 0;
+#pragma unroll
+    for (int i = j; i < 9; ++i) nrm2 += A[j][i] * A[j][i];
+    const double nrm = sqrt(nrm2);
+    const double alpha = -dsign(nrm, A[j][j]);
+    const double v0 = A[j][j] - alpha;
+    // v = (v0, A[j][j+1..8]);  beta = 2 / v^T v = -1/(alpha*v0)
+    const double vtv = v0 * v0 + (nrm2 - A[j][j] * A[j][j]);
+    beta[j] = vtv > 0 ? 2.0 / vtv : 0.0;
+    A[j][j] = v0;
+#pragma unroll
+    for (int c = j + 1; c < K; ++c) {
+      double dot = 0;
+#pragma unroll
+      for (int i = j; i < 9; ++i) dot += A[j][i] * A[c][i];
+      dot *= beta[j];
+#pragma unroll
+      for (int i = j; i < 9; ++i) A[c][i] -= dot * A[j][i];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9 - K; ++t) {
+    double q[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i] = (i == K + t) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+      double dot = 0;
+#pragma unroll
+      for (int i = j; i < 9; ++i) dot += A[j][i] * q[i];
+      dot *= beta[j];
+#pragma unroll
+      for (int i = j; i < 9; ++i) q[i] -= dot * A[j][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nb[t][i] = q[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gauss-Jordan with partial pivoting of an R x C matrix in LDS (left R x R block -> identity).
+// Returns false when a pivot underflows rel_tiny * (largest |entry| of the input).
+// ------------------------------------------------------------------------------------------------
+template <int R, int C>
+__device__ __forceinline__ bool gauss_jordan_lds(const LaneWs &w, double rel_tiny = 1e-14) {
+  double amax = 0;
+  for (int e = 0; e < R * C; ++e) amax = fmax(amax, fabs(w[e]));
+  bool ok = amax > 0 && is_finite(amax);
+  const double tiny = rel_tiny * amax;
+#pragma unroll
+  for (int col = 0; col < R; ++col) {
+    int piv = col;
+    double best = fabs(w[col * C + col]);
+    for (int r = col + 1; r < R; ++r) {
+      const double v = fabs(w[r * C + col]);
+      if (v > best) { best = v; piv = r; }
+    }
+    if (!(best > tiny)) ok = false;
+    // bring the pivot row to `col`, normalise it, keep it in registers
+    double prow[C];
+    const double inv = best > 0 ? 1.0 / w[piv * C + col] : 0.0;
+#pragma unroll
+    for (int c = col; c < C; ++c) {
+      const double a = w[piv * C + c];
+      const double b = w[col * C + c];
+      w[piv * C + c] = b;
+      prow[c] = a * inv;
+      w[col * C + c] = prow[c];
+    }
+    for (int r = 0; r < R; ++r) {
+      if (r == col) continue;
+      const double f = w[r * C + col];
+#pragma unroll
+      for (int c = col + 1; c < C; ++c) w[r * C + c] -= f * prow[c];
+      w[r * C + col] = 0.0;
+    }
+  }
+  return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// All real roots of a degree-D polynomial (coefficients ascending), robustly in plain arithmetic:
+// the real roots of p^(m) split the line into intervals on which p^(m-1) is monotone, so going from
+// the linear 10th.. derivative up to p itself every root is bracketed and found by safeguarded
+// Newton.  Each level emits exactly d sorted points (true roots or harmless duplicate breakpoints),
+// so no compaction is ever needed; `mask` flags which of the final D points are roots.
+// Replaces the per-sample companion-matrix eigvals of nister.py:361-370.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double falling(int n, int m) {  // n!/(n-m)!
+  double f = 1;
+  for (int i = 0; i < m; ++i) f *= (double)(n - i);
+  return f;
+}
+
+template <int D>
+__device__ void real_roots(const double (&c)[D + 1], double (&roots)[D], unsigned &mask) {
+  mask = 0;
+  double cmax = 0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
+  const double lead = c[D];
+  bool ok = is_finite(cmax) && lead != 0.0 && cmax > 0;
+  double R = 1.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) R = fmax(R, 1.0 + fabs(c[i] / (ok ? lead : 1.0)));
+  R = fmin(R, 1e10);
+  double pts[D + 1];  // pts[0..d] breakpoints of the current level (pts[0] = -R, pts[d] = R)
+#pragma unroll
+  for (int i = 0; i <= D; ++i) pts[i] = R;
+  pts[0] = -R;
+#pragma unroll
+  for (int d = 1; d <= D; ++d) {
+    // q = p^(D-d), degree d, ascending coefficients
+    double q[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) q[i] = 0;
+#pragma unroll
+    for (int i = 0; i <= d; ++i) {
+      double f = 1;
+#pragma unroll
+      for (int t = 0; t < D - d; ++t) f *= (double)(i + D - d - t);
+      q[i] = c[i + D - d] * f;
+    }
+    auto eval = [&](double x, double &fx, double &dfx) {
+      fx = q[d];
+      dfx = 0;
+#pragma unroll
+      for (int i = d - 1; i >= 0; --i) {
+        dfx = dfx * x + fx;
+        fx = fx * x + q[i];
+      }
+    };
+    // breakpoints: -R, previous level's d-1 points, R
+    double a[D], b[D], x[D];
+    bool neg_a[D];
+    unsigned live = 0;
+    double fprev, dtmp;
+    eval(pts[0], fprev, dtmp);
+#pragma unroll
+    for (int i = 0; i < d; ++i) {
+      const double lo = pts[i], hi = (i == d - 1) ? R : pts[i + 1];
+      double fhi;
+      eval(hi, fhi, dtmp);
+      const bool has = ok && ((fprev < 0) != (fhi < 0)) && (hi > lo);
+      a[i] = lo;
+      b[i] = hi;
+      neg_a[i] = fprev < 0;
+      x[i] = has ? 0.5 * (lo + hi) : hi;
+      if (has) live |= 1u << i;
+      fprev = fhi;
+    }
+    const unsigned found = live;
+    const double tol = (d == D) ? 4e-16 : 1e-11;
+    for (int it = 0; it < 200 && __any(live != 0); ++it) {
+#pragma unroll
+      for (int i = 0; i < d; ++i) {
+        if (!((live >> i) & 1u)) continue;
+        double fx, dfx;
+        eval(x[i], fx, dfx);
+        if ((fx < 0) == neg_a[i]) a[i] = x[i];
+        else b[i] = x[i];
+        double xn = x[i] - fx / dfx;
+        if (!(xn > a[i] && xn < b[i])) xn = 0.5 * (a[i] + b[i]);
+        const double dx = fabs(xn - x[i]);
+        x[i] = xn;
+        if (dx <= tol * (1.0 + fabs(xn)) || fx == 0.0) live &= ~(1u << i);
+      }
+    }
+    // next level's interior breakpoints: this level's d points (sorted by construction)
+#pragma unroll
+    for (int i = 0; i < d; ++i) pts[i + 1] = x[i];
+    if (d == D) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) roots[i] = x[i];
+      mask = found;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cyclic Jacobi eigen-decomposition of a symmetric n x n matrix held in LDS (A: n*n, V: n*n).
+// On return A's diagonal holds the eigenvalues and the columns of V the eigenvectors.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ void jacobi_eig_lds(const LaneWs &A, const LaneWs &V) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0, dg = 0;
+    for (int i = 0; i < N; ++i) {
+      dg += A[i * N + i] * A[i * N + i];
+      for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j];
+    }
+    const bool done = !(off > 1e-34 * dg) ;
+    if (__all(done)) break;
+    for (int p = 0; p < N - 1; ++p) {
+      for (int q = p + 1; q < N; ++q) {
+        const double apq = A[p * N + q];
+        const double app = A[p * N + p], aqq = A[q * N + q];
+        double c = 1.0, s = 0.0;
+        if (fabs(apq) > 1e-300 && !done) {
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = dsign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          s = t * c;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double akp = A[k * N + p], akq = A[k * N + q];
+          A[k * N + p] = c * akp - s * akq;
+          A[k * N + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double apk = A[p * N + k], aqk = A[q * N + k];
+          A[p * N + k] = c * apk - s * aqk;
+          A[q * N + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < N; ++k) {
+          const double vkp = V[k * N + p], vkq = V[k * N + q];
+          V[k * N + p] = c * vkp - s * vkq;
+          V[k * N + q] = s * vkp + c * vkq;
+        }
+      }
+    }
+  }
+}
+
+// symmetric 3x3 Jacobi in registers; eigenvalues in d[], eigenvectors = columns of V
+__device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3], double (&d)[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 24; ++sweep) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    const bool done = !(off > 1e-36 * dg);
+    if (__all(done)) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[p][q];
+        double c = 1.0, s = 0.0;
+        if (fabs(apq) > 1e-300 && !done) {
+          const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+          const double t = dsign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          s = t * c;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d[i] = A[i][i];
+}
+
+// ---- multivariate polynomial tables (x, y, z), shared by the two five-point solvers -----------------
+struct Mono { int x, y, z; };
+__host__ __device__ constexpr bool mono_eq(Mono a, Mono b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+struct Tables {
+  // degree-1 order (x, y, z, 1)
+  Mono e1[4] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+  Mono e2[10];
+  Mono e3[20];
+  int t11[4][4] = {};   // product of two degree-1 monomials -> index into e2
+  int t21[10][4] = {};  // degree-2 x degree-1 -> index into e3
+  constexpr Tables(const Mono (&m2)[10], const Mono (&m3)[20]) : e2{}, e3{} {
+    for (int i = 0; i < 10; ++i) e2[i] = m2[i];
+    for (int i = 0; i < 20; ++i) e3[i] = m3[i];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        Mono s{e1[i].x + e1[j].x, e1[i].y + e1[j].y, e1[i].z + e1[j].z};
+        for (int o = 0; o < 10; ++o)
+          if (mono_eq(e2[o], s)) t11[i][j] = o;
+      }
+    for (int i = 0; i < 10; ++i)
+      for (int j = 0; j < 4; ++j) {
+        Mono s{e2[i].x + e1[j].x, e2[i].y + e1[j].y, e2[i].z + e1[j].z};
+        for (int o = 0; o < 20; ++o)
+          if (mono_eq(e3[o], s)) t21[i][j] = o;
+      }
+  }
+};
+
+// Nister's orders (nister.py:410-430)
+constexpr Mono kN2[10] = {{2, 0, 0}, {1, 1, 0}, {1, 0, 1}, {1, 0, 0}, {0, 2, 0}, {0, 1, 1}, {0, 1, 0}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+constexpr Mono kN3[20] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1}, {2, 0, 0}, {0, 2, 1}, {0, 2, 0}, {1, 1, 1}, {1, 1, 0},
+                          {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2}, {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
+// GrevLex orders of the Stewenius solver (stewenius.py:134-172)
+constexpr Mono kG2[10] = {{2, 0, 0}, {1, 1, 0}, {0, 2, 0}, {1, 0, 1}, {0, 1, 1}, {0, 0, 2}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+constexpr Mono kG3[20] = {{3, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 3, 0}, {2, 0, 1}, {1, 1, 1}, {0, 2, 1}, {1, 0, 2}, {0, 1, 2}, {0, 0, 3},
+                          {2, 0, 0}, {1, 1, 0}, {0, 2, 0}, {1, 0, 1}, {0, 1, 1}, {0, 0, 2}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+
+struct NisterOrder { static constexpr Tables T{kN2, kN3}; };
+struct GrevlexOrder { static constexpr Tables T{kG2, kG3}; };
+
+template <class Ord>
+__device__ __forceinline__ void pmul11(const double (&a)[4], const double (&b)[4], double (&o)[10], double scale = 1.0,
+                                       bool accumulate = false) {
+  if (!accumulate) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) o[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[Ord::T.t11[i][j]] += scale * a[i] * b[j];
+}
+
+template <class Ord>
+__device__ __forceinline__ void pmul21_acc(const double (&a)[10], const double (&b)[4], double (&o)[20], double scale) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[Ord::T.t21[i][j]] += scale * a[i] * b[j];
+}
+
+// Ten cubic constraints on E(x,y,z) = x B0 + y B1 + z B2 + B3 written into the LDS matrix w (10 x 20):
+// rows 0-8 = entries (row-major i,j) of  s*(E E^T E - 1/2 tr(E E^T) E)  (s = 2 for Stewenius' 2EE^TE - tr(EE^T)E),
+// row 9 = det E.   e[i][j][0..3] = entry polynomial (i,j) in (x,y,z,1).
+template <class Ord>
+__device__ void build_constraints(const double (&e)[3][3][4], const LaneWs &w, double s) {
+  // EE^T (symmetric): 6 polynomials of degree 2
+  double eet[3][3][10];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j) {
+      pmul11<Ord>(e[i][0], e[j][0], eet[i][j]);
+      pmul11<Ord>(e[i][1], e[j][1], eet[i][j], 1.0, true);
+      pmul11<Ord>(e[i][2], e[j][2], eet[i][j], 1.0, true);
+    }
+#pragma unroll
+  for (int i = 1; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+#pragma unroll
+      for (int t = 0; t < 10; ++t) eet[i][j][t] = eet[j][i][t];
+  // subtract half the trace from the diagonal:  (EE^T - 1/2 tr I)
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    const double h = 0.5 * (eet[0][0][t] + eet[1][1][t] + eet[2][2][t]);
+    eet[0][0][t] -= h;
+    eet[1][1][t] -= h;
+    eet[2][2][t] -= h;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double row[20];
+#pragma unroll
+      for (int t = 0; t < 20; ++t) row[t] = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pmul21_acc<Ord>(eet[i][k], e[k][j], row, s);
+#pragma unroll
+      for (int t = 0; t < 20; ++t) w[(3 * i + j) * 20 + t] = row[t];
+    }
+  // determinant
+  double row[20];
+#pragma unroll
+  for (int t = 0; t < 20; ++t) row[t] = 0;
+  double m[10], m2[10];
+  pmul11<Ord>(e[0][1], e[1][2], m);
+  pmul11<Ord>(e[0][2], e[1][1], m2);
+#pragma unroll
+  for (int t = 0; t < 10; ++t) m[t] -= m2[t];
+  pmul21_acc<Ord>(m, e[2][0], row, 1.0);
+  pmul11<Ord>(e[0][2], e[1][0], m);
+  pmul11<Ord>(e[0][0], e[1][2], m2);
+#pragma unroll
+  for (int t = 0; t < 10; ++t) m[t] -= m2[t];
+  pmul21_acc<Ord>(m, e[2][1], row, 1.0);
+  pmul11<Ord>(e[0][0], e[1][1], m);
+  pmul11<Ord>(e[0][1], e[1][0], m2);
+#pragma unroll
+  for (int t = 0; t < 10; ++t) m[t] -= m2[t];
+  pmul21_acc<Ord>(m, e[2][2], row, 1.0);
+#pragma unroll
+  for (int t = 0; t < 20; ++t) w[9 * 20 + t] = row[t];
+}
+
+// rows (x1x2, x1y2, x1, y1x2, y1y2, y1, x2, y2, 1) of the five-point solvers (nister.py:87-115)
+__device__ __forceinline__ void epipolar_row_5pt(double x1, double y1, double x2, double y2, double w, double (&r)[9]) {
+  r[0] = w * x1 * x2; r[1] = w * x1 * y2; r[2] = w * x1;
+  r[3] = w * y1 * x2; r[4] = w * y1 * y2; r[5] = w * y1;
+  r[6] = w * x2; r[7] = w * y2; r[8] = w;
+}
+// rows (x1x2, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1) of the fundamental-matrix solvers (fundamental…:243-246)
+__device__ __forceinline__ void epipolar_row_f(double x1, double y1, double x2, double y2, double w, double (&r)[9]) {
+  r[0] = w * x1 * x2; r[1] = w * x2 * y1; r[2] = w * x2;
+  r[3] = w * y2 * x1; r[4] = w * y2 * y1; r[5] = w * y2;
+  r[6] = w * x1; r[7] = w * y1; r[8] = w;
+}
+
+}  // namespace dr

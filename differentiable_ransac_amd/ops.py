@@ -157,3 +157,93 @@ class SampleGather(torch.autograd.Function):
         a_sel, gm = gather_bwd(matches, idx, y_sel, g_samples, g_w, want_grad_matches=ctx.needs_input_grad[0])
         gl = gumbel_topk_bwd(logits, gumbel if has_noise else None, seed, tau, idx, lse, a_sel)
         return gm, gl, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ K3 solvers
+def _flat_samples(samples: torch.Tensor, c: int):
+    s = samples.reshape(-1, samples.shape[-2], c).contiguous()
+    return s, s.shape[0], s.shape[1]
+
+
+def solve_nister5(samples: torch.Tensor, weights: Optional[torch.Tensor] = None):
+    """samples [..., n>=5, 4] -> models [..., 10, 3, 3], valid [..., 10] bool (real solutions, ascending root)."""
+    s, Bt, n = _flat_samples(samples, 4)
+    lead = samples.shape[:-2]
+    models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=s.dtype)
+    valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
+    w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
+    L.call(f"dr_solve_nister5_{L.suffix(s.dtype)}", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(valid),
+           stream())
+    return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
+
+
+def solve_stewenius5(samples: torch.Tensor):
+    s, Bt, n = _flat_samples(samples, 4)
+    if n != 5:
+        raise L.DransacError("the Stewenius solver takes exactly 5 correspondences per sample")
+    lead = samples.shape[:-2]
+    models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=s.dtype)
+    valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
+    L.call(f"dr_solve_stewenius5_{L.suffix(s.dtype)}", ptr(s), c_int(Bt), ptr(models), ptr(valid), stream())
+    return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
+
+
+def solve_f8(samples: torch.Tensor, weights: Optional[torch.Tensor] = None):
+    """samples [..., n>=8, 4] -> F [..., 3, 3], valid [...] bool."""
+    s, Bt, n = _flat_samples(samples, 4)
+    lead = samples.shape[:-2]
+    models = torch.empty((Bt, 3, 3), device=s.device, dtype=s.dtype)
+    valid = torch.empty((Bt,), device=s.device, dtype=torch.bool)
+    w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
+    L.call(f"dr_solve_f8_{L.suffix(s.dtype)}", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(valid), stream())
+    return models.reshape(*lead, 3, 3), valid.reshape(lead)
+
+
+def solve_f7(samples: torch.Tensor):
+    s, Bt, n = _flat_samples(samples, 4)
+    if n != 7:
+        raise L.DransacError("the 7-point solver takes exactly 7 correspondences per sample")
+    lead = samples.shape[:-2]
+    models = torch.empty((Bt, 4, 3, 3), device=s.device, dtype=s.dtype)
+    valid = torch.empty((Bt, 4), device=s.device, dtype=torch.bool)
+    L.call(f"dr_solve_f7_{L.suffix(s.dtype)}", ptr(s), c_int(Bt), ptr(models), ptr(valid), stream())
+    return models.reshape(*lead, 4, 3, 3), valid.reshape(*lead, 4)
+
+
+def solve_rigid(samples: torch.Tensor, weights: Optional[torch.Tensor] = None, flag: bool = True):
+    """samples [..., n>=3, 6] -> model [...,4,4], R [...,3,3], t [...,3], scale [...], valid [...] bool."""
+    s, Bt, n = _flat_samples(samples, 6)
+    lead = samples.shape[:-2]
+    dev, dt = s.device, s.dtype
+    model = torch.empty((Bt, 4, 4), device=dev, dtype=dt)
+    R = torch.empty((Bt, 3, 3), device=dev, dtype=dt)
+    t = torch.empty((Bt, 3), device=dev, dtype=dt)
+    scale = torch.empty((Bt,), device=dev, dtype=dt)
+    valid = torch.empty((Bt,), device=dev, dtype=torch.bool)
+    w = None if weights is None else weights.reshape(Bt, n).to(dt).contiguous()
+    L.call(f"dr_solve_rigid_{L.suffix(dt)}", ptr(s), ptr(w), c_int(Bt), c_int(n), c_int(1 if flag else 0), ptr(model),
+           ptr(R), ptr(t), ptr(scale), ptr(valid), stream())
+    return (model.reshape(*lead, 4, 4), R.reshape(*lead, 3, 3), t.reshape(*lead, 3), scale.reshape(lead),
+            valid.reshape(lead))
+
+
+def rigid_residual(pts: torch.Tensor, models: torch.Tensor, threshold: float = 0.03, want_masks: bool = True):
+    """pts [P,N,6], models [P,M,4,4] -> res_sum [P,M], masks [P,M,N] bool | None."""
+    P, N, _ = pts.shape
+    M = models.shape[1]
+    res = torch.empty((P, M), device=pts.device, dtype=pts.dtype)
+    masks = torch.empty((P, M, N), device=pts.device, dtype=torch.bool) if want_masks else None
+    L.call(f"dr_rigid_residual_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()),
+           L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(res), ptr(masks), stream())
+    return res, masks
+
+
+def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torch.Tensor):
+    """K5: models [P,B,S,3,3], valid [P,B,S] | None, gt [P,3,3] -> chosen [P,B,3,3], which [P,B] int32."""
+    P, B, S = models.shape[:3]
+    chosen = torch.empty((P, B, 3, 3), device=models.device, dtype=models.dtype)
+    which = torch.empty((P, B), device=models.device, dtype=torch.int32)
+    v = None if valid is None else valid.contiguous().view(torch.uint8)
+    L.call(f"dr_select_closest_{L.suffix(models.dtype)}", ptr(models.contiguous()), ptr(v),
+           ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), stream())
+    return chosen, which
