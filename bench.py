@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Headline benchmark: hypotheses/s of the differentiable-RANSAC hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the hot path (test mode, ransac.py:55-144, one RANSAC batch) over one batch of
+synthetic image pairs resident in HBM: K1 Gumbel top-k sampling (in-kernel Philox) -> K2 gather ->
+K3 Nister 5-point -> K4 MSAC scoring of all 10*B models against all N points (masks materialised, as
+MSACScore.score's contract requires) -> K6 per-pair arg-max / best mask / inlier count.
+Workload = BASELINE.json configs[1]: Nister 5-pt, N = 2000 points, B = 1024 hypotheses per pair, Gumbel
+sampler, MSAC; `--pairs` pairs per GPU per step (weak scaling: pairs shard across ranks, no data-path
+collective -- SURVEY 8(e)).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_PEAK_TFLOPS = 157.3   # packed-f32 VALU = f32 MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
+    ap.add_argument("--points", type=int, default=2000)
+    ap.add_argument("--hyps", type=int, default=1024)
+    ap.add_argument("--solver", default="nister", choices=["nister", "stewenius", "f8"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--profile-kernels", action="store_true", help="per-kernel HIP-event breakdown (extra syncs)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, pairs_data):
+    """The CPU oracle (oracle/cpu_ref.py, a vectorised torch restatement of the reference path) timed on the host
+    cores, on a bounded sample of the same workload: whole pairs (N points x B hypotheses), one after the other like
+    the reference's per-pair loop (model_cl.py:488), until the time budget is spent."""
+    from oracle import cpu_ref as O
+    from differentiable_ransac_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    k = 8 if args.solver == "f8" else 5
+    done, t_used = 0, 0.0
+    with torch.no_grad():
+        while t_used < args.cpu_seconds and done < pairs_data["matches"].shape[0]:
+            m = pairs_data["matches"][done]
+            lg = pairs_data["logits"][done]
+            noise = synth.gumbel_noise((args.hyps, args.points), seed=1000 + done)
+            t0 = time.perf_counter()
+            idx, ret, _ = O.gumbel_topk(lg, noise, 1.0, k)
+            smp = O.gather_samples(m, ret)
+            if args.solver == "f8":
+                models = O.fundamental_8pt(smp)
+            elif args.solver == "stewenius":
+                models = O.stewenius_5pt(smp)[0].reshape(-1, 3, 3)
+            else:
+                E, ok, _ = O.nister_5pt(smp)
+                models = O.compact_models(E, ok)
+            scores, masks = O.msac_score(m, models, 7.5e-4, chunk=2048)
+            b = int(torch.argmax(torch.nan_to_num(scores, nan=-1.0)))
+            _ = masks[b].sum()
+            dt = time.perf_counter() - t0
+            if done > 0 or dt > args.cpu_seconds:   # first pair = warm-up unless it alone exceeds the budget
+                t_used += dt
+            done += 1
+    timed = max(done - 1, 1)
+    return {"value": timed * args.hyps / max(t_used, 1e-9), "unit": "hypotheses/s", "cores": cores, "kind": "port",
+            "sample": f"{timed} pair(s) x {args.points} pts x {args.hyps} hyps, torch-CPU f32 oracle "
+                      f"(sample+gather+solve+score+argmax), {t_used:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from differentiable_ransac_amd import ops, synth
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+
+    P, N, B = args.pairs, args.points, args.hyps
+    S = 1 if args.solver == "f8" else 10
+    M = B * S
+    data = synth.batch_two_view(P, N, seed0=rank * P, pixel=(args.solver == "f8"))
+    matches = data["matches"].to(dev)
+    logits = data["logits"].to(dev)
+    K1, K2 = data["K1"].to(dev), data["K2"].to(dev)
+    thr_px = 0.75
+    rn = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
+                       seed=1234 + rank, keep_masks=True, refit=False)
+
+    ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in range(args.steps)]
+    state = {"i": -1}
+    orig_msac = ops.msac_score
+
+    def timed_msac(m, md, thr, want_masks=True):
+        i = state["i"]
+        if 0 <= i < args.steps and want_masks:
+            ev[i][0].record()
+            out = orig_msac(m, md, thr, want_masks)
+            ev[i][1].record()
+            return out
+        return orig_msac(m, md, thr, want_masks)
+
+    ops.msac_score = timed_msac
+
+    def step():
+        return rn(matches, logits, K1, K2)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        state["i"] = i
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    state["i"] = -1
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included
+    flops_per_launch = 39.0 * P * M * N
+    achieved = bytes_per_launch / (k4_ms * 1e-3) / 1e9
+
+    # sanity of the result (cheap, outside the timed region): the synthetic pairs have 50 % inliers
+    inl_frac = float(out["inliers"].float().mean()) / N
+
+    result = {
+        "metric": "hypotheses/sec (and image-pairs/sec) at 2000 pts x 1024 hyps, 1/2/4/8 GPU",
+        "value": world * P * B * args.steps / elapsed,
+        "unit": "hypotheses/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.solver} 5-pt E, {N} pts x {B} hyps per pair, Gumbel top-k sampler (in-kernel "
+                               f"Philox), MSAC scoring with masks, test mode, {P} pairs/GPU/step",
+                   "pairs_per_gpu": P, "points": N, "hypotheses_per_pair": B, "models_per_pair": M,
+                   "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
+        "pairs_per_s": world * P * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "kernel": "msac_score_kernel<float,true>", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": k4_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                     "valu_tflops": flops_per_launch / (k4_ms * 1e-3) / 1e12,
+                     "valu_frac_of_157.3": flops_per_launch / (k4_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+        "check": {"mean_inlier_fraction_of_best_model": inl_frac},
+    }
+    if args.profile_kernels and rank == 0:
+        result["kernel_breakdown_ms"] = kernel_breakdown(args, rn, matches, logits, K1, K2, ops)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, data)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def kernel_breakdown(args, rn, matches, logits, K1, K2, ops):
+    """Per-stage device time by HIP events (each stage synchronised): sampler / gather / solver / scoring / select."""
+    import torch
+    P, N, B = args.pairs, args.points, args.hyps
+    k = rn.k
+    out = {}
+
+    def t(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            r = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps, r
+
+    out["K1_gumbel_topk"], r = t(lambda: ops.gumbel_topk(logits, B, k, 1.0, None, seed=1))
+    out["K2_gather"], smp = t(lambda: ops.gather(matches, r["idx"], r["y_sel"]))
+    if args.solver == "f8":
+        out["K3_solver"], (F, v) = t(lambda: ops.solve_f8(smp))
+        models, valid = F.unsqueeze(2), v.unsqueeze(2)
+    elif args.solver == "stewenius":
+        out["K3_solver"], (models, valid) = t(lambda: ops.solve_stewenius5(smp))
+    else:
+        out["K3_solver"], (models, valid) = t(lambda: ops.solve_nister5(smp))
+    flat = models.reshape(P, -1, 3, 3)
+    thr = torch.full((P,), 7.5e-4, device=matches.device)
+    out["K4_msac_masks"], (sc, mk) = t(lambda: ops.msac_score(matches, flat, thr, True))
+    out["K4_msac_nomask"], _ = t(lambda: ops.msac_score(matches, flat, thr, False))
+    out["K6_select_best"], _ = t(lambda: ops.select_best(matches, flat, sc, thr, valid.reshape(P, -1)))
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -247,3 +247,174 @@ def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torc
     L.call(f"dr_select_closest_{L.suffix(models.dtype)}", ptr(models.contiguous()), ptr(v),
            ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), stream())
     return chosen, which
+
+
+# ------------------------------------------------------------------------------------------ autograd wrappers
+class _SolveEssential(torch.autograd.Function):
+    """Five-point solve with implicit-function backward (dr_solve_nister5_bwd): at a returned model E the five
+    epipolar constraints x2^T E x1 = 0 restricted to the tangent space of the essential manifold determine dE/dpts."""
+
+    @staticmethod
+    def forward(ctx, samples, weights, which):
+        if which == "nister":
+            models, valid = solve_nister5(samples, weights)
+        else:
+            models, valid = solve_stewenius5(samples)
+        ctx.save_for_backward(samples, models, valid)
+        ctx.minimal = samples.shape[-2] == 5
+        ctx.mark_non_differentiable(valid)
+        return models, valid
+
+    @staticmethod
+    def backward(ctx, g_models, _g_valid):
+        samples, models, valid = ctx.saved_tensors
+        if not ctx.minimal:
+            raise L.DransacError("backward of the non-minimal five-point fallback is not defined (refit is test-mode only)")
+        if samples.dtype != torch.float32:
+            raise L.DransacError("backward is implemented for f32 only")
+        s, Bt, _ = _flat_samples(samples, 4)
+        gs = torch.empty_like(s)
+        L.call("dr_solve_nister5_bwd_f32", ptr(s), ptr(models.contiguous()), ptr(valid.contiguous().view(torch.uint8)),
+               ptr(g_models.contiguous()), c_int(Bt), ptr(gs), stream())
+        return gs.reshape(samples.shape), None, None
+
+
+def solve_essential(samples, weights=None, which="nister"):
+    """Differentiable five-point solve: samples [...,n,4] -> (models [...,10,3,3], valid [...,10])."""
+    return _SolveEssential.apply(samples, weights, which)
+
+
+class _SolveF8(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, samples, weights):
+        F, valid = solve_f8(samples, weights)
+        ctx.save_for_backward(samples, weights if weights is not None else torch.empty(0, device=samples.device), F)
+        ctx.has_w = weights is not None
+        ctx.mark_non_differentiable(valid)
+        return F, valid
+
+    @staticmethod
+    def backward(ctx, gF, _gv):
+        samples, weights, F = ctx.saved_tensors
+        if samples.dtype != torch.float32:
+            raise L.DransacError("backward is implemented for f32 only")
+        s, Bt, n = _flat_samples(samples, 4)
+        gs = torch.empty_like(s)
+        w = weights.reshape(Bt, n).contiguous() if ctx.has_w else None
+        gw = torch.empty_like(w) if ctx.has_w else None
+        L.call("dr_solve_f8_bwd_f32", ptr(s), ptr(w), ptr(F.contiguous()), ptr(gF.contiguous()), c_int(Bt), c_int(n),
+               ptr(gs), ptr(gw), stream())
+        return gs.reshape(samples.shape), (gw.reshape(weights.shape) if ctx.has_w else None)
+
+
+def solve_fundamental8(samples, weights=None):
+    return _SolveF8.apply(samples, weights)
+
+
+class _SolveRigid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, samples, weights, flag):
+        out = solve_rigid(samples, weights, flag)
+        ctx.save_for_backward(samples, out[0])
+        ctx.flag = flag
+        ctx.has_w = weights is not None
+        ctx.mark_non_differentiable(out[4])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_model, g_R, g_t, g_scale, _gv):
+        samples, model = ctx.saved_tensors
+        if samples.dtype != torch.float32:
+            raise L.DransacError("backward is implemented for f32 only")
+        if ctx.has_w:
+            raise L.DransacError("backward of the weighted rigid solver is not implemented")
+        g = g_model.clone() if g_model is not None else torch.zeros_like(model)
+        if g_R is not None:
+            g[..., :3, :3] += g_R
+        if g_t is not None:
+            g[..., :3, 3] += g_t
+        s, Bt, n = _flat_samples(samples, 6)
+        gs = torch.empty_like(s)
+        L.call("dr_solve_rigid_bwd_f32", ptr(s), ptr(model.contiguous()), ptr(g.contiguous()), c_int(Bt), c_int(n),
+               c_int(1 if ctx.flag else 0), ptr(gs), stream())
+        return gs.reshape(samples.shape), None, None
+
+
+def solve_rigid_autograd(samples, weights=None, flag=True):
+    return _SolveRigid.apply(samples, weights, flag)
+
+
+class _MsacScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, matches, models, thr, want_masks):
+        scores, masks = msac_score(matches, models, thr, want_masks)
+        ctx.save_for_backward(matches, models, thr)
+        if masks is not None:
+            ctx.mark_non_differentiable(masks)
+        return scores, masks
+
+    @staticmethod
+    def backward(ctx, g_scores, _gm):
+        matches, models, thr = ctx.saved_tensors
+        if matches.dtype != torch.float32:
+            raise L.DransacError("backward is implemented for f32 only")
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        gm = torch.empty_like(models)
+        L.call("dr_msac_score_bwd_f32", ptr(matches.contiguous()), ptr(models.contiguous()), ptr(thr),
+               ptr(g_scores.contiguous()), c_int(P), c_int(M), c_int(N), ptr(gm), stream())
+        return None, gm, None, None
+
+
+def msac_score_autograd(matches, models, threshold, want_masks=True):
+    thr = _thr_tensor(threshold, matches.shape[0], matches)
+    return _MsacScore.apply(matches, models.reshape(models.shape[0], -1, 3, 3), thr, want_masks)
+
+
+class _RigidResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, models, threshold):
+        res, masks = rigid_residual(pts, models, threshold, True)
+        ctx.save_for_backward(pts, models)
+        ctx.mark_non_differentiable(masks)
+        return res, masks
+
+    @staticmethod
+    def backward(ctx, g_res, _gm):
+        pts, models = ctx.saved_tensors
+        if pts.dtype != torch.float32:
+            raise L.DransacError("backward is implemented for f32 only")
+        P, N, _ = pts.shape
+        M = models.shape[1]
+        gm = torch.empty_like(models)
+        L.call("dr_rigid_residual_bwd_f32", ptr(pts.contiguous()), ptr(models.contiguous()), ptr(g_res.contiguous()),
+               c_int(P), c_int(M), c_int(N), ptr(gm), stream())
+        return None, gm, None
+
+
+def rigid_residual_autograd(pts, models, threshold=0.03):
+    return _RigidResidual.apply(pts, models, threshold)
+
+
+class _SelectClosest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, models, valid, gt):
+        chosen, which = select_closest(models, valid, gt)
+        ctx.save_for_backward(which)
+        ctx.shape = models.shape
+        ctx.mark_non_differentiable(which)
+        return chosen, which
+
+    @staticmethod
+    def backward(ctx, g_chosen, _gw):
+        (which,) = ctx.saved_tensors
+        P, B, S = ctx.shape[:3]
+        g = torch.zeros(ctx.shape, device=g_chosen.device, dtype=g_chosen.dtype)
+        w = which.long().clamp(min=0)
+        live = (which >= 0).to(g_chosen.dtype)[..., None, None]
+        g.scatter_(2, w[..., None, None, None].expand(P, B, 1, 3, 3), (g_chosen * live).unsqueeze(2))
+        return g, None, None
+
+
+def select_closest_autograd(models, valid, gt):
+    return _SelectClosest.apply(models, valid, gt)

@@ -1,0 +1,325 @@
+"""RANSAC drivers -- same classes, constructor arguments and return values as the reference's
+ransac.py (RANSAC :6-299, RANSAC3D :303-450), plus BatchedRANSAC, which runs the same algorithm
+over a whole (image-pair x hypothesis) grid in a handful of launches instead of the reference's
+per-pair Python loop (model_cl.py:488).
+
+Everything numeric happens in libdransac.so through differentiable_ransac_amd.ops; these classes
+only sequence launches and keep the (tiny) per-pair state.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+
+def adaptive_iteration_number(inlier_number, point_number, sample_size, confidence=0.999, eps=1e-5,
+                              max_iterations=5000):
+    """ransac.py:202-215."""
+    ratio = float(inlier_number) / float(point_number)
+    prob = 1.0 - ratio ** sample_size
+    if prob >= 1.0 - eps:
+        return max_iterations
+    return max(0.0, math.log10(1.0 - confidence) / math.log10(1 - ratio ** sample_size + eps))
+
+
+def normalized_threshold(threshold, K1, K2, fmat):
+    """ransac.py:49-53 -- (K1[0,0] + K1[1,1] + K1[0,0] + K2[1,1]) / 4, K1[0,0] twice on purpose (Q3)."""
+    if fmat:
+        return threshold
+    return threshold / ((K1[..., 0, 0] + K1[..., 1, 1] + K1[..., 0, 0] + K2[..., 1, 1]) / 4)
+
+
+def _is_gumbel(sampler_id):
+    # ids 2 and 3 in the reference; id 1 builds a Gumbel sampler there too but then crashes (Q16): treated as 2
+    return sampler_id in (1, 2, 3)
+
+
+class RANSAC(object):
+    """Drop-in for the reference's RANSAC (ransac.py:6-200): __call__(matches [N,4], logits [N], K1, K2, gt_model)
+    -> (best_model | {iteration: models}, best_mask, best_score, iterations)."""
+
+    def __init__(self, estimator, sampler, scoring, fmat=False, train=False, ransac_batch_size=64, sampler_id=0,
+                 weighted=0, threshold=1e-3, confidence=0.999, max_iterations=5000, lo=0, lo_iters=64, eps=1e-5):
+        self.estimator = estimator
+        self.sampler = sampler
+        self.scoring = scoring
+        self.lo = lo
+        self.lo_iters = lo_iters
+        self.fmat = fmat
+        self.train = train
+        self.ransac_batch_size = ransac_batch_size
+        self.sampler_id = sampler_id
+        self.weighted = weighted
+        self.threshold = threshold
+        self.confidence = confidence
+        self.max_iterations = max_iterations
+        self.eps = eps
+        if lo:
+            raise NotImplementedError("local optimisation is out of scope (it never ran in the reference either: "
+                                      "lo defaults to 0 and lo=3 raises TypeError, SURVEY Q2)")
+
+    # -- one batch: sample -> gather -> solve; returns models [B,S,3,3], valid [B,S], soft weights
+    def _hypotheses(self, matches, logits, gumbels=None):
+        B = self.ransac_batch_size
+        k = self.sampler.num_samples
+        if _is_gumbel(self.sampler_id):
+            seed = self.sampler._next_seed()
+            g = None if gumbels is None else gumbels.unsqueeze(0)
+            samples, w, _ = ops.SampleGather.apply(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), B, k,
+                                                   self.sampler.tau, g, seed)
+            samples, w = samples[0], w[0]
+        else:
+            idx = self.sampler.sample(matches.shape[0])
+            samples, w = matches[idx], None
+        models, valid = self.estimator.estimate_model_slots(samples, w if self.weighted else None)
+        return models, valid
+
+    def __call__(self, matches, logits, K1, K2, gt_model, gumbels=None):
+        """`gumbels` (optional, list of [B,N] tensors, one per batch) replaces the in-kernel noise: parity runs."""
+        iterations = 0
+        best_score = 0
+        point_number = matches.shape[0]
+        best_mask, best_model = [], []
+        models_out: Dict[int, torch.Tensor] = {}
+        threshold = normalized_threshold(self.threshold, K1, K2, self.fmat)
+        threshold = float(threshold) if not isinstance(threshold, float) else threshold
+        max_iters = self.max_iterations
+        batch = 0
+        while iterations < max_iters:
+            g = None
+            if gumbels is not None:
+                if batch >= len(gumbels):
+                    break
+                g = gumbels[batch]
+            models, valid = self._hypotheses(matches, logits, g)
+            batch += 1
+            B, S = valid.shape
+            if self.train:
+                if self.sampler.num_samples == 8 or S == 1:
+                    chosen, keep = models[:, 0], valid[:, 0]
+                else:
+                    chosen, which = ops.select_closest_autograd(models.unsqueeze(0), valid.unsqueeze(0),
+                                                                gt_model.unsqueeze(0))
+                    chosen, keep = chosen[0], which[0] >= 0
+                models_out[iterations] = chosen[keep]
+            else:
+                flat = models.reshape(B * S, 3, 3)
+                scores, masks = self.scoring.score(matches, flat, threshold)
+                scores = torch.where(valid.reshape(-1) & ~torch.isnan(scores), scores, torch.full_like(scores, -1.0))
+                best_idx = torch.argmax(scores)
+                if scores[best_idx] > best_score or iterations == 0:
+                    best_score = scores[best_idx]
+                    best_mask = masks[best_idx]
+                    best_model = flat[best_idx]
+                    best_inlier_number = int(torch.sum(best_mask))
+                    max_iters = min(self.max_iterations,
+                                    adaptive_iteration_number(best_inlier_number, point_number, self.estimator.sample_size,
+                                                              self.confidence, self.eps, self.max_iterations))
+            iterations += self.ransac_batch_size
+
+        if self.train:
+            return models_out, best_mask, best_score, iterations
+
+        # final refit on the inliers (ransac.py:148-195); not differentiable
+        with torch.no_grad():
+            inl = best_mask.nonzero(as_tuple=True)[0]
+            if self.fmat:
+                cand = self.estimator.estimate_model(matches[inl].unsqueeze(0)) if inl.numel() >= 8 else None
+            else:
+                # pymagsac absent: Nister on ALL points in f64 as one sample (ransac.py:157-165 -> nister.py:64-65)
+                cand = self.estimator.estimate_model(matches.unsqueeze(0).double())
+            if cand is None or cand.shape[0] == 0:
+                if not isinstance(best_model, torch.Tensor):
+                    best_model = torch.eye(3, device=matches.device, dtype=matches.dtype)
+            else:
+                cand = cand.to(matches.dtype)
+                scores, _ = self.scoring.score(matches, cand, threshold)
+                scores = torch.where(torch.isnan(scores), torch.full_like(scores, -1.0), scores)
+                if scores.max() > best_score:
+                    b = torch.argmax(scores)
+                    best_model, best_score = cand[b], scores[b]
+        return best_model, best_mask, best_score, iterations
+
+
+class RANSAC3D(object):
+    """Drop-in for the reference's RANSAC3D (ransac.py:303-450).  Train mode as in the reference; test mode (dead code
+    there) = arg-min of the residual sum."""
+
+    def __init__(self, estimator, sampler, scoring, fmat=False, train=False, ransac_batch_size=64, sampler_id=0,
+                 weighted=0, threshold=1e-3, confidence=0.999, max_iterations=5000, lo=0, lo_iters=64, eps=1e-5,
+                 flag=True):
+        self.estimator = estimator
+        self.sampler = sampler
+        self.scoring = scoring
+        self.train = train
+        self.ransac_batch_size = ransac_batch_size
+        self.sampler_id = sampler_id
+        self.threshold = threshold
+        self.confidence = confidence
+        self.max_iterations = max_iterations
+        self.eps = eps
+        self.flag = flag
+
+    def __call__(self, matches, logits, gt_model, valid=False, gumbels=None):
+        train = self.train and not valid
+        B = self.ransac_batch_size
+        iterations, batch = 0, 0
+        models, residuals, mean_residuals = {}, {}, {}
+        best_model, best_score = None, float("inf")
+        while iterations < self.max_iterations:
+            g = None
+            if gumbels is not None:
+                if batch >= len(gumbels):
+                    break
+                g = gumbels[batch].unsqueeze(0)
+            batch += 1
+            if _is_gumbel(self.sampler_id):
+                samples, _, _ = ops.SampleGather.apply(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), B, 3,
+                                                       self.sampler.tau, g, self.sampler._next_seed())
+                samples = samples[0]
+            else:
+                samples = matches[self.sampler.sample(matches.shape[0])]
+            est, R, t, _ = self.estimator.estimate_model(samples, flag=self.flag)
+            ok = self.estimator.last_valid
+            res, mean_res, _ = self.estimator.squared_residual(matches[:, :3], matches[:, 3:],
+                                                               est[:, :3, :].transpose(-1, -2))
+            if train:
+                models[iterations] = est[ok]
+                residuals[iterations] = res
+                mean_residuals[iterations] = mean_res
+            else:
+                b = torch.argmin(torch.where(ok, res, torch.full_like(res, float("inf"))))
+                if float(res[b]) < best_score:
+                    best_score, best_model = float(res[b]), est[b]
+            iterations += B
+        if train:
+            return models, residuals, mean_residuals, 0, iterations
+        return best_model, residuals, mean_residuals, best_score, iterations
+
+
+class BatchedRANSAC(object):
+    """The (pair x hypothesis) grid in one go: all P pairs sample, solve, score and select per round with a fixed
+    number of launches (K1, K2, K3, K4, K6) and no [B,N] / [M,N] tensor in HBM unless `keep_masks` is set.
+
+    solver: "nister" | "stewenius" | "f8" | "f7".  Test mode reproduces ransac.py:109-195 per pair (arg-max,
+    adaptive stop with the per-pair inlier count evaluated on the device, final refit); train mode returns the
+    chosen models [P, rounds*B, 3, 3] with autograd to `logits`.
+    """
+
+    _SOLVERS = {"nister": (5, 10), "stewenius": (5, 10), "f8": (8, 1), "f7": (7, 4)}
+
+    def __init__(self, solver="nister", ransac_batch_size=1024, train=False, threshold=0.75, confidence=0.999,
+                 max_iterations=5000, tau=1.0, seed=0, weighted=0, keep_masks=False, refit=True, eps=1e-5):
+        self.solver = solver
+        self.k, self.S = self._SOLVERS[solver]
+        self.B = ransac_batch_size
+        self.train = train
+        self.threshold = threshold
+        self.confidence = confidence
+        self.max_iterations = max_iterations
+        self.tau = tau
+        self.seed = seed
+        self.calls = 0
+        self.weighted = weighted
+        self.keep_masks = keep_masks
+        self.refit = refit
+        self.eps = eps
+        self.fmat = solver in ("f8", "f7")
+
+    def _next_seed(self):
+        s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
+        self.calls += 1
+        return s
+
+    def hypotheses(self, matches, logits, gumbels=None):
+        """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
+        samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, self._next_seed())
+        wts = w if self.weighted else None
+        if self.solver in ("nister", "stewenius"):
+            models, valid = ops.solve_essential(samples, wts, self.solver)
+        elif self.solver == "f8":
+            F, v = ops.solve_fundamental8(samples, wts)
+            models, valid = F.unsqueeze(2), v.unsqueeze(2)
+        else:
+            models, valid = ops.solve_f7(samples)
+        return models, valid, idx
+
+    def __call__(self, matches, logits, K1=None, K2=None, gt_model=None, gumbels=None):
+        P, N, _ = matches.shape
+        dev, dt = matches.device, matches.dtype
+        if K1 is not None and not self.fmat:
+            thr = normalized_threshold(self.threshold, K1, K2, False).to(dt).reshape(-1)
+            thr = thr.expand(P).contiguous() if thr.numel() == 1 else thr.contiguous()
+        else:
+            thr = torch.full((P,), float(self.threshold), device=dev, dtype=dt)
+        rounds = max(1, math.ceil(self.max_iterations / self.B))
+        if self.train:
+            out = []
+            for r in range(rounds):
+                g = None if gumbels is None else gumbels[r]
+                models, valid, _ = self.hypotheses(matches, logits, g)
+                if self.S == 1:
+                    chosen = models[:, :, 0]
+                    keep = valid[:, :, 0]
+                else:
+                    chosen, which = ops.select_closest_autograd(models, valid, gt_model)
+                    keep = which >= 0
+                out.append((chosen, keep))
+            return torch.cat([c for c, _ in out], dim=1), torch.cat([k for _, k in out], dim=1)
+
+        with torch.no_grad():
+            best_score = torch.zeros(P, device=dev, dtype=dt)
+            best_model = torch.eye(3, device=dev, dtype=dt).repeat(P, 1, 1)
+            best_mask = torch.zeros(P, N, device=dev, dtype=torch.bool)
+            best_inl = torch.zeros(P, device=dev, dtype=torch.int32)
+            iters = torch.zeros(P, device=dev, dtype=torch.int64)
+            max_it = torch.full((P,), float(self.max_iterations), device=dev, dtype=torch.float64)
+            all_masks = None
+            for r in range(rounds):
+                g = None if gumbels is None else (gumbels[r] if r < len(gumbels) else None)
+                if gumbels is not None and g is None:
+                    break
+                active = iters.double() < max_it
+                models, valid, _ = self.hypotheses(matches, logits, g)
+                flat = models.reshape(P, self.B * self.S, 3, 3)
+                scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks)
+                if self.keep_masks:
+                    all_masks = masks
+                bi, bs, bm, bmask, inl = ops.select_best(matches, flat, scores, thr, valid.reshape(P, -1))
+                better = active & ((bs > best_score) | (iters == 0)) & (bi >= 0)
+                best_score = torch.where(better, bs, best_score)
+                best_model = torch.where(better[:, None, None], bm, best_model)
+                best_mask = torch.where(better[:, None], bmask, best_mask)
+                best_inl = torch.where(better, inl, best_inl)
+                # adaptive stop, ransac.py:135-142 / 202-215, on the device
+                ratio = best_inl.double() / N
+                p_fail = 1.0 - ratio ** self.k
+                new_max = torch.where(p_fail >= 1.0 - self.eps, torch.full_like(max_it, float(self.max_iterations)),
+                                      (math.log10(1.0 - self.confidence) / torch.log10(p_fail + self.eps)).clamp(min=0.0))
+                max_it = torch.where(better, torch.minimum(new_max, torch.full_like(max_it, float(self.max_iterations))),
+                                     max_it)
+                iters = iters + torch.where(active, self.B, 0)
+                if r + 1 < rounds and not bool((iters.double() < max_it).any()):
+                    break
+            if self.refit:
+                if self.fmat:
+                    cand = []
+                    for p in range(P):  # ragged inlier sets: one LSQ per pair
+                        pts = matches[p][best_mask[p]]
+                        cand.append(ops.solve_f8(pts.unsqueeze(0))[0] if pts.shape[0] >= 8 else
+                                    torch.eye(3, device=dev, dtype=dt).unsqueeze(0))
+                    cand = torch.stack(cand)  # [P,1,3,3]
+                else:
+                    cand, cvalid = ops.solve_nister5(matches.double())  # all N points as one f64 sample per pair
+                    cand = cand.to(dt)
+                cs, _ = ops.msac_score(matches, cand, thr, want_masks=False)
+                ci, cbs, cbm, cmask, cinl = ops.select_best(matches, cand, cs, thr, None if self.fmat else cvalid)
+                better = (cbs > best_score) & (ci >= 0)
+                best_model = torch.where(better[:, None, None], cbm, best_model)
+                best_score = torch.where(better, cbs, best_score)
+            return dict(model=best_model, mask=best_mask, score=best_score, iterations=iters, inliers=best_inl,
+                        masks=all_masks)

@@ -181,20 +181,6 @@ int dr_select_best_f64(const double *matches, const double *models, const uint8_
                        const double *thr, int P, int M, int N, int32_t *best_idx, double *best_score,
                        double *best_model, uint8_t *best_mask, int32_t *inliers, void *stream);
 
-/* ------------------------------------------------------------------------------------------
- * Fused (pair x hypothesis) drivers: K1 -> K2 -> K3 in ONE launch (sampling, gather and solve never
- * touch HBM in between).  solver: 0 nister5, 1 stewenius5, 2 f8 (k = 8), 3 f7, 4 rigid (c = 6).
- *   idx [P,B,k], y_sel [P,B,k], lse [P,B] as in K1; models [P,B,S,9|16]; valid [P,B,S].
- * ------------------------------------------------------------------------------------------ */
-#define DR_SOLVER_NISTER5 0
-#define DR_SOLVER_STEWENIUS5 1
-#define DR_SOLVER_F8 2
-#define DR_SOLVER_F7 3
-#define DR_SOLVER_RIGID 4
-int dr_sample_solve_f32(int solver, const float *matches, const float *logits, const float *gumbel, uint64_t seed,
-                        float tau, int P, int N, int B, int32_t *idx, float *y_sel, float *lse, float *models,
-                        uint8_t *valid, void *stream);
-
 #ifdef __cplusplus
 }
 #endif
