@@ -88,4 +88,27 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
   return -__logf(-__logf(u));
 }
 
+// ---- optional per-stage cycle accounting (profiling builds only: -DDR_PROFILE_STAGES) --------------------
+#ifdef DR_PROFILE_STAGES
+static __device__ unsigned long long g_stage_cycles[16];   // one copy per translation unit (no RDC)
+#define DR_STAGE_BEGIN() unsigned long long _t_prev = __builtin_readcyclecounter()
+#define DR_STAGE(i)                                                        \
+  do {                                                                     \
+    unsigned long long _t = __builtin_readcyclecounter();                  \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&::dr::g_stage_cycles[i], _t - _t_prev); \
+    _t_prev = __builtin_readcyclecounter();                                \
+  } while (0)
+#define DR_DEFINE_STAGE_READER(name)                                                                          \
+  extern "C" int name(unsigned long long *out16) {                                                            \
+    unsigned long long zero[16] = {0};                                                                        \
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(::dr::g_stage_cycles), sizeof(zero)) != hipSuccess) return -2; \
+    if (hipMemcpyToSymbol(HIP_SYMBOL(::dr::g_stage_cycles), zero, sizeof(zero)) != hipSuccess) return -2;    \
+    return 0;                                                                                                 \
+  }
+#else
+#define DR_DEFINE_STAGE_READER(name)
+#define DR_STAGE_BEGIN() do {} while (0)
+#define DR_STAGE(i) do {} while (0)
+#endif
+
 }  // namespace dr

@@ -102,9 +102,11 @@ __device__ __forceinline__ void essential_residual(const double (&E)[9], double 
   r[9] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
 }
 
-__device__ __forceinline__ void polish_xyz(const double (&nb)[4][9], double &x, double &y, double &z) {
+__device__ __forceinline__ void polish_xyz(const double (&nb)[4][9], double &x, double &y, double &z, bool live) {
+  // two iterations for everybody, then only waves that still hold an unconverged sample go on (max 8)
 #pragma unroll 1
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < 8; ++it) {
+    if (it >= 2 && !__any(live)) break;
     double E[9], r[10];
 #pragma unroll
     for (int q = 0; q < 9; ++q) E[q] = x * nb[0][q] + y * nb[1][q] + z * nb[2][q] + nb[3][q];
@@ -183,7 +185,13 @@ __device__ __forceinline__ void polish_xyz(const double (&nb)[4][9], double &x, 
     essential_residual(E2, r2);
 #pragma unroll
     for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
-    if (n1 <= n0 && is_finite(n1)) { x = nx; y = ny; z = nz; }
+    const bool better = n1 <= n0 && is_finite(n1);
+    if (better && (live || it < 2)) { x = nx; y = ny; z = nz; }
+    // converged when the residual stops shrinking or is at rounding level relative to |E|^3
+    double e2 = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) e2 += E2[q] * E2[q];
+    live = live && better && (n1 > 1e-28 * e2 * e2 * e2) && (n1 < 0.25 * n0);
   }
 }
 
@@ -201,6 +209,62 @@ __device__ __forceinline__ void write_model(const double (&nb)[4][9], double x, 
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) dst[3 * i + j] = (T)(f[3 * j + i] * inv);
+}
+
+// Final stage shared by both solvers.  (x, y, z, 1) are the coefficients of E on the null-space basis.  The chart
+// "last coefficient = 1" is badly scaled when a solution has a (nearly) vanishing N3 component (|z| -> infinity), so the
+// coefficient vector is renormalised by its largest entry and the basis permuted to make that entry the fixed one before
+// the Gauss-Newton polish.  A candidate is accepted only if it verifies the constraints (relative residual <= 1e-7):
+// `valid` therefore means "checked essential matrix through the five points", not "the root finder said so".
+template <typename T>
+__device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double x, double y, double z, bool candidate,
+                                                T *__restrict__ dst, bool store) {
+  double v[4] = {x, y, z, 1.0};
+  int fix = 3;
+  double big = 1.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (fabs(v[i]) > big) { big = fabs(v[i]); fix = i; }
+  double vfix = 1.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vfix = (i == fix) ? v[i] : vfix;
+  const double inv = 1.0 / vfix;
+  // permuted basis: pb[3] = nb[fix], pb[0..2] = the others in order; coefficients likewise
+  double pb[4][9], u[3];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    pb[3][q] = (fix == 0) ? nb[0][q] : (fix == 1) ? nb[1][q] : (fix == 2) ? nb[2][q] : nb[3][q];
+    pb[0][q] = (fix == 0) ? nb[1][q] : nb[0][q];
+    pb[1][q] = (fix <= 1) ? nb[2][q] : nb[1][q];
+    pb[2][q] = (fix <= 2) ? nb[3][q] : nb[2][q];
+  }
+  u[0] = ((fix == 0) ? v[1] : v[0]) * inv;
+  u[1] = ((fix <= 1) ? v[2] : v[1]) * inv;
+  u[2] = ((fix <= 2) ? v[3] : v[2]) * inv;
+  bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]);
+  polish_xyz(pb, u[0], u[1], u[2], good);
+  // verification on the unit-norm matrix
+  double E[9], r[10], n2 = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    E[q] = u[0] * pb[0][q] + u[1] * pb[1][q] + u[2] * pb[2][q] + pb[3][q];
+    n2 += E[q] * E[q];
+  }
+  const double s = 1.0 / sqrt(n2);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) E[q] *= s;
+  essential_residual(E, r);
+  double rn = 0;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) rn += r[q] * r[q];
+  good = good && is_finite(rn) && rn <= 1e-14;
+  if (good && store) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dst[3 * i + j] = (T)E[3 * j + i];   // stored transposed (nister.py:407)
+  }
+  return good;
 }
 
 // ---- Nister: B(z) from the reduced rows, det B(z), roots, back-substitution -----------------------------
@@ -246,14 +310,17 @@ __device__ void nister_finish(const double (&nb)[4][9], const LaneWs &w, bool ok
   minor_acc(0, 1, 2, 1.0);
 
   double roots[10];
-  unsigned mask;
-  real_roots<10>(cs, roots, mask);
-  if (!ok) mask = 0;
+  int nroots;
+  DR_STAGE_BEGIN();
+  real_roots<10>(cs, roots, nroots);
+  DR_STAGE(3);
+  if (!ok) nroots = 0;
 
   int slot = 0;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    if (!((mask >> i) & 1u)) continue;
+    if (!__any(i < nroots)) continue;   // wave-uniform skip; lanes without this root compute and discard
+    const bool has_root = i < nroots;
     const double z = roots[i];
     // rows of B(z): (bx(z), by(z), b1(z)) . (x, y, 1) = 0 ; null vector = best-conditioned cross product
     double rx[3], ry[3], r1[3];
@@ -275,13 +342,8 @@ __device__ void nister_finish(const double (&nb)[4][9], const LaneWs &w, bool ok
         if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
       }
     const double x = vx / vw, y = vy / vw;
-    const bool good = is_finite(x) && is_finite(y);
-    double px = x, py = y, pz = z;
-    if (good) polish_xyz(nb, px, py, pz);
-    if (good && active) {
-      write_model<T>(nb, px, py, pz, models + 9 * slot);
-      valid[slot] = 1;
-    }
+    const bool good = finish_solution<T>(nb, x, y, z, has_root && is_finite(x) && is_finite(y), models + 9 * slot, active);
+    if (good && active) valid[slot] = 1;
     slot += good ? 1 : 0;
   }
   if (active) {
@@ -305,13 +367,18 @@ __global__ __launch_bounds__(64) void nister5_kernel(const T *__restrict__ sampl
   const T *pts = samples + (size_t)sc * n * 4;
   const T *wts = weights ? weights + (size_t)sc * n : nullptr;
   double nb[4][9];
+  DR_STAGE_BEGIN();
   if (n == 5) fivepoint_basis_minimal<T>(pts, wts, nb);
   else fivepoint_basis_nonminimal<T>(pts, wts, n, w, nb);
+  DR_STAGE(0);
   double e[3][3][4];
   basis_to_entries(nb, e);
   build_constraints<NisterOrder>(e, w, 1.0);
+  DR_STAGE(1);
   const bool ok = gauss_jordan_lds<10, 20>(w);
+  DR_STAGE(2);
   nister_finish<T>(nb, w, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active);
+  DR_STAGE(5);
 }
 
 // ---- Stewenius ---------------------------------------------------------------------------------------------
@@ -429,9 +496,9 @@ __global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ sa
     }
   }
   double roots[10];
-  unsigned mask;
-  real_roots<10>(cs, roots, mask);
-  if (!ok) mask = 0;
+  int nroots;
+  real_roots<10>(cs, roots, nroots);
+  if (!ok) nroots = 0;
 
   T *mdl = models + (size_t)sc * 90;
   uint8_t *vld = valid + (size_t)sc * 10;
@@ -439,8 +506,8 @@ __global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ sa
   LaneWs K{w.base};  // 6 x 6 augmented system, reuses the Hessenberg area
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    if (!__any((mask >> i) & 1u)) continue;
-    const bool has = (mask >> i) & 1u;
+    if (!__any(i < nroots)) continue;
+    const bool has = i < nroots;
     const double lam = roots[i];
     const double l2 = lam * lam;
     // unknown order u = (v2, v4, v5, v7, v8) ; column 5 = right-hand side (minus the constant term)
@@ -488,13 +555,9 @@ __global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ sa
       u[col] = acc / K[col * 6 + col];
     }
     const double x = -lam, y = u[3], z = u[4];
-    const bool good = has && solvable && is_finite(y) && is_finite(z);
-    double px = x, py = y, pz = z;
-    if (good) polish_xyz(nb, px, py, pz);
-    if (good && active) {
-      write_model<T>(nb, px, py, pz, mdl + 9 * slot);
-      vld[slot] = 1;
-    }
+    const bool good = finish_solution<T>(nb, x, y, z, has && solvable && is_finite(y) && is_finite(z), mdl + 9 * slot,
+                                         active);
+    if (good && active) vld[slot] = 1;
     slot += good ? 1 : 0;
   }
   if (active) {
@@ -533,6 +596,8 @@ int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStr
 }
 
 }  // namespace dr
+
+DR_DEFINE_STAGE_READER(dr_debug_stage_read_fivepoint)
 
 extern "C" {
 

@@ -130,14 +130,14 @@ __global__ __launch_bounds__(64) void f7_kernel(const T *__restrict__ samples, i
   c[1] = 2.0 * (p1 - pm1) / 3.0 - (p2 - pm2) / 12.0;
   c[3] = (p2 - pm2) / 12.0 - (p1 - pm1) / 6.0;
   double roots[3];
-  unsigned mask;
-  real_roots<3>(c, roots, mask);
+  int nroots;
+  real_roots<3, 24, 8>(c, roots, nroots, 1e-14);   // cubic: cheap, and there is no polish afterwards -> run it to full precision
   T *mdl = models + (size_t)sc * 36;
   uint8_t *vld = valid + (size_t)sc * 4;
   int slot = 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    if (!((mask >> i) & 1u)) continue;
+    if (!(i < nroots)) continue;
     const double l = roots[i];
     double m[9], n2 = 0;
 #pragma unroll

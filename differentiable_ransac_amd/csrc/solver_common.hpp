@@ -110,40 +110,28 @@ __device__ __forceinline__ bool gauss_jordan_lds(const LaneWs &w, double rel_tin
 }
 
 // ------------------------------------------------------------------------------------------------
-// All real roots of a degree-D polynomial (coefficients ascending), robustly in plain arithmetic:
-// the real roots of p^(m) split the line into intervals on which p^(m-1) is monotone, so going from
-// the linear 10th.. derivative up to p itself every root is bracketed and found by safeguarded
-// Newton.  Each level emits exactly d sorted points (true roots or harmless duplicate breakpoints),
-// so no compaction is ever needed; `mask` flags which of the final D points are roots.
-// Replaces the per-sample companion-matrix eigvals of nister.py:361-370.
+// All real roots of a degree-D polynomial (coefficients ascending), robustly in plain arithmetic.
+//   * |z| <= 1 : roots of p in [-1, 1];   |z| > 1 : z = 1/w with w a root of the reversed polynomial in (-1, 1).
+//     Both searches live on [-1, 1], so there is no root bound to estimate and no huge outer bracket to crawl through.
+//   * On [-1, 1] the real roots of q' split the interval into pieces on which q is monotone; going from the linear
+//     (D-1)-th derivative up to the polynomial itself, every root is bracketed by the previous level's points.
+//     Each level emits exactly d sorted points (roots, or the right end of an empty bracket -- a harmless extra
+//     breakpoint), so nothing is ever compacted and all indexing is static.
+//   * Every bracket is refined by a FIXED schedule -- kBis bisections, then kNewt safeguarded Newton steps -- so the
+//     64 samples of a wave never wait for a slow one.  A root that Newton does not finish is still inside a bracket
+//     of width 2^(1-kBis); the five-point callers polish (x, y, z) on the defining constraints afterwards.
+// Replaces the per-sample companion-matrix eigvals of nister.py:361-370 / the Sturm recursion of math_utils.py.
 // ------------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ double falling(int n, int m) {  // n!/(n-m)!
-  double f = 1;
-  for (int i = 0; i < m; ++i) f *= (double)(n - i);
-  return f;
-}
-
-template <int D>
-__device__ void real_roots(const double (&c)[D + 1], double (&roots)[D], unsigned &mask) {
+template <int D, int kBisLast, int kNewtLast>
+__device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (&x)[D], unsigned &mask, double tail_tol) {
+  double pts[D + 1];
+#pragma unroll
+  for (int i = 0; i <= D; ++i) pts[i] = 1.0;
+  pts[0] = -1.0;
   mask = 0;
-  double cmax = 0;
-#pragma unroll
-  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
-  const double lead = c[D];
-  bool ok = is_finite(cmax) && lead != 0.0 && cmax > 0;
-  double R = 1.0;
-#pragma unroll
-  for (int i = 0; i < D; ++i) R = fmax(R, 1.0 + fabs(c[i] / (ok ? lead : 1.0)));
-  R = fmin(R, 1e10);
-  double pts[D + 1];  // pts[0..d] breakpoints of the current level (pts[0] = -R, pts[d] = R)
-#pragma unroll
-  for (int i = 0; i <= D; ++i) pts[i] = R;
-  pts[0] = -R;
 #pragma unroll
   for (int d = 1; d <= D; ++d) {
-    // q = p^(D-d), degree d, ascending coefficients
-    double q[D + 1];
+    double q[D + 1];  // q = p^(D-d): degree d, ascending
 #pragma unroll
     for (int i = 0; i <= D; ++i) q[i] = 0;
 #pragma unroll
@@ -153,59 +141,145 @@ __device__ void real_roots(const double (&c)[D + 1], double (&roots)[D], unsigne
       for (int t = 0; t < D - d; ++t) f *= (double)(i + D - d - t);
       q[i] = c[i + D - d] * f;
     }
-    auto eval = [&](double x, double &fx, double &dfx) {
+    auto evalf = [&](double t) {
+      double fx = q[d];
+#pragma unroll
+      for (int i = d - 1; i >= 0; --i) fx = fx * t + q[i];
+      return fx;
+    };
+    auto eval2 = [&](double t, double &fx, double &dfx) {
       fx = q[d];
       dfx = 0;
 #pragma unroll
       for (int i = d - 1; i >= 0; --i) {
-        dfx = dfx * x + fx;
-        fx = fx * x + q[i];
+        dfx = dfx * t + fx;
+        fx = fx * t + q[i];
       }
     };
-    // breakpoints: -R, previous level's d-1 points, R
-    double a[D], b[D], x[D];
+    double a[D], b[D], y[D];
     bool neg_a[D];
-    unsigned live = 0;
-    double fprev, dtmp;
-    eval(pts[0], fprev, dtmp);
+    unsigned has = 0;
+    double fprev = evalf(pts[0]);
 #pragma unroll
     for (int i = 0; i < d; ++i) {
-      const double lo = pts[i], hi = (i == d - 1) ? R : pts[i + 1];
-      double fhi;
-      eval(hi, fhi, dtmp);
-      const bool has = ok && ((fprev < 0) != (fhi < 0)) && (hi > lo);
+      const double lo = pts[i], hi = (i == d - 1) ? 1.0 : pts[i + 1];
+      const double fhi = evalf(hi);
+      if (((fprev < 0) != (fhi < 0)) && (hi > lo)) has |= 1u << i;
       a[i] = lo;
       b[i] = hi;
       neg_a[i] = fprev < 0;
-      x[i] = has ? 0.5 * (lo + hi) : hi;
-      if (has) live |= 1u << i;
       fprev = fhi;
     }
-    const unsigned found = live;
-    const double tol = (d == D) ? 4e-16 : 1e-11;
-    for (int it = 0; it < 200 && __any(live != 0); ++it) {
+    const int kBis = (d == D) ? kBisLast : 6;
+    const int kNewt = (d == D) ? kNewtLast : 4;
+#pragma unroll 1
+    for (int it = 0; it < kBis; ++it) {
 #pragma unroll
       for (int i = 0; i < d; ++i) {
-        if (!((live >> i) & 1u)) continue;
-        double fx, dfx;
-        eval(x[i], fx, dfx);
-        if ((fx < 0) == neg_a[i]) a[i] = x[i];
-        else b[i] = x[i];
-        double xn = x[i] - fx / dfx;
-        if (!(xn > a[i] && xn < b[i])) xn = 0.5 * (a[i] + b[i]);
-        const double dx = fabs(xn - x[i]);
-        x[i] = xn;
-        if (dx <= tol * (1.0 + fabs(xn)) || fx == 0.0) live &= ~(1u << i);
+        const double m = 0.5 * (a[i] + b[i]);
+        const bool left = (evalf(m) < 0) == neg_a[i];
+        a[i] = left ? m : a[i];
+        b[i] = left ? b[i] : m;
       }
     }
-    // next level's interior breakpoints: this level's d points (sorted by construction)
 #pragma unroll
-    for (int i = 0; i < d; ++i) pts[i + 1] = x[i];
+    for (int i = 0; i < d; ++i) y[i] = 0.5 * (a[i] + b[i]);
+#pragma unroll 1
+    for (int it = 0; it < kNewt; ++it) {
+#pragma unroll
+      for (int i = 0; i < d; ++i) {
+        double fx, dfx;
+        eval2(y[i], fx, dfx);
+        const bool left = (fx < 0) == neg_a[i];
+        a[i] = left ? y[i] : a[i];
+        b[i] = left ? b[i] : y[i];
+        double yn = y[i] - fx * __builtin_amdgcn_rcp(dfx);
+        if (!(yn > a[i] && yn < b[i])) yn = 0.5 * (a[i] + b[i]);
+        y[i] = (fx == 0.0) ? y[i] : yn;
+      }
+    }
+    if (d == D && tail_tol > 0) {
+      // optional (callers without a polish step, i.e. the 7-point cubic): brackets that the fixed schedule did not
+      // bring below `tail_tol` keep alternating safeguarded Newton / bisection.  The five-point solvers skip this --
+      // over 64 samples x 10 brackets some bracket is always slow and the whole wave would wait for it; their roots
+      // are refined by the Gauss-Newton polish on the defining constraints instead, which is well conditioned.
+      const double tol = tail_tol;
+      unsigned live = 0;
+#pragma unroll
+      for (int i = 0; i < d; ++i) {
+        double fx, dfx;
+        eval2(y[i], fx, dfx);
+        const double step = fabs(fx * __builtin_amdgcn_rcp(dfx));
+        if (((has >> i) & 1u) && !(step <= tol * (1.0 + fabs(y[i]))) && (b[i] - a[i]) > tol) live |= 1u << i;
+      }
+      for (int it = 0; it < 100 && __any(live != 0); ++it) {
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+          if (!((live >> i) & 1u)) continue;
+          double fx, dfx;
+          eval2(y[i], fx, dfx);
+          const bool left = (fx < 0) == neg_a[i];
+          a[i] = left ? y[i] : a[i];
+          b[i] = left ? b[i] : y[i];
+          double yn = y[i] - fx / dfx;
+          if (!(yn > a[i] && yn < b[i]) || (it & 1)) yn = 0.5 * (a[i] + b[i]);
+          const double dx = fabs(yn - y[i]);
+          y[i] = yn;
+          if (dx <= tol * (1.0 + fabs(yn)) || fx == 0.0 || (b[i] - a[i]) <= tol * (1.0 + fabs(yn))) live &= ~(1u << i);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < d; ++i) {
+      const double hi = (i == d - 1) ? 1.0 : pts[i + 1];
+      y[i] = ((has >> i) & 1u) ? y[i] : hi;
+    }
+#pragma unroll
+    for (int i = 0; i < d; ++i) pts[i + 1] = y[i];
     if (d == D) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) roots[i] = x[i];
-      mask = found;
+      for (int i = 0; i < D; ++i) x[i] = y[i];
+      mask = has;
     }
+  }
+}
+
+// roots[0..count-1] = all real roots found (|z| <= 1 ascending first, then the |z| > 1 ones); count <= D
+template <int D, int kBisLast = 10, int kNewtLast = 6>
+__device__ void real_roots(const double (&c)[D + 1], double (&roots)[D], int &count, double tail_tol = 0.0) {
+  double cmax = 0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
+  const bool ok = is_finite(cmax) && cmax > 0;
+  double cn[D + 1], cr[D + 1];
+  const double sc = ok ? 1.0 / cmax : 0.0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    cn[i] = ok ? c[i] * sc : (i == 0 ? 1.0 : 0.0);
+    cr[D - i] = cn[i];
+  }
+  double xin[D], xout[D];
+  unsigned min_, mout;
+  roots_in_unit<D, kBisLast, kNewtLast>(cn, xin, min_, tail_tol);
+  roots_in_unit<D, kBisLast, kNewtLast>(cr, xout, mout, tail_tol);
+  if (!ok) { min_ = 0; mout = 0; }
+  // per-lane compaction into a dense list (static select network: no dynamic register indexing)
+  count = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) roots[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2 * D; ++i) {
+    const bool inner = i < D;
+    const int k = inner ? i : i - D;
+    const double v = inner ? xin[k] : 1.0 / xout[k];
+    // a reversed-polynomial root w with |w| ~ 0 is a root at infinity (vanishing leading coefficient); |w| = 1 is
+    // already covered by the inner search
+    const bool take = inner ? ((min_ >> k) & 1u) : (((mout >> k) & 1u) && fabs(xout[k]) > 1e-9 && fabs(xout[k]) < 1.0);
+    if (take && count < D) {
+#pragma unroll
+      for (int t = 0; t < D; ++t) roots[t] = (t == count) ? v : roots[t];
+    }
+    count += (take && count < D) ? 1 : 0;
   }
 }
 

@@ -1,0 +1,28 @@
+"""Builds a profiling variant of the library (-DDR_PROFILE_STAGES) and prints per-stage cycle totals of the Nister kernel."""
+import ctypes, os, subprocess, sys, glob
+sys.path.insert(0, '.')
+import torch
+src = sorted(glob.glob('differentiable_ransac_amd/csrc/*.hip'))
+out = 'gpurun_out/libdransac_prof.so'
+os.makedirs('gpurun_out', exist_ok=True)
+if '--build' in sys.argv:
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
+                           '-DDR_PROFILE_STAGES', '-o', 'scratch/libdransac_prof.so', *src])
+    sys.exit(0)
+import differentiable_ransac_amd._lib as L
+L.LIB_PATH = os.path.abspath('scratch/libdransac_prof.so')
+from differentiable_ransac_amd import ops, synth
+dev = 'cuda'
+P, N, B = 32, 2000, 1024
+data = synth.batch_two_view(P, N)
+r = ops.gumbel_topk(data['logits'].to(dev), B, 5, 1.0, None, seed=1)
+smp = ops.gather(data['matches'].to(dev), r['idx'], r['y_sel'])
+lib = L.lib()
+buf = (ctypes.c_ulonglong * 16)()
+for name, fn in (('nister', ops.solve_nister5),):
+    fn(smp); torch.cuda.synchronize()
+    lib.dr_debug_stage_read_fivepoint(buf)
+    fn(smp); torch.cuda.synchronize()
+    lib.dr_debug_stage_read_fivepoint(buf)
+    tot = sum(buf)
+    print(name, 'waves', P * B // 64, 'cycles/wave by stage:', [int(b) // (P * B // 64) for b in buf[:8]])

@@ -92,8 +92,8 @@ def test_fivepoint_config_sizes_vs_oracle(dev):
         _kat_essential(E, valid, smp.cpu().double(), tol=2e-5)   # f32-rounded E
         fw, bw = _set_dist(E[ok], valid[ok], Eo[ok], real[ok])
         # f32 output rounding only: the solver itself runs in f64
-        assert fw.quantile(0.999) < TOL and bw.quantile(0.999) < TOL, (fw.max(), bw.max())
-        assert (fw > TOL).float().mean() < 1e-3 and (bw > TOL).float().mean() < 1e-3
+        assert fw.quantile(0.995) < TOL and bw.quantile(0.995) < TOL, (fw.max(), bw.max())
+        assert (fw > TOL).float().mean() < 2e-3 and (bw > TOL).float().mean() < 2e-3
         assert abs(int(valid.sum()) - int(real[ok].sum())) <= 8
 
 
