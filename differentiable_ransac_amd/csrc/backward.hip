@@ -50,8 +50,9 @@ __device__ __forceinline__ bool solve_spd5(double (&G)[5][5], double (&b)[5]) {
   return true;
 }
 
+template <typename MT>
 __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restrict__ samples,
-                                                           const float *__restrict__ models,
+                                                           const MT *__restrict__ models,
                                                            const uint8_t *__restrict__ valid,
                                                            const float *__restrict__ grad_models, int Bt,
                                                            float *__restrict__ grad_samples) {
@@ -562,12 +563,17 @@ __global__ __launch_bounds__(kBT) void rigid_residual_bwd_kernel(const float *__
 
 extern "C" {
 
-int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const uint8_t *valid,
-                             const float *grad_models, int Bt, float *grad_samples, void *stream) {
-  DR_REQUIRE(samples && models && valid && grad_models && grad_samples, "null pointer");
+int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const double *models_f64,
+                             const uint8_t *valid, const float *grad_models, int Bt, float *grad_samples,
+                             void *stream) {
+  DR_REQUIRE(samples && (models || models_f64) && valid && grad_models && grad_samples, "null pointer");
   DR_REQUIRE(Bt > 0, "need Bt > 0");
-  hipLaunchKernelGGL(dr::fivepoint_bwd_kernel, dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, samples, models,
-                     valid, grad_models, Bt, grad_samples);
+  if (models_f64)
+    hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<double>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       samples, models_f64, valid, grad_models, Bt, grad_samples);
+  else
+    hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<float>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       samples, models, valid, grad_models, Bt, grad_samples);
   return dr::check_launch("fivepoint_bwd_kernel");
 }
 

@@ -256,26 +256,32 @@ class _SolveEssential(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, samples, weights, which):
-        if which == "nister":
-            models, valid = solve_nister5(samples, weights)
+        fn = (lambda s_, w_: solve_nister5(s_, w_)) if which == "nister" else (lambda s_, w_: solve_stewenius5(s_))
+        need_grad = samples.requires_grad and samples.dtype == torch.float32
+        if need_grad:
+            # train mode: run the f64 entry point on the (exactly representable) f32 samples and keep the f64 models
+            # for the backward -- its tangent-space system is conditioned ~1e5, which f32-rounded models cannot afford
+            m64, valid = fn(samples.double(), None if weights is None else weights.double())
+            models = m64.float()
         else:
-            models, valid = solve_stewenius5(samples)
-        ctx.save_for_backward(samples, models, valid)
+            models, valid = fn(samples, weights)
+            m64 = torch.empty(0, device=samples.device, dtype=torch.float64)
+        ctx.save_for_backward(samples, models, m64, valid)
         ctx.minimal = samples.shape[-2] == 5
         ctx.mark_non_differentiable(valid)
         return models, valid
 
     @staticmethod
     def backward(ctx, g_models, _g_valid):
-        samples, models, valid = ctx.saved_tensors
+        samples, models, m64, valid = ctx.saved_tensors
         if not ctx.minimal:
             raise L.DransacError("backward of the non-minimal five-point fallback is not defined (refit is test-mode only)")
         if samples.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
         s, Bt, _ = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
-        L.call("dr_solve_nister5_bwd_f32", ptr(s), ptr(models.contiguous()), ptr(valid.contiguous().view(torch.uint8)),
-               ptr(g_models.contiguous()), c_int(Bt), ptr(gs), stream())
+        L.call("dr_solve_nister5_bwd_f32", ptr(s), ptr(models.contiguous()), ptr(m64.contiguous() if m64.numel() else None),
+               ptr(valid.contiguous().view(torch.uint8)), ptr(g_models.contiguous()), c_int(Bt), ptr(gs), stream())
         return gs.reshape(samples.shape), None, None
 
 

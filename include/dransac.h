@@ -125,8 +125,11 @@ int dr_solve_rigid_f64(const double *samples, const double *weights, int Bt, int
 /* Backward of the minimal solvers by implicit differentiation of the defining constraints at the
  * returned model.  grad_models has the forward's model shape; grad_samples [Bt,k,c]
  * is overwritten.  Invalid slots contribute nothing. */
-int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const uint8_t *valid,
-                             const float *grad_models, int Bt, float *grad_samples, void *stream);
+/* models_f64 (optional, preferred): the same models computed by dr_solve_nister5_f64 on the same samples -- with
+ * f32-rounded models the epipolar residual (6e-8) is amplified by the conditioning of the tangent-space system. */
+int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const double *models_f64,
+                             const uint8_t *valid, const float *grad_models, int Bt, float *grad_samples,
+                             void *stream);
 int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float *models, const float *grad_models,
                         int Bt, int n, float *grad_samples, float *grad_weights, void *stream);
 int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const float *grad_models, int Bt, int n,

@@ -142,7 +142,7 @@ def test_fivepoint_backward_finite_difference(dev):
             tot = tot + (sgn * cand[j] * W[b, sl]).sum()
         return tot
 
-    eps = 1e-6
+    eps = 2e-5   # the oracle's own solutions are good to ~1e-9: smaller steps drown in that noise
     num = torch.zeros_like(smp)
     base = smp.float().double()
     for b in range(B):
@@ -153,7 +153,7 @@ def test_fivepoint_backward_finite_difference(dev):
                 xm[k, d] -= eps
                 num[b, k, d] = (loss_cpu(xp, b) - loss_cpu(xm, b)) / (2 * eps)
     rel = (g - num).abs().amax((-1, -2)) / num.abs().amax((-1, -2)).clamp(min=1e-9)
-    assert rel.median() < 1e-3 and rel.max() < 5e-2, (rel.median(), rel.max())
+    assert rel.median() < 1e-3 and rel.max() < 2e-2, (rel.median(), rel.max())
     # Stewenius shares the backward (same manifold, same constraints)
     s32b = smp.float().to(dev).requires_grad_(True)
     E2, v2 = ops.solve_essential(s32b, None, "stewenius")
