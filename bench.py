@@ -112,20 +112,22 @@ def main():
     rn = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
                        seed=1234 + rank, keep_masks=True, refit=False)
 
+    # HIP events bracket exactly the dr_msac_score launch (the ctypes call), on the stream it is launched on
+    from differentiable_ransac_amd import _lib as L
     ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in range(args.steps)]
     state = {"i": -1}
-    orig_msac = ops.msac_score
+    orig_call = L.call
 
-    def timed_msac(m, md, thr, want_masks=True):
+    def timed_call(name, *a):
         i = state["i"]
-        if 0 <= i < args.steps and want_masks:
+        if 0 <= i < args.steps and name.startswith("dr_msac_score_f"):
             ev[i][0].record()
-            out = orig_msac(m, md, thr, want_masks)
+            orig_call(name, *a)
             ev[i][1].record()
-            return out
-        return orig_msac(m, md, thr, want_masks)
+        else:
+            orig_call(name, *a)
 
-    ops.msac_score = timed_msac
+    L.call = timed_call
 
     def step():
         return rn(matches, logits, K1, K2)

@@ -184,6 +184,92 @@ __global__ __launch_bounds__(kThreads) void select_best_kernel(const T *__restri
   if (tid == 0 && inliers) inliers[p] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// ---- K6 fused: arg-max + "is it better" + best mask + adaptive stop, all per-pair state on the device ----------
+// (ransac.py:109-144 and adaptive_iteration_number :202-215).  One 1024-thread block per pair.
+constexpr int kUpdThreads = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
+    const T *__restrict__ matches, const T *__restrict__ models, const uint8_t *__restrict__ valid,
+    const T *__restrict__ scores, const T *__restrict__ thr, int M, int N, int B, int k, double confidence,
+    double eps, int max_iterations, T *__restrict__ best_score, T *__restrict__ best_model,
+    uint8_t *__restrict__ best_mask, int32_t *__restrict__ best_inliers, int32_t *__restrict__ iters,
+    double *__restrict__ max_iters) {
+  __shared__ T s_val[kUpdThreads / kWave];
+  __shared__ int s_idx[kUpdThreads / kWave];
+  __shared__ int s_cnt[kUpdThreads / kWave];
+  __shared__ int s_flag;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int it0 = iters[p];
+  if ((double)it0 >= max_iters[p]) return;  // this pair has terminated (uniform across the block)
+  const T *sc = scores + (size_t)p * M;
+  const uint8_t *vd = valid ? valid + (size_t)p * M : nullptr;
+  T bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int m0 = tid; m0 < M; m0 += 4 * kUpdThreads) {
+    T v[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * kUpdThreads;
+      v[u] = m < M ? sc[m] : T(0);
+      ok[u] = m < M && (!vd || vd[m]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + u * kUpdThreads;
+      if (ok[u] && v[u] == v[u] && (v[u] > bv || (v[u] == bv && m < bi))) { bv = v[u]; bi = m; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T ov = __shfl_xor(bv, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
+  __syncthreads();
+  bv = s_val[0]; bi = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < kUpdThreads / kWave; ++w)
+    if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+  const bool have = bi != 0x7fffffff;
+  const bool better = have && (bv > best_score[p] || it0 == 0);   // ransac.py:116
+  if (better) {
+    T m[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m[q] = models[((size_t)p * M + bi) * 9 + q];
+    const T t = T(1.5) * thr[p];
+    const T inv_thr2 = T(1) / (t * t);
+    int cnt = 0;
+    for (int n = tid; n < N; n += kUpdThreads) {
+      const T *q = matches + ((size_t)p * N + n) * 4;
+      const bool in = sampson_s<T>(m, q[0], q[1], q[2], q[3], inv_thr2) < T(0);
+      best_mask[(size_t)p * N + n] = in;
+      cnt += in;
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) s_cnt[wv] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+      int inl = 0;
+#pragma unroll
+      for (int w = 0; w < kUpdThreads / kWave; ++w) inl += s_cnt[w];
+      best_inliers[p] = inl;
+      best_score[p] = bv;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) best_model[(size_t)p * 9 + q] = m[q];
+      // adaptive_iteration_number, ransac.py:202-215
+      const double ratio = (double)inl / (double)N;
+      const double prob = 1.0 - pow(ratio, (double)k);
+      double mi = (double)max_iterations;
+      if (!(prob >= 1.0 - eps)) mi = fmax(0.0, log10(1.0 - confidence) / log10(1.0 - pow(ratio, (double)k) + eps));
+      max_iters[p] = fmin((double)max_iterations, mi);
+    }
+  }
+  if (tid == 0) iters[p] = it0 + B;
+}
+
 template <typename T>
 int msac_score_launch(const T *matches, const T *models, const T *thr, int P, int M, int N, T *scores,
                       uint8_t *masks, hipStream_t st) {
@@ -235,6 +321,32 @@ int dr_select_best_f32(const float *matches, const float *models, const uint8_t 
   hipLaunchKernelGGL((dr::select_best_kernel<float>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches,
                      models, valid, scores, thr, M, N, best_idx, best_score, best_model, best_mask, inliers);
   return dr::check_launch("select_best_kernel");
+}
+
+int dr_ransac_update_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
+                         const float *thr, int P, int M, int N, int B, int k, double confidence, double eps,
+                         int max_iterations, float *best_score, float *best_model, uint8_t *best_mask,
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+  DR_REQUIRE(matches && models && scores && thr && best_score && best_model && best_mask && best_inliers && iters &&
+                 max_iters, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && B > 0 && k > 0, "bad sizes");
+  hipLaunchKernelGGL((dr::ransac_update_kernel<float>), dim3(P), dim3(dr::kUpdThreads), 0, (hipStream_t)stream,
+                     matches, models, valid, scores, thr, M, N, B, k, confidence, eps, max_iterations, best_score,
+                     best_model, best_mask, best_inliers, iters, max_iters);
+  return dr::check_launch("ransac_update_kernel");
+}
+
+int dr_ransac_update_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,
+                         const double *thr, int P, int M, int N, int B, int k, double confidence, double eps,
+                         int max_iterations, double *best_score, double *best_model, uint8_t *best_mask,
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+  DR_REQUIRE(matches && models && scores && thr && best_score && best_model && best_mask && best_inliers && iters &&
+                 max_iters, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && B > 0 && k > 0, "bad sizes");
+  hipLaunchKernelGGL((dr::ransac_update_kernel<double>), dim3(P), dim3(dr::kUpdThreads), 0, (hipStream_t)stream,
+                     matches, models, valid, scores, thr, M, N, B, k, confidence, eps, max_iterations, best_score,
+                     best_model, best_mask, best_inliers, iters, max_iters);
+  return dr::check_launch("ransac_update_kernel");
 }
 
 int dr_select_best_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,

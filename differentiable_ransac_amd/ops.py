@@ -56,6 +56,32 @@ def select_best(matches: torch.Tensor, models: torch.Tensor, scores: torch.Tenso
     return best_idx, best_score, best_model, best_mask, inliers
 
 
+class RansacState:
+    """Per-pair test-mode state kept on the device (best score / model / mask / inlier count, iteration counters)."""
+
+    def __init__(self, P: int, N: int, max_iterations: int, device, dtype):
+        self.best_score = torch.zeros(P, device=device, dtype=dtype)
+        self.best_model = torch.eye(3, device=device, dtype=dtype).repeat(P, 1, 1)
+        self.best_mask = torch.zeros(P, N, device=device, dtype=torch.bool)
+        self.best_inliers = torch.zeros(P, device=device, dtype=torch.int32)
+        self.iters = torch.zeros(P, device=device, dtype=torch.int32)
+        self.max_iters = torch.full((P,), float(max_iterations), device=device, dtype=torch.float64)
+        self.max_iterations = max_iterations
+
+
+def ransac_update(state: RansacState, matches, models, valid, scores, thr, B: int, k: int, confidence: float = 0.999,
+                  eps: float = 1e-5) -> None:
+    """K6 fused (dr_ransac_update): arg-max, best-model bookkeeping and adaptive termination, in place, one launch."""
+    P, N, _ = matches.shape
+    M = models.shape[1]
+    v = None if valid is None else valid.contiguous().view(torch.uint8)
+    L.call(f"dr_ransac_update_{L.suffix(matches.dtype)}", ptr(matches), ptr(models.contiguous()), ptr(v),
+           ptr(scores.contiguous()), ptr(thr), c_int(P), c_int(M), c_int(N), c_int(B), c_int(k),
+           L.c_double(confidence), L.c_double(eps), c_int(state.max_iterations), ptr(state.best_score),
+           ptr(state.best_model), ptr(state.best_mask), ptr(state.best_inliers), ptr(state.iters), ptr(state.max_iters),
+           stream())
+
+
 # ------------------------------------------------------------------------------------------ K1 / K1u / K2
 def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0,
                 gumbel: Optional[torch.Tensor] = None, seed: int = 0, N: Optional[int] = None,

@@ -272,39 +272,26 @@ class BatchedRANSAC(object):
             return torch.cat([c for c, _ in out], dim=1), torch.cat([k for _, k in out], dim=1)
 
         with torch.no_grad():
-            best_score = torch.zeros(P, device=dev, dtype=dt)
-            best_model = torch.eye(3, device=dev, dtype=dt).repeat(P, 1, 1)
-            best_mask = torch.zeros(P, N, device=dev, dtype=torch.bool)
-            best_inl = torch.zeros(P, device=dev, dtype=torch.int32)
-            iters = torch.zeros(P, device=dev, dtype=torch.int64)
-            max_it = torch.full((P,), float(self.max_iterations), device=dev, dtype=torch.float64)
+            st = ops.RansacState(P, N, self.max_iterations, dev, dt)
             all_masks = None
+            matches = matches.contiguous()
             for r in range(rounds):
                 g = None if gumbels is None else (gumbels[r] if r < len(gumbels) else None)
                 if gumbels is not None and g is None:
                     break
-                active = iters.double() < max_it
                 models, valid, _ = self.hypotheses(matches, logits, g)
                 flat = models.reshape(P, self.B * self.S, 3, 3)
                 scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks)
                 if self.keep_masks:
                     all_masks = masks
-                bi, bs, bm, bmask, inl = ops.select_best(matches, flat, scores, thr, valid.reshape(P, -1))
-                better = active & ((bs > best_score) | (iters == 0)) & (bi >= 0)
-                best_score = torch.where(better, bs, best_score)
-                best_model = torch.where(better[:, None, None], bm, best_model)
-                best_mask = torch.where(better[:, None], bmask, best_mask)
-                best_inl = torch.where(better, inl, best_inl)
-                # adaptive stop, ransac.py:135-142 / 202-215, on the device
-                ratio = best_inl.double() / N
-                p_fail = 1.0 - ratio ** self.k
-                new_max = torch.where(p_fail >= 1.0 - self.eps, torch.full_like(max_it, float(self.max_iterations)),
-                                      (math.log10(1.0 - self.confidence) / torch.log10(p_fail + self.eps)).clamp(min=0.0))
-                max_it = torch.where(better, torch.minimum(new_max, torch.full_like(max_it, float(self.max_iterations))),
-                                     max_it)
-                iters = iters + torch.where(active, self.B, 0)
-                if r + 1 < rounds and not bool((iters.double() < max_it).any()):
+                # K6: arg-max, "better?" test, best mask / inlier count and the adaptive stop of ransac.py:135-142, on the device
+                ops.ransac_update(st, matches, flat, valid.reshape(P, -1), scores, thr, self.B, self.k, self.confidence,
+                                  self.eps)
+                # one host sync per round, only when another round could follow
+                if r + 1 < rounds and not bool((st.iters.double() < st.max_iters).any()):
                     break
+            best_score, best_model, best_mask, best_inl, iters = (st.best_score, st.best_model, st.best_mask,
+                                                                  st.best_inliers, st.iters.long())
             if self.refit:
                 if self.fmat:
                     cand = []

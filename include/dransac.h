@@ -184,6 +184,23 @@ int dr_select_best_f64(const double *matches, const double *models, const uint8_
                        const double *thr, int P, int M, int N, int32_t *best_idx, double *best_score,
                        double *best_model, uint8_t *best_mask, int32_t *inliers, void *stream);
 
+/* K6 (batched, state on the device)  RANSAC.__call__ ransac.py:109-144 + adaptive_iteration_number :202-215.
+ *   For every pair p with iters[p] < max_iters[p] (the others have terminated and are left untouched):
+ *     b = first arg-max of scores[p] over valid, non-NaN models;
+ *     if scores[p,b] > best_score[p] or iters[p] == 0:  best_score / best_model [P,9] / best_mask [P,N] /
+ *         best_inliers <- model b (mask recomputed), max_iters[p] = min(max_iterations,
+ *         log10(1-confidence) / log10(1 - (inliers/N)^k + eps))   (computed in f64);
+ *     iters[p] += B.
+ *   The caller initialises best_score = 0, iters = 0, max_iters = max_iterations. */
+int dr_ransac_update_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
+                         const float *thr, int P, int M, int N, int B, int k, double confidence, double eps,
+                         int max_iterations, float *best_score, float *best_model, uint8_t *best_mask,
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+int dr_ransac_update_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,
+                         const double *thr, int P, int M, int N, int B, int k, double confidence, double eps,
+                         int max_iterations, double *best_score, double *best_model, uint8_t *best_mask,
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
