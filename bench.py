@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--hyps", type=int, default=1024)
     ap.add_argument("--solver", default="nister", choices=["nister", "stewenius", "f8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--profile-kernels", action="store_true", help="per-kernel HIP-event breakdown (extra syncs)")
     return ap.parse_args()
 
@@ -48,19 +48,22 @@ def parse():
 def cpu_baseline(args, pairs_data):
     """The CPU oracle (oracle/cpu_ref.py, a vectorised torch restatement of the reference path) timed on the host
     cores, on a bounded sample of the same workload: whole pairs (N points x B hypotheses), one after the other like
-    the reference's per-pair loop (model_cl.py:488), until the time budget is spent."""
+    the reference's per-pair loop (model_cl.py:488), until the time budget is spent.  The thread count is calibrated
+    first (torch's small batched LAPACK calls collapse when oversubscribed: 256 threads are 250x slower than 16 here)."""
     from oracle import cpu_ref as O
     from differentiable_ransac_amd import synth
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     k = 8 if args.solver == "f8" else 5
-    done, t_used = 0, 0.0
-    with torch.no_grad():
-        while t_used < args.cpu_seconds and done < pairs_data["matches"].shape[0]:
-            m = pairs_data["matches"][done]
-            lg = pairs_data["logits"][done]
-            noise = synth.gumbel_noise((args.hyps, args.points), seed=1000 + done)
-            t0 = time.perf_counter()
+    noise_cache = {}
+
+    def one_pair(i):
+        m = pairs_data["matches"][i % pairs_data["matches"].shape[0]]
+        lg = pairs_data["logits"][i % pairs_data["logits"].shape[0]]
+        if i not in noise_cache:
+            noise_cache[i] = synth.gumbel_noise((args.hyps, args.points), seed=1000 + i)
+        noise = noise_cache[i]
+        t0 = time.perf_counter()
+        with torch.no_grad():
             idx, ret, _ = O.gumbel_topk(lg, noise, 1.0, k)
             smp = O.gather_samples(m, ret)
             if args.solver == "f8":
@@ -72,15 +75,25 @@ def cpu_baseline(args, pairs_data):
                 models = O.compact_models(E, ok)
             scores, masks = O.msac_score(m, models, 7.5e-4, chunk=2048)
             b = int(torch.argmax(torch.nan_to_num(scores, nan=-1.0)))
-            _ = masks[b].sum()
-            dt = time.perf_counter() - t0
-            if done > 0 or dt > args.cpu_seconds:   # first pair = warm-up unless it alone exceeds the budget
-                t_used += dt
-            done += 1
-    timed = max(done - 1, 1)
-    return {"value": timed * args.hyps / max(t_used, 1e-9), "unit": "hypotheses/s", "cores": cores, "kind": "port",
-            "sample": f"{timed} pair(s) x {args.points} pts x {args.hyps} hyps, torch-CPU f32 oracle "
-                      f"(sample+gather+solve+score+argmax), {t_used:.1f} s"}
+            _ = int(masks[b].sum())
+        return time.perf_counter() - t0
+
+    best_t, best_n = None, 1
+    for n in sorted({1, min(8, cores), min(16, cores), min(32, cores)}):
+        torch.set_num_threads(n)
+        one_pair(0)                       # warm-up at this thread count
+        t = min(one_pair(0), one_pair(0))
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+    torch.set_num_threads(best_n)
+    done, t_used = 0, 0.0
+    while t_used < args.cpu_seconds and done < 4096:
+        t_used += one_pair(1 + done % 64)
+        done += 1
+    return {"value": done * args.hyps / max(t_used, 1e-9), "unit": "hypotheses/s", "cores": best_n, "kind": "port",
+            "host_cores": cores,
+            "sample": f"{done} pair(s) x {args.points} pts x {args.hyps} hyps, torch-CPU f32 oracle "
+                      f"(sample+gather+solve+score+argmax), {t_used:.1f} s, threads calibrated over 1/8/16/32"}
 
 
 def main():
@@ -148,10 +161,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     state["i"] = -1
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    # whole-job rate = sum of hypotheses over ranks / max elapsed over ranks (no data-path collective: SURVEY 8(e))
+    from differentiable_ransac_amd import sharding
+    job_hyps_per_s, elapsed = sharding.job_throughput(P * B * args.steps, elapsed, dist, dev)
 
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included
@@ -163,7 +175,7 @@ def main():
 
     result = {
         "metric": "hypotheses/sec (and image-pairs/sec) at 2000 pts x 1024 hyps, 1/2/4/8 GPU",
-        "value": world * P * B * args.steps / elapsed,
+        "value": job_hyps_per_s,
         "unit": "hypotheses/s",
         "n_gpus": world,
         "steps": args.steps,
