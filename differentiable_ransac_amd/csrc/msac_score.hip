@@ -122,6 +122,126 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
   }
 }
 
+// ---- f32 fast path ---------------------------------------------------------------------------------------------
+// Same mapping as above, hand-shaped for the VALU (the binding unit at this shape):
+//  * points are processed in PAIRS so that the 19 FMAs per (model, point) become v_pk_fma_f32 (two lanes-worth of
+//    FMAs per issue; the model coefficient is an SGPR broadcast to both halves through op_sel);
+//  * the next model's nine coefficients are fetched through the scalar cache while the current one is evaluated;
+//  * non-finite models are detected on the scalar unit from the exponent bits (no VALU work);
+//  * the soft score is acc = fma(max(-s, 0), w, acc) with a per-point 0/1 weight (tail handling for free) and the
+//    mask byte is the sign bit of s, packed four at a time with v_perm_b32.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
+
+__global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const float *__restrict__ matches,
+                                                                       const float *__restrict__ models,
+                                                                       const float *__restrict__ thr, int M, int N,
+                                                                       float *__restrict__ scores,
+                                                                       uint8_t *__restrict__ masks, int write_masks,
+                                                                       int chunks_per_block, int use_atomic) {
+  __shared__ float part[kThreads / kWave][kModelsPerBlock];
+  const int p = blockIdx.z;
+  const int m0 = blockIdx.x * kModelsPerBlock;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mcount = min(kModelsPerBlock, M - m0);
+  const float t = 1.5f * thr[p];
+  const float inv_thr2 = 1.0f / (t * t);
+  const float *mt = matches + (size_t)p * N * 4;
+  const float *md = models + ((size_t)p * M + m0) * 9;
+  const bool row_aligned = (N % 8) == 0;
+  for (int i = tid; i < (kThreads / kWave) * kModelsPerBlock; i += kThreads) (&part[0][0])[i] = 0.f;
+  __syncthreads();
+
+  const int c_begin = blockIdx.y * chunks_per_block;
+  for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
+    if (c * kChunk >= N) break;
+    const int n0 = c * kChunk + tid * kPts;
+    v2f x1[kPts / 2], y1[kPts / 2], x2[kPts / 2], y2[kPts / 2], w[kPts / 2];
+#pragma unroll
+    for (int j = 0; j < kPts; ++j) {
+      const int n = n0 + j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) v = reinterpret_cast<const float4 *>(mt)[n];
+      x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+      w[j / 2][j & 1] = (n < N) ? 1.f : 0.f;
+    }
+    const int nvalid = min(kPts, max(0, N - n0));
+    uint32_t vlo = 0, vhi = 0;   // byte j = 1 for valid points
+#pragma unroll
+    for (int j = 0; j < kPts; ++j) {
+      if (j < nvalid) { if (j < 4) vlo |= 1u << (8 * j); else vhi |= 1u << (8 * (j - 4)); }
+    }
+
+    float mc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mc[q] = md[q];
+    for (int ml = 0; ml < mcount; ++ml) {
+      float m[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) m[q] = mc[q];
+      const int nx = (ml + 1 < mcount) ? ml + 1 : ml;   // prefetch the next model through the scalar cache
+#pragma unroll
+      for (int q = 0; q < 9; ++q) mc[q] = md[nx * 9 + q];
+      // scalar-unit finiteness test: largest exponent field over the nine coefficients
+      uint32_t ex = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
+      const bool finite = ex != 0x7f800000u;
+
+      v2f acc = splat(0.f);
+      uint32_t sb[kPts];
+#pragma unroll
+      for (int j = 0; j < kPts / 2; ++j) {
+        const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
+        const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
+        const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
+        const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
+        const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
+        const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
+        const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
+        const v2f rr = r * r;
+        v2f rc;
+        rc[0] = __builtin_amdgcn_rcpf(jj[0]);
+        rc[1] = __builtin_amdgcn_rcpf(jj[1]);
+        const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);   // s = d2/thr2 - 1
+        v2f mx;
+        mx[0] = fmaxf(-sv[0], 0.f);
+        mx[1] = fmaxf(-sv[1], 0.f);
+        acc = mx * w[j] + acc;
+        sb[2 * j] = __float_as_uint(sv[0]);
+        sb[2 * j + 1] = __float_as_uint(sv[1]);
+      }
+      float a = acc[0] + acc[1];
+      if (write_masks && nvalid > 0) {
+        // top bytes of four s values -> one dword, then sign bit -> bit 0 of each byte
+        const uint32_t t01 = __builtin_amdgcn_perm(sb[1], sb[0], 0x0c0c0703u);  // bytes: [s0.b3, s1.b3, 0, 0]
+        const uint32_t t23 = __builtin_amdgcn_perm(sb[3], sb[2], 0x07030c0cu);  // bytes: [0, 0, s2.b3, s3.b3]
+        const uint32_t t45 = __builtin_amdgcn_perm(sb[5], sb[4], 0x0c0c0703u);
+        const uint32_t t67 = __builtin_amdgcn_perm(sb[7], sb[6], 0x07030c0cu);
+        uint32_t lo = (((t01 | t23) >> 7) & 0x01010101u) & vlo;
+        uint32_t hi = (((t45 | t67) >> 7) & 0x01010101u) & vhi;
+        if (!finite) { lo = 0; hi = 0; }
+        uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
+        if (row_aligned && nvalid == kPts) {
+          *reinterpret_cast<uint2 *>(row) = make_uint2(lo, hi);
+        } else {
+          for (int j = 0; j < nvalid; ++j) row[j] = (uint8_t)(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 1u);
+        }
+      }
+      a = wave_sum(a);
+      if (lane == 0) part[wv][ml] += finite ? a : NAN;
+    }
+  }
+  __syncthreads();
+  if (tid < mcount) {
+    const float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    float *dst = scores + (size_t)p * M + m0 + tid;
+    if (use_atomic) atomicAdd(dst, v);
+    else *dst = v;
+  }
+}
+
 // ---- K6: per-pair first arg-max over valid, non-NaN scores; recompute the winner's mask -------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void select_best_kernel(const T *__restrict__ matches,
@@ -286,12 +406,18 @@ int msac_score_launch(const T *matches, const T *models, const T *thr, int P, in
     if (hipMemsetAsync(scores, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
   }
   dim3 grid(tiles, ny, P);
-  if (masks)
-    hipLaunchKernelGGL((msac_score_kernel<T, true>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N, scores,
-                       masks, cpb, use_atomic);
-  else
-    hipLaunchKernelGGL((msac_score_kernel<T, false>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N, scores,
-                       masks, cpb, use_atomic);
+  if constexpr (sizeof(T) == 4) {
+    hipLaunchKernelGGL(msac_score_kernel_f32_fast, grid, dim3(kThreads), 0, st, (const float *)matches,
+                       (const float *)models, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0, cpb,
+                       use_atomic);
+  } else {
+    if (masks)
+      hipLaunchKernelGGL((msac_score_kernel<T, true>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N, scores,
+                         masks, cpb, use_atomic);
+    else
+      hipLaunchKernelGGL((msac_score_kernel<T, false>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N,
+                         scores, masks, cpb, use_atomic);
+  }
   return check_launch("msac_score_kernel");
 }
 
