@@ -13,7 +13,7 @@
 
 namespace dr {
 
-constexpr int kFiveWs = 200;   // doubles of LDS per lane (Nister: the 10x20 matrix)
+constexpr int kFiveWs = 162;   // doubles of LDS per lane: B block (100) for the minimal path, A^T A + V (162) for n > 5
 constexpr int kStewWs = 212;   // Stewenius: 10x20, then Hessenberg 10x10 (0..99) + La Budde polynomials (100..209)
 
 // ---- null-space basis ---------------------------------------------------------------------------------
@@ -34,7 +34,7 @@ __device__ __forceinline__ void fivepoint_basis_minimal(const T *__restrict__ pt
 // with the smallest eigenvalues, by cyclic Jacobi in LDS.  Order: nb[0] <-> 4th smallest ... nb[3] <-> smallest,
 // which is the order torch.linalg.svd's Vh[-4:] has.
 template <typename T>
-__device__ void fivepoint_basis_nonminimal(const T *__restrict__ pts, const T *__restrict__ wts, int n,
+__device__ __forceinline__ void fivepoint_basis_nonminimal(const T *__restrict__ pts, const T *__restrict__ wts, int n,
                                            const LaneWs &ws, double (&nb)[4][9]) {
   LaneWs A{ws.base}, V{ws.base + 81 * 64};
   for (int e = 0; e < 81; ++e) A[e] = 0.0;
@@ -102,96 +102,114 @@ __device__ __forceinline__ void essential_residual(const double (&E)[9], double 
   r[9] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
 }
 
-__device__ __forceinline__ void polish_xyz(const double (&nb)[4][9], double &x, double &y, double &z, bool live) {
+// Gauss-Newton in HOMOGENEOUS coordinates: E = sum_k u_k N_k with |u| = 1 (so |E|_F = 1: the basis is orthonormal).
+// r(E) is homogeneous of degree 3, hence J u = 3 r ~ 0 and the normal matrix is singular along u; adding u u^T picks the
+// step orthogonal to u.  No chart, no scaling problem when a solution has a vanishing N3 component (|z| -> infinity), and
+// no per-root permutation of the basis (everything is statically indexed).
+__device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&u)[4], bool live) {
   // two iterations for everybody, then only waves that still hold an unconverged sample go on (max 8)
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     if (it >= 2 && !__any(live)) break;
     double E[9], r[10];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) E[q] = x * nb[0][q] + y * nb[1][q] + z * nb[2][q] + nb[3][q];
+    for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
     essential_residual(E, r);
     double n0 = 0;
 #pragma unroll
     for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
-    // directional derivatives along N0, N1, N2 by the exact polynomial identity D r[H] (r is cubic in E):
-    double J[3][10];
+    double J[4][10];
     double EEt[9], EtE[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        EEt[3 * i + j] = E[3 * i] * E[3 * j] + E[3 * i + 1] * E[3 * j + 1] + E[3 * i + 2] * E[3 * j + 2];
-        EtE[3 * i + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+      for (int jx = 0; jx < 3; ++jx) {
+        EEt[3 * i + jx] = E[3 * i] * E[3 * jx] + E[3 * i + 1] * E[3 * jx + 1] + E[3 * i + 2] * E[3 * jx + 2];
+        EtE[3 * i + jx] = E[i] * E[jx] + E[3 + i] * E[3 + jx] + E[6 + i] * E[6 + jx];
       }
     const double tr = EEt[0] + EEt[4] + EEt[8];
     const double cof[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
                            E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
                            E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
       const double(&H)[9] = nb[k];
-      // A = H E^T (3x3), then D = 2(H EtE + (A + A^T)... ) expanded:  H E^T E + E H^T E + E E^T H
       double HEt[9];
       double trEHt = 0;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          HEt[3 * i + j] = H[3 * i] * E[3 * j] + H[3 * i + 1] * E[3 * j + 1] + H[3 * i + 2] * E[3 * j + 2];
+        for (int jx = 0; jx < 3; ++jx)
+          HEt[3 * i + jx] = H[3 * i] * E[3 * jx] + H[3 * i + 1] * E[3 * jx + 1] + H[3 * i + 2] * E[3 * jx + 2];
 #pragma unroll
       for (int q = 0; q < 9; ++q) trEHt += E[q] * H[q];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double t1 = H[3 * i] * EtE[j] + H[3 * i + 1] * EtE[3 + j] + H[3 * i + 2] * EtE[6 + j];          // H E^T E
-          const double t2 = HEt[i] * E[j] + HEt[3 + i] * E[3 + j] + HEt[6 + i] * E[6 + j];                       // E H^T E = (H E^T)^T E
-          const double t3 = EEt[3 * i] * H[j] + EEt[3 * i + 1] * H[3 + j] + EEt[3 * i + 2] * H[6 + j];          // E E^T H
-          J[k][3 * i + j] = 2.0 * (t1 + t2 + t3) - 2.0 * trEHt * E[3 * i + j] - tr * H[3 * i + j];
+        for (int jx = 0; jx < 3; ++jx) {
+          const double t1 = H[3 * i] * EtE[jx] + H[3 * i + 1] * EtE[3 + jx] + H[3 * i + 2] * EtE[6 + jx];     // H E^T E
+          const double t2 = HEt[i] * E[jx] + HEt[3 + i] * E[3 + jx] + HEt[6 + i] * E[6 + jx];                  // E H^T E
+          const double t3 = EEt[3 * i] * H[jx] + EEt[3 * i + 1] * H[3 + jx] + EEt[3 * i + 2] * H[6 + jx];     // E E^T H
+          J[k][3 * i + jx] = 2.0 * (t1 + t2 + t3) - 2.0 * trEHt * E[3 * i + jx] - tr * H[3 * i + jx];
         }
       double dd = 0;
 #pragma unroll
       for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
       J[k][9] = dd;
     }
-    // normal equations (3x3, symmetric) by Cramer
-    double a[3][3], g[3];
+    // (J^T J + u u^T) d = J^T r : 4x4 SPD, LDL^T without pivoting
+    double a[4][4], g[4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
       g[i] = 0;
 #pragma unroll
       for (int q = 0; q < 10; ++q) g[i] += J[i][q] * r[q];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        a[i][j] = 0;
+      for (int jx = 0; jx < 4; ++jx) {
+        double acc = u[i] * u[jx];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) a[i][j] += J[i][q] * J[j][q];
+        for (int q = 0; q < 10; ++q) acc += J[i][q] * J[jx][q];
+        a[i][jx] = acc;
       }
     }
-    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
-                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
-    const double dx = (g[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (g[1] * a[2][2] - a[1][2] * g[2]) +
-                       a[0][2] * (g[1] * a[2][1] - a[1][1] * g[2])) / det;
-    const double dy = (a[0][0] * (g[1] * a[2][2] - a[1][2] * g[2]) - g[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
-                       a[0][2] * (a[1][0] * g[2] - g[1] * a[2][0])) / det;
-    const double dz = (a[0][0] * (a[1][1] * g[2] - g[1] * a[2][1]) - a[0][1] * (a[1][0] * g[2] - g[1] * a[2][0]) +
-                       g[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0])) / det;
-    const double nx = x - dx, ny = y - dy, nz = z - dz;
-    // accept only a step that does not increase the residual
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double inv = 1.0 / a[c][c];
+#pragma unroll
+      for (int rr = c + 1; rr < 4; ++rr) {
+        const double f = a[rr][c] * inv;
+#pragma unroll
+        for (int k = c; k < 4; ++k) a[rr][k] -= f * a[c][k];
+        g[rr] -= f * g[c];
+      }
+    }
+    double d[4];
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+      double acc = g[c];
+#pragma unroll
+      for (int k = c + 1; k < 4; ++k) acc -= a[c][k] * d[k];
+      d[c] = acc / a[c][c];
+    }
+    double un[4], nn = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { un[k] = u[k] - d[k]; nn += un[k] * un[k]; }
+    const double sc = 1.0 / sqrt(nn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) un[k] *= sc;
     double E2[9], r2[10], n1 = 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) E2[q] = nx * nb[0][q] + ny * nb[1][q] + nz * nb[2][q] + nb[3][q];
+    for (int q = 0; q < 9; ++q) E2[q] = un[0] * nb[0][q] + un[1] * nb[1][q] + un[2] * nb[2][q] + un[3] * nb[3][q];
     essential_residual(E2, r2);
 #pragma unroll
     for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
     const bool better = n1 <= n0 && is_finite(n1);
-    if (better && (live || it < 2)) { x = nx; y = ny; z = nz; }
-    // converged when the residual stops shrinking or is at rounding level relative to |E|^3
-    double e2 = 0;
+    if (better && (live || it < 2)) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) e2 += E2[q] * E2[q];
-    live = live && better && (n1 > 1e-28 * e2 * e2 * e2) && (n1 < 0.25 * n0);
+      for (int k = 0; k < 4; ++k) u[k] = un[k];
+    }
+    // |E| = 1: stop at rounding level, or when the residual no longer shrinks geometrically
+    live = live && better && (n1 > 1e-28) && (n1 < 0.25 * n0);
   }
 }
 
@@ -211,48 +229,20 @@ __device__ __forceinline__ void write_model(const double (&nb)[4][9], double x, 
     for (int j = 0; j < 3; ++j) dst[3 * i + j] = (T)(f[3 * j + i] * inv);
 }
 
-// Final stage shared by both solvers.  (x, y, z, 1) are the coefficients of E on the null-space basis.  The chart
-// "last coefficient = 1" is badly scaled when a solution has a (nearly) vanishing N3 component (|z| -> infinity), so the
-// coefficient vector is renormalised by its largest entry and the basis permuted to make that entry the fixed one before
-// the Gauss-Newton polish.  A candidate is accepted only if it verifies the constraints (relative residual <= 1e-7):
-// `valid` therefore means "checked essential matrix through the five points", not "the root finder said so".
+// Final stage shared by both solvers: homogeneous polish of the coefficient vector (x, y, z, 1)/|.|, then a
+// VERIFICATION of the ten constraints on the (unit-norm) matrix.  `valid` therefore means "checked essential matrix
+// through the five points", not "the root finder said so".
 template <typename T>
 __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double x, double y, double z, bool candidate,
                                                 T *__restrict__ dst, bool store) {
-  double v[4] = {x, y, z, 1.0};
-  int fix = 3;
-  double big = 1.0;
+  const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+  double u[4] = {x * inv, y * inv, z * inv, inv};
+  bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
+  if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
+  polish_homog(nb, u, good);
+  double E[9], r[10];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (fabs(v[i]) > big) { big = fabs(v[i]); fix = i; }
-  double vfix = 1.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) vfix = (i == fix) ? v[i] : vfix;
-  const double inv = 1.0 / vfix;
-  // permuted basis: pb[3] = nb[fix], pb[0..2] = the others in order; coefficients likewise
-  double pb[4][9], u[3];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    pb[3][q] = (fix == 0) ? nb[0][q] : (fix == 1) ? nb[1][q] : (fix == 2) ? nb[2][q] : nb[3][q];
-    pb[0][q] = (fix == 0) ? nb[1][q] : nb[0][q];
-    pb[1][q] = (fix <= 1) ? nb[2][q] : nb[1][q];
-    pb[2][q] = (fix <= 2) ? nb[3][q] : nb[2][q];
-  }
-  u[0] = ((fix == 0) ? v[1] : v[0]) * inv;
-  u[1] = ((fix <= 1) ? v[2] : v[1]) * inv;
-  u[2] = ((fix <= 2) ? v[3] : v[2]) * inv;
-  bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]);
-  polish_xyz(pb, u[0], u[1], u[2], good);
-  // verification on the unit-norm matrix
-  double E[9], r[10], n2 = 0;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    E[q] = u[0] * pb[0][q] + u[1] * pb[1][q] + u[2] * pb[2][q] + pb[3][q];
-    n2 += E[q] * E[q];
-  }
-  const double s = 1.0 / sqrt(n2);
-#pragma unroll
-  for (int q = 0; q < 9; ++q) E[q] *= s;
+  for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
   essential_residual(E, r);
   double rn = 0;
 #pragma unroll
@@ -262,14 +252,14 @@ __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) dst[3 * i + j] = (T)E[3 * j + i];   // stored transposed (nister.py:407)
+      for (int jx = 0; jx < 3; ++jx) dst[3 * i + jx] = (T)E[3 * jx + i];   // stored transposed (nister.py:407)
   }
   return good;
 }
 
 // ---- Nister: B(z) from the reduced rows, det B(z), roots, back-substitution -----------------------------
 template <typename T>
-__device__ void nister_finish(const double (&nb)[4][9], const LaneWs &w, bool ok, T *__restrict__ models,
+__device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const double (&X)[6][10], bool ok, T *__restrict__ models,
                               uint8_t *__restrict__ valid, bool active) {
   // reduced rows e..j = rows 4..9, right block columns 10..19 hold (x z^2, x z, x | y z^2, y z, y | z^3, z^2, z, 1)
   // k = e - z f, l = g - z h, m = i - z j  ->  B(z) columns (x: deg 3, y: deg 3, 1: deg 4), ascending coefficients
@@ -279,8 +269,8 @@ __device__ void nister_finish(const double (&nb)[4][9], const LaneWs &w, bool ok
     double hi[10], lo[10];
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
-      hi[c] = w[(4 + 2 * r) * 20 + 10 + c];
-      lo[c] = w[(5 + 2 * r) * 20 + 10 + c];
+      hi[c] = X[2 * r][c];
+      lo[c] = X[2 * r + 1][c];
     }
     // hi = (a2 z^2 + a1 z + a0) with hi[0]=a2,hi[1]=a1,hi[2]=a0 ; minus z*(lo)
     bx[r][0] = hi[2];          bx[r][1] = hi[1] - lo[2]; bx[r][2] = hi[0] - lo[1]; bx[r][3] = -lo[0];
@@ -355,7 +345,7 @@ __device__ void nister_finish(const double (&nb)[4][9], const LaneWs &w, bool ok
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void nister5_kernel(const T *__restrict__ samples, const T *__restrict__ weights,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_kernel(const T *__restrict__ samples, const T *__restrict__ weights,
                                                      int Bt, int n, T *__restrict__ models,
                                                      uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
@@ -373,11 +363,10 @@ __global__ __launch_bounds__(64) void nister5_kernel(const T *__restrict__ sampl
   DR_STAGE(0);
   double e[3][3][4];
   basis_to_entries(nb, e);
-  build_constraints<NisterOrder>(e, w, 1.0);
-  DR_STAGE(1);
-  const bool ok = gauss_jordan_lds<10, 20>(w);
+  double X[6][10];   // reduced rows e..j = rows 4..9 of A^-1 B
+  const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
   DR_STAGE(2);
-  nister_finish<T>(nb, w, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active);
+  nister_finish<T>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active);
   DR_STAGE(5);
 }
 
@@ -388,7 +377,7 @@ __global__ __launch_bounds__(64) void nister5_kernel(const T *__restrict__ sampl
 // roots come from the same root finder; the eigenvector follows from rows 0-5 of (M - lambda I) v = 0 with
 // the structural rows substituted (unknowns y^2, yz, z^2, y, z).
 template <typename T>
-__global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ samples, int Bt,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_kernel(const T *__restrict__ samples, int Bt,
                                                         T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
@@ -400,17 +389,16 @@ __global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ sa
   fivepoint_basis_minimal<T>(samples + (size_t)sc * 20, nullptr, nb);
   double e[3][3][4];
   basis_to_entries(nb, e);
-  build_constraints<GrevlexOrder>(e, w, 2.0);
-  bool ok = gauss_jordan_lds<10, 20>(w);
-
-  // G rows (right block) needed by the action matrix, kept in registers: g[r][c], r in {0,1,2,4,5,7}
-  double g[6][10];
+  double g[6][10];   // G rows (right block) needed by the action matrix: r in {0,1,2,4,5,7}
+  bool ok;
   {
+    double X[10][10];
+    ok = constraints_reduce<GrevlexOrder, 0>(e, w, 2.0, X);
     const int src[6] = {0, 1, 2, 4, 5, 7};
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 10; ++c) g[r][c] = w[src[r] * 20 + 10 + c];
+      for (int c = 0; c < 10; ++c) g[r][c] = X[src[r]][c];
   }
   // H = action matrix in LDS (elements 0..99), reduce to upper Hessenberg by Householder similarity
   LaneWs H{w.base};
@@ -570,11 +558,13 @@ __global__ __launch_bounds__(64) void stewenius5_kernel(const T *__restrict__ sa
 
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st) {
-  const size_t smem = sizeof(double) * kFiveWs * 64;
+  // minimal samples only park the 10x10 right block in LDS (100 doubles per lane = 50 KiB per block => three blocks per
+  // CU); the n > 5 fallback needs A^T A + eigenvectors (162 doubles)
+  const size_t smem = sizeof(double) * (n == 5 ? 100 : kFiveWs) * 64;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nister5_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nister5_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kFiveWs * 64));
     attr_set = true;
   }
   hipLaunchKernelGGL((nister5_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, n, models,

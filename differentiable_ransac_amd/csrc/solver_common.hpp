@@ -246,7 +246,7 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
 
 // roots[0..count-1] = all real roots found (|z| <= 1 ascending first, then the |z| > 1 ones); count <= D
 template <int D, int kBisLast = 10, int kNewtLast = 6>
-__device__ void real_roots(const double (&c)[D + 1], double (&roots)[D], int &count, double tail_tol = 0.0) {
+__device__ __forceinline__ void real_roots(const double (&c)[D + 1], double (&roots)[D], int &count, double tail_tol = 0.0) {
   double cmax = 0;
 #pragma unroll
   for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
@@ -288,7 +288,7 @@ __device__ void real_roots(const double (&c)[D + 1], double (&roots)[D], int &co
 // On return A's diagonal holds the eigenvalues and the columns of V the eigenvectors.
 // ------------------------------------------------------------------------------------------------
 template <int N>
-__device__ void jacobi_eig_lds(const LaneWs &A, const LaneWs &V) {
+__device__ __forceinline__ void jacobi_eig_lds(const LaneWs &A, const LaneWs &V) {
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) V[i * N + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 30; ++sweep) {
@@ -503,6 +503,146 @@ __device__ void build_constraints(const double (&e)[3][3][4], const LaneWs &w, d
   pmul21_acc<Ord>(m, e[2][2], row, 1.0);
 #pragma unroll
   for (int t = 0; t < 20; ++t) w[9 * 20 + t] = row[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Constraint system [A | B] (10 x 20) -> selected rows of X = A^-1 B, without pivoting and without run-time
+// indexing: A (left 10 x 10) stays in VGPRs and is factored by Householder QR (backward stable with no
+// pivoting, unlike the Gauss-Jordan it replaces); B (right 10 x 10) is parked in LDS row by row as the
+// constraints are generated and then pulled back one COLUMN at a time: reflectors applied in registers,
+// back-substitution down to the first needed row, results written to X.  LDS per lane: 100 doubles
+// (51 KiB per 64-lane block => three blocks per CU instead of one), ~200 LDS accesses per sample instead of ~6000.
+// kFirstRow = smallest row index the caller needs (rows kFirstRow..9 of X are produced: X[r - kFirstRow][c]).
+// ------------------------------------------------------------------------------------------------
+template <class Ord, int kFirstRow>
+__device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], const LaneWs &Bw, double s,
+                                   double (&X)[10 - kFirstRow][10]) {
+  double A[10][10];
+  // ---- generate the ten rows (same maths as build_constraints), A-part to registers, B-part to LDS
+  double tr[10];
+  {
+    double d0[10], d1[10], d2[10];
+    pmul11<Ord>(e[0][0], e[0][0], d0); pmul11<Ord>(e[0][1], e[0][1], d0, 1.0, true); pmul11<Ord>(e[0][2], e[0][2], d0, 1.0, true);
+    pmul11<Ord>(e[1][0], e[1][0], d1); pmul11<Ord>(e[1][1], e[1][1], d1, 1.0, true); pmul11<Ord>(e[1][2], e[1][2], d1, 1.0, true);
+    pmul11<Ord>(e[2][0], e[2][0], d2); pmul11<Ord>(e[2][1], e[2][1], d2, 1.0, true); pmul11<Ord>(e[2][2], e[2][2], d2, 1.0, true);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) tr[t] = 0.5 * (d0[t] + d1[t] + d2[t]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    // (E E^T - 1/2 tr I) row i : three degree-2 polynomials
+    double g[3][10];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pmul11<Ord>(e[i][0], e[k][0], g[k]);
+      pmul11<Ord>(e[i][1], e[k][1], g[k], 1.0, true);
+      pmul11<Ord>(e[i][2], e[k][2], g[k], 1.0, true);
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) g[i][t] -= tr[t];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double row[20];
+#pragma unroll
+      for (int t = 0; t < 20; ++t) row[t] = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pmul21_acc<Ord>(g[k], e[k][j], row, s);
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        A[3 * i + j][t] = row[t];
+        Bw[(3 * i + j) * 10 + t] = row[10 + t];
+      }
+    }
+  }
+  {
+    double row[20];
+#pragma unroll
+    for (int t = 0; t < 20; ++t) row[t] = 0;
+    double m[10], m2[10];
+    pmul11<Ord>(e[0][1], e[1][2], m); pmul11<Ord>(e[0][2], e[1][1], m2);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) m[t] -= m2[t];
+    pmul21_acc<Ord>(m, e[2][0], row, 1.0);
+    pmul11<Ord>(e[0][2], e[1][0], m); pmul11<Ord>(e[0][0], e[1][2], m2);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) m[t] -= m2[t];
+    pmul21_acc<Ord>(m, e[2][1], row, 1.0);
+    pmul11<Ord>(e[0][0], e[1][1], m); pmul11<Ord>(e[0][1], e[1][0], m2);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) m[t] -= m2[t];
+    pmul21_acc<Ord>(m, e[2][2], row, 1.0);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      A[9][t] = row[t];
+      Bw[9 * 10 + t] = row[10 + t];
+    }
+  }
+  // ---- Householder QR of A: reflector j lives in A[j..9][j] (v, with v_j = A[j][j]), R above the diagonal + rdiag
+  double beta[10], rdiag[10];
+  double amax = 0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    double nrm2 = 0;
+#pragma unroll
+    for (int i = j; i < 10; ++i) nrm2 += A[i][j] * A[i][j];
+    const double nrm = sqrt(nrm2);
+    const double alpha = -dsign(nrm, A[j][j]);
+    const double v0 = A[j][j] - alpha;
+    const double vtv = v0 * v0 + (nrm2 - A[j][j] * A[j][j]);
+    beta[j] = vtv > 0 ? 2.0 / vtv : 0.0;
+    rdiag[j] = alpha;
+    A[j][j] = v0;
+    amax = fmax(amax, fabs(alpha));
+#pragma unroll
+    for (int c = j + 1; c < 10; ++c) {
+      double dot = 0;
+#pragma unroll
+      for (int i = j; i < 10; ++i) dot += A[i][j] * A[i][c];
+      dot *= beta[j];
+#pragma unroll
+      for (int i = j; i < 10; ++i) A[i][c] -= dot * A[i][j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 10; ++j) ok = ok && (fabs(rdiag[j]) > 1e-13 * amax);
+  ok = ok && is_finite(amax) && amax > 0;
+  double rinv[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) rinv[j] = ok ? 1.0 / rdiag[j] : 0.0;
+  // ---- one right-hand-side column at a time
+#pragma unroll 1
+  for (int c = 0; c < 10; ++c) {
+    double b[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) b[i] = Bw[i * 10 + c];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      double dot = 0;
+#pragma unroll
+      for (int i = j; i < 10; ++i) dot += A[i][j] * b[i];
+      dot *= beta[j];
+#pragma unroll
+      for (int i = j; i < 10; ++i) b[i] -= dot * A[i][j];
+    }
+    // back-substitution R x = b, rows 9 .. kFirstRow
+    double x[10];
+#pragma unroll
+    for (int r = 9; r >= kFirstRow; --r) {
+      double acc = b[r];
+#pragma unroll
+      for (int k = r + 1; k < 10; ++k) acc -= A[r][k] * x[k];
+      x[r] = acc * rinv[r];
+    }
+    // park the result where the column came from; it is re-read with static indices below
+#pragma unroll
+    for (int r = kFirstRow; r < 10; ++r) Bw[r * 10 + c] = x[r];
+  }
+#pragma unroll
+  for (int r = kFirstRow; r < 10; ++r)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) X[r - kFirstRow][c] = Bw[r * 10 + c];
+  return ok;
 }
 
 // rows (x1x2, x1y2, x1, y1x2, y1y2, y1, x2, y2, 1) of the five-point solvers (nister.py:87-115)
