@@ -238,8 +238,11 @@ def kernel_breakdown(args, rn, matches, logits, K1, K2, ops):
         out["K3_solver"], (models, valid) = t(lambda: ops.solve_nister5(smp))
     flat = models.reshape(P, -1, 3, 3)
     thr = torch.full((P,), 7.5e-4, device=matches.device)
-    out["K4_msac_masks"], (sc, mk) = t(lambda: ops.msac_score(matches, flat, thr, True))
-    out["K4_msac_nomask"], _ = t(lambda: ops.msac_score(matches, flat, thr, False))
+    vflat = valid.reshape(P, -1)
+    out["K4_msac_masks"], (sc, mk) = t(lambda: ops.msac_score(matches, flat, thr, True, vflat))
+    out["K4_msac_nomask"], _ = t(lambda: ops.msac_score(matches, flat, thr, False, vflat))
+    out["K4_msac_masks_all_slots"], _ = t(lambda: ops.msac_score(matches, flat, thr, True))
+    out["valid_fraction"] = float(valid.float().mean())
     out["K6_select_best"], _ = t(lambda: ops.select_best(matches, flat, sc, thr, valid.reshape(P, -1)))
     return out
 

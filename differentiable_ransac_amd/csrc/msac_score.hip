@@ -42,6 +42,7 @@ __device__ __forceinline__ T sampson_s(const T m[9], T x1, T y1, T x2, T y2, T i
 template <typename T, bool kMask>
 __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restrict__ matches,
                                                               const T *__restrict__ models,
+                                                              const uint8_t *__restrict__ valid,
                                                               const T *__restrict__ thr, int M, int N,
                                                               T *__restrict__ scores, uint8_t *__restrict__ masks,
                                                               int chunks_per_block, int use_atomic) {
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
 
     for (int ml = 0; ml < mcount; ++ml) {
       T m[9];
-      bool finite = true;
+      bool finite = !valid || valid[(size_t)p * M + m0 + ml];   // invalid slots: score 0, empty mask, no arithmetic
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         m[q] = md[ml * 9 + q];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
         }
       }
       acc = wave_sum(acc);
-      if (lane == 0) part[wv][ml] += finite ? acc : (acc + T(NAN));
+      if (lane == 0) part[wv][ml] += (finite || (valid && !valid[(size_t)p * M + m0 + ml])) ? acc : (acc + T(NAN));
     }
   }
   __syncthreads();
@@ -136,6 +137,7 @@ __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
 __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const float *__restrict__ matches,
                                                                        const float *__restrict__ models,
+                                                                       const uint8_t *__restrict__ valid,
                                                                        const float *__restrict__ thr, int M, int N,
                                                                        float *__restrict__ scores,
                                                                        uint8_t *__restrict__ masks, int write_masks,
@@ -188,6 +190,17 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
 #pragma unroll
       for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
       const bool finite = ex != 0x7f800000u;
+      // slots the solver marked invalid (non-real roots: more than half of the 10 five-point slots) are wave-uniformly
+      // skipped: score 0, empty mask row, no arithmetic
+      if (valid && !valid[(size_t)p * M + m0 + ml]) {
+        if (write_masks && nvalid > 0) {
+          uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
+          if (row_aligned && nvalid == kPts) *reinterpret_cast<uint2 *>(row) = make_uint2(0u, 0u);
+          else
+            for (int j = 0; j < nvalid; ++j) row[j] = 0;
+        }
+        continue;
+      }
 
       v2f acc = splat(0.f);
       uint32_t sb[kPts];
@@ -391,8 +404,8 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
 }
 
 template <typename T>
-int msac_score_launch(const T *matches, const T *models, const T *thr, int P, int M, int N, T *scores,
-                      uint8_t *masks, hipStream_t st) {
+int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, const T *thr, int P, int M, int N,
+                      T *scores, uint8_t *masks, hipStream_t st) {
   const int tiles = (M + kModelsPerBlock - 1) / kModelsPerBlock;
   const int chunks = (N + kChunk - 1) / kChunk;
   // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip
@@ -408,14 +421,14 @@ int msac_score_launch(const T *matches, const T *models, const T *thr, int P, in
   dim3 grid(tiles, ny, P);
   if constexpr (sizeof(T) == 4) {
     hipLaunchKernelGGL(msac_score_kernel_f32_fast, grid, dim3(kThreads), 0, st, (const float *)matches,
-                       (const float *)models, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0, cpb,
-                       use_atomic);
+                       (const float *)models, valid, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0,
+                       cpb, use_atomic);
   } else {
     if (masks)
-      hipLaunchKernelGGL((msac_score_kernel<T, true>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N, scores,
-                         masks, cpb, use_atomic);
+      hipLaunchKernelGGL((msac_score_kernel<T, true>), grid, dim3(kThreads), 0, st, matches, models, valid, thr, M, N,
+                         scores, masks, cpb, use_atomic);
     else
-      hipLaunchKernelGGL((msac_score_kernel<T, false>), grid, dim3(kThreads), 0, st, matches, models, thr, M, N,
+      hipLaunchKernelGGL((msac_score_kernel<T, false>), grid, dim3(kThreads), 0, st, matches, models, valid, thr, M, N,
                          scores, masks, cpb, use_atomic);
   }
   return check_launch("msac_score_kernel");
@@ -425,18 +438,18 @@ int msac_score_launch(const T *matches, const T *models, const T *thr, int P, in
 
 extern "C" {
 
-int dr_msac_score_f32(const float *matches, const float *models, const float *thr, int P, int M, int N,
-                      float *scores, uint8_t *masks, void *stream) {
+int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
+                      int M, int N, float *scores, uint8_t *masks, void *stream) {
   DR_REQUIRE(matches && models && thr && scores, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  return dr::msac_score_launch<float>(matches, models, thr, P, M, N, scores, masks, (hipStream_t)stream);
+  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
 }
 
-int dr_msac_score_f64(const double *matches, const double *models, const double *thr, int P, int M, int N,
-                      double *scores, uint8_t *masks, void *stream) {
+int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,
+                      int M, int N, double *scores, uint8_t *masks, void *stream) {
   DR_REQUIRE(matches && models && thr && scores, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  return dr::msac_score_launch<double>(matches, models, thr, P, M, N, scores, masks, (hipStream_t)stream);
+  return dr::msac_score_launch<double>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
 }
 
 int dr_select_best_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,

@@ -22,9 +22,10 @@ def _thr_tensor(threshold, P: int, like: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ K4 / K6
-def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_masks: bool = True
-               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None."""
+def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_masks: bool = True,
+               valid: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None.
+    valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row)."""
     P, N, _ = matches.shape
     M = models.shape[1]
     matches = matches.contiguous()
@@ -32,7 +33,8 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
     thr = _thr_tensor(threshold, P, matches)
     scores = torch.empty((P, M), device=matches.device, dtype=matches.dtype)
     masks = torch.empty((P, M, N), device=matches.device, dtype=torch.bool) if want_masks else None
-    L.call(f"dr_msac_score_{L.suffix(matches.dtype)}", ptr(matches), ptr(models), ptr(thr), c_int(P), c_int(M),
+    v = None if valid is None else valid.contiguous().view(torch.uint8)
+    L.call(f"dr_msac_score_{L.suffix(matches.dtype)}", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M),
            c_int(N), ptr(scores), ptr(masks), stream())
     return scores, masks
 

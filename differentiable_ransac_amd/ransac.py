@@ -281,7 +281,7 @@ class BatchedRANSAC(object):
                     break
                 models, valid, _ = self.hypotheses(matches, logits, g)
                 flat = models.reshape(P, self.B * self.S, 3, 3)
-                scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks)
+                scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks, valid=valid.reshape(P, -1))
                 if self.keep_masks:
                     all_masks = masks
                 # K6: arg-max, "better?" test, best mask / inlier count and the adaptive stop of ransac.py:135-142, on the device

@@ -140,12 +140,13 @@ int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const floa
  *   matches [P,N,4], models [P,M,9], thr [P] (the `threshold` argument per pair; the kernel applies
  *   the (3/2 thr)^2 of msac_score.py:21).  scores [P,M]; masks [P,M,N] uint8 (torch.bool layout) or NULL.
  *   Models with a non-finite coefficient get score = NaN and an all-false mask (what the reference's
- *   arithmetic yields for them).
+ *   arithmetic yields for them).  valid [P,M] uint8 (optional, NULL = score everything): slots the solver marked
+ *   invalid (eye(3) fillers of non-real roots) get score 0 and an all-false mask row without being evaluated.
  * ------------------------------------------------------------------------------------------ */
-int dr_msac_score_f32(const float *matches, const float *models, const float *thr, int P, int M, int N,
-                      float *scores, uint8_t *masks, void *stream);
-int dr_msac_score_f64(const double *matches, const double *models, const double *thr, int P, int M, int N,
-                      double *scores, uint8_t *masks, void *stream);
+int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
+                      int M, int N, float *scores, uint8_t *masks, void *stream);
+int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,
+                      int M, int N, double *scores, uint8_t *masks, void *stream);
 /* dL/dmodels [P,M,9] from dL/dscores [P,M] (flows only through points with d2 < thr2). */
 int dr_msac_score_bwd_f32(const float *matches, const float *models, const float *thr, const float *grad_scores,
                           int P, int M, int N, float *grad_models, void *stream);

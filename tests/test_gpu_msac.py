@@ -102,3 +102,19 @@ def test_msac_linearity_property_full_size(dev):
     cnt = k1.sum(-1)
     assert (s1 <= cnt + 1e-3).all() and (cnt <= N).all()
     assert (s1[:, 0] >= 0).all()
+
+
+def test_msac_valid_slots_are_skipped(dev):
+    from differentiable_ransac_amd import ops, synth
+    P, N, M = 3, 2000, 100
+    b = synth.batch_two_view(P, N, seed0=500)
+    gen = torch.Generator().manual_seed(3)
+    models = (b["gt_E"][:, None] + 0.02 * torch.randn(P, M, 3, 3, generator=gen)).to(dev)
+    valid = (torch.rand(P, M, generator=gen) > 0.5).to(dev)
+    s_all, k_all = ops.msac_score(b["matches"].to(dev), models, 7.5e-4)
+    s, k = ops.msac_score(b["matches"].to(dev), models, 7.5e-4, valid=valid)
+    assert torch.equal(s[valid], s_all[valid]) and torch.equal(k[valid], k_all[valid])
+    assert (s[~valid] == 0).all() and not k[~valid].any()
+    s64, k64 = ops.msac_score(b["matches"].double().to(dev), models.double(), 7.5e-4, valid=valid)
+    assert (s64[~valid] == 0).all() and not k64[~valid].any()
+    assert torch.allclose(s64[valid].float(), s[valid], rtol=1e-4, atol=1e-4)
