@@ -85,7 +85,11 @@ struct Philox {
 __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
   float r = (float)(bits >> 8) * 5.9604644775390625e-08f;  // [0,1)
   float u = r * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f) + 1.17549435e-38f;
-  return -__logf(-__logf(u));
+  // u in [2^-126, 1) and -ln u in [6e-8, 87.4]: both log arguments are normal numbers, so the raw v_log_f32
+  // (no denormal fix-up sequence) is exact to its 1-ulp spec
+  const float kLn2 = 0.69314718055994530942f;
+  const float a = -kLn2 * __builtin_amdgcn_logf(u);
+  return -kLn2 * __builtin_amdgcn_logf(a);
 }
 
 // ---- optional per-stage cycle accounting (profiling builds only: -DDR_PROFILE_STAGES) --------------------

@@ -44,25 +44,46 @@ template <> __device__ __forceinline__ double gumbel_from_bits_t<double>(uint32_
 template <typename T>
 __device__ __forceinline__ void load_group(const GumbelArgs<T> &a, int p, int b, int q, T g[4], T noise[4]) {
   const int n0 = 4 * q;
+  const bool full = (n0 + 3 < a.N) && ((a.N & 3) == 0);   // 16-byte aligned, fully inside the row
   if (a.gumbel) {
     const T *src = a.gumbel + ((size_t)p * a.B + b) * a.N + n0;
+    if (full && sizeof(T) == 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(src);
+      noise[0] = v.x; noise[1] = v.y; noise[2] = v.z; noise[3] = v.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) noise[j] = (n0 + j < a.N) ? src[j] : T(0);
+      for (int j = 0; j < 4; ++j) noise[j] = (n0 + j < a.N) ? src[j] : T(0);
+    }
   } else {
     uint32_t r[4];
     Philox::gen(a.seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
 #pragma unroll
     for (int j = 0; j < 4; ++j) noise[j] = gumbel_from_bits_t<T>(r[j]);
   }
+  T l[4];
+  if (!a.logits) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    T l = a.logits ? ((n0 + j < a.N) ? a.logits[(size_t)p * a.N + n0 + j] : T(0)) : T(1);
-    g[j] = (n0 + j < a.N) ? (l + noise[j]) / a.tau : -INFINITY;
+    for (int j = 0; j < 4; ++j) l[j] = T(1);
+  } else if (full && sizeof(T) == 4) {
+    const float4 v = *reinterpret_cast<const float4 *>(a.logits + (size_t)p * a.N + n0);
+    l[0] = v.x; l[1] = v.y; l[2] = v.z; l[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l[j] = (n0 + j < a.N) ? a.logits[(size_t)p * a.N + n0 + j] : T(0);
+  }
+  if (a.tau == T(1)) {   // wave-uniform: x/1 == x exactly, skip the IEEE division sequence
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = (n0 + j < a.N) ? (l[j] + noise[j]) : -INFINITY;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = (n0 + j < a.N) ? (l[j] + noise[j]) / a.tau : -INFINITY;
   }
 }
 
 template <typename T> __device__ __forceinline__ T exp_t(T x);
-template <> __device__ __forceinline__ float exp_t<float>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ float exp_t<float>(float x) {
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);   // arguments are <= 0 and flush to 0 for x < -87: fine for soft-max terms
+}
 template <> __device__ __forceinline__ double exp_t<double>(double x) { return exp(x); }
 template <typename T> __device__ __forceinline__ T log_t(T x);
 template <> __device__ __forceinline__ float log_t<float>(float x) { return logf(x); }
