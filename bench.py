@@ -166,9 +166,21 @@ def main():
     job_hyps_per_s, elapsed = sharding.job_throughput(P * B * args.steps, elapsed, dist, dev)
 
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included
+    bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
     flops_per_launch = 39.0 * P * M * N
     achieved = bytes_per_launch / (k4_ms * 1e-3) / 1e9
+
+    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (profiles/, collected with
+    # `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 5`; KiB per dispatch)
+    traffic, traffic_note = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_fetch_write.json")
+    if os.path.exists(pmc_path) and (P, N, B, args.solver) == (32, 2000, 1024, "nister"):
+        pmc = json.load(open(pmc_path)).get("dr::msac_score_kernel_f32_fast", {})
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # gfx950: FETCH_SIZE shows half the bytes of 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled (upper bound:
+            # most of this kernel's reads are scalar-cache model loads); WRITE_SIZE taken as is (matches the mask bytes to 0.2 %)
+            traffic = (2.0 * pmc["FETCH_SIZE"]["avg"] + pmc["WRITE_SIZE"]["avg"]) * 1024.0
+            traffic_note = "profiles/r1_pmc_fetch_write.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch"
 
     # sanity of the result (cheap, outside the timed region): the synthetic pairs have 50 % inliers
     inl_frac = float(out["inliers"].float().mean()) / N
@@ -192,7 +204,8 @@ def main():
                    "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
         "pairs_per_s": world * P * args.steps / elapsed,
         "roofline": {"bound": "hbm", "kernel": "msac_score_kernel<float,true>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "frac_of_measured_copy_peak_6290": achieved / 6290.0,
                      "valu_tflops": flops_per_launch / (k4_ms * 1e-3) / 1e12,
