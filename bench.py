@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--profile-kernels", action="store_true", help="per-kernel HIP-event breakdown (extra syncs)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are issued on round-robin: consecutive batches overlap (the latency-bound "
+                         "sampler/solver of batch i+1 runs under the throughput-bound scoring of batch i)")
     return ap.parse_args()
 
 
@@ -145,8 +148,19 @@ def main():
     def step():
         return rn(matches, logits, K1, K2)
 
-    for _ in range(args.warmup):
-        out = step()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    outs = [None] * len(streams)
+
+    def issue(i):
+        if args.streams <= 0:      # torch's default stream
+            outs[0] = step()
+            return
+        st = streams[i % len(streams)]
+        with torch.cuda.stream(st):
+            outs[i % len(streams)] = step()
+
+    for w in range(args.warmup):
+        issue(w)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -154,16 +168,36 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         state["i"] = i
-        out = step()
+        issue(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    out = outs[(args.steps - 1) % len(streams)]
     elapsed = time.perf_counter() - t0
     state["i"] = -1
     # whole-job rate = sum of hypotheses over ranks / max elapsed over ranks (no data-path collective: SURVEY 8(e))
     from differentiable_ransac_amd import sharding
     job_hyps_per_s, elapsed = sharding.job_throughput(P * B * args.steps, elapsed, dist, dev)
+
+    # informational second region: the same K steps issued round-robin on two streams, so that the latency-bound
+    # sampler/solver of batch i+1 overlaps the scoring of batch i (a serving loop would do this; it is not the headline
+    # number because it blurs the per-kernel roofline attribution)
+    overlap = None
+    if len(streams) == 1 and world == 1:
+        s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        keep = [None, None]
+        for i in range(4):                       # warm the per-stream allocator pools
+            with torch.cuda.stream(s2[i % 2]):
+                keep[i % 2] = step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            with torch.cuda.stream(s2[i % 2]):
+                keep[i % 2] = step()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        overlap = {"streams": 2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
 
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
@@ -201,7 +235,8 @@ def main():
         "config": {"workload": f"{args.solver} 5-pt E, {N} pts x {B} hyps per pair, Gumbel top-k sampler (in-kernel "
                                f"Philox), MSAC scoring with masks, test mode, {P} pairs/GPU/step",
                    "pairs_per_gpu": P, "points": N, "hypotheses_per_pair": B, "models_per_pair": M,
-                   "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
+                   "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective",
+                   "streams": len(streams)},
         "pairs_per_s": world * P * args.steps / elapsed,
         "roofline": {"bound": "hbm", "kernel": "msac_score_kernel<float,true>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -211,6 +246,7 @@ def main():
                      "valu_tflops": flops_per_launch / (k4_ms * 1e-3) / 1e12,
                      "valu_frac_of_157.3": flops_per_launch / (k4_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
         "check": {"mean_inlier_fraction_of_best_model": inl_frac},
+        "overlap": overlap,
     }
     if args.profile_kernels and rank == 0:
         result["kernel_breakdown_ms"] = kernel_breakdown(args, rn, matches, logits, K1, K2, ops)

@@ -153,6 +153,13 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
   const float *md = models + ((size_t)p * M + m0) * 9;
   const bool row_aligned = (N % 8) == 0;
   for (int i = tid; i < (kThreads / kWave) * kModelsPerBlock; i += kThreads) (&part[0][0])[i] = 0.f;
+  // validity of the tile's 32 slots as one wave-uniform bit mask (one parallel byte load + ballot instead of a
+  // dependent byte load per model inside the loop)
+  uint32_t vmask = 0xffffffffu;
+  if (valid) {
+    const bool v = (lane < mcount) ? (valid[(size_t)p * M + m0 + lane] != 0) : false;
+    vmask = (uint32_t)__ballot(v);
+  }
   __syncthreads();
 
   const int c_begin = blockIdx.y * chunks_per_block;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
       const bool finite = ex != 0x7f800000u;
       // slots the solver marked invalid (non-real roots: more than half of the 10 five-point slots) are wave-uniformly
       // skipped: score 0, empty mask row, no arithmetic
-      if (valid && !valid[(size_t)p * M + m0 + ml]) {
+      if (!((vmask >> ml) & 1u)) {
         if (write_masks && nvalid > 0) {
           uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
           if (row_aligned && nvalid == kPts) *reinterpret_cast<uint2 *>(row) = make_uint2(0u, 0u);
