@@ -5,14 +5,18 @@
 // score() contract), flops = 39*M*N  =>  38 flop/B at C2: the kernel is f32-VALU bound, the
 // masks are the only HBM stream that matters.
 //
-// Mapping.  One 256-thread block = (pair p, tile of kModelsPerBlock models, chunk range of points).
-// A lane owns kPts = 8 CONSECUTIVE points held in VGPRs for the whole block lifetime (32 VGPRs),
-// so the inner loop touches no LDS and no vector memory except the 8-byte mask store: the model's
-// nine coefficients are wave-uniform and arrive through the scalar cache (s_load) into SGPRs,
-// which VALU instructions read for free.  Score partials are reduced inside the wave and summed
-// across the block's four waves through 1 KiB of LDS; with one chunk per pair (N <= 2048) the
-// result is stored directly, i.e. deterministically; larger N split over blocks use one
-// atomicAdd per (block, model).
+// Mapping.  One block = (pair p, tile of model slots, chunk range of points).  A lane owns 16 (f32 fast
+// path, N % 16 == 0) or 8 CONSECUTIVE points held in VGPRs for the whole block lifetime, so the inner
+// loop touches no LDS and no vector memory except one 16-byte (8-byte) mask store per model: the model's
+// nine coefficients are wave-uniform and arrive through the scalar cache (s_load, prefetched one model
+// ahead) into SGPRs, which VALU instructions read for free.  Slots flagged invalid by the solver are
+// never evaluated (the loop walks the set bits of a per-tile validity mask).  Score partials are reduced
+// inside the wave and summed across the block's waves through LDS; with one chunk per pair (N <= 2048)
+// the result is stored directly, i.e. deterministically; larger N split over blocks use one atomicAdd
+// per (block, model).
+// Measured A/B (scratch/ab_k4.py, P=32, N=2000, M=10240, 44.5 % valid slots, masks on): 32-slot tiles +
+// 8-byte stores 279 us; 64-slot tiles 264 us; zero rows after the evaluations 259 us; 16 points per lane +
+// 16-byte stores 229 us (the mask stream is store-issue bound: halving the store count is worth 30 us).
 #include "dr_common.hpp"
 
 namespace dr {
@@ -135,6 +139,38 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
+// A/B knobs (scratch/ab_k4.py builds one shared object per variant)
+#ifndef DR_K4_VARIANT
+#define DR_K4_VARIANT 6
+#endif
+#if DR_K4_VARIANT == 0      // 128-slot tiles, zero rows first, 8-byte stores
+#define DR_K4_TILE 128
+#define DR_K4_ZERO 0
+#elif DR_K4_VARIANT == 1    // 128-slot tiles, zero rows first, 16-byte row stores spread over the waves
+#define DR_K4_TILE 128
+#define DR_K4_ZERO 1
+#elif DR_K4_VARIANT == 2    // 32-slot tiles
+#define DR_K4_TILE 32
+#define DR_K4_ZERO 0
+#elif DR_K4_VARIANT == 3    // 64-slot tiles
+#define DR_K4_TILE 64
+#define DR_K4_ZERO 0
+#elif DR_K4_VARIANT == 4    // zero rows after the evaluations
+#define DR_K4_TILE 128
+#define DR_K4_ZERO 2
+#elif DR_K4_VARIANT == 5    // 64-slot tiles, zero rows after
+#define DR_K4_TILE 64
+#define DR_K4_ZERO 2
+#elif DR_K4_VARIANT == 6    // 16 points per lane, 16-byte mask stores (N % 16 == 0), else as variant 5
+#define DR_K4_TILE 64
+#define DR_K4_ZERO 2
+#define DR_K4_FAST16 1
+#endif
+#ifndef DR_K4_FAST16
+#define DR_K4_FAST16 0
+#endif
+constexpr int kFastTile = DR_K4_TILE;   // model slots per block in the f32 fast path (32-bit validity words)
+
 __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const float *__restrict__ matches,
                                                                        const float *__restrict__ models,
                                                                        const uint8_t *__restrict__ valid,
@@ -142,23 +178,27 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
                                                                        float *__restrict__ scores,
                                                                        uint8_t *__restrict__ masks, int write_masks,
                                                                        int chunks_per_block, int use_atomic) {
-  __shared__ float part[kThreads / kWave][kModelsPerBlock];
+  __shared__ float part[kThreads / kWave][kFastTile];
   const int p = blockIdx.z;
-  const int m0 = blockIdx.x * kModelsPerBlock;
+  const int m0 = blockIdx.x * kFastTile;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int mcount = min(kModelsPerBlock, M - m0);
+  const int mcount = min(kFastTile, M - m0);
   const float t = 1.5f * thr[p];
   const float inv_thr2 = 1.0f / (t * t);
   const float *mt = matches + (size_t)p * N * 4;
   const float *md = models + ((size_t)p * M + m0) * 9;
   const bool row_aligned = (N % 8) == 0;
-  for (int i = tid; i < (kThreads / kWave) * kModelsPerBlock; i += kThreads) (&part[0][0])[i] = 0.f;
-  // validity of the tile's 32 slots as one wave-uniform bit mask (one parallel byte load + ballot instead of a
-  // dependent byte load per model inside the loop)
-  uint32_t vmask = 0xffffffffu;
-  if (valid) {
-    const bool v = (lane < mcount) ? (valid[(size_t)p * M + m0 + lane] != 0) : false;
-    vmask = (uint32_t)__ballot(v);
+  for (int i = tid; i < (kThreads / kWave) * kFastTile; i += kThreads) (&part[0][0])[i] = 0.f;
+  // Validity of the tile's slots as wave-uniform bit masks.  Slots the solver marked invalid (non-real roots: more than
+  // half of the ten five-point slots) are never evaluated: the loop below walks the set bits only, so a block's work is
+  // its number of VALID models and there is no per-slot skip cost; their mask rows are zero-filled by a store-only loop.
+  uint32_t vword[kFastTile / 32];
+#pragma unroll
+  for (int w = 0; w < kFastTile / 32; ++w) {
+    const int ml = 32 * w + (lane & 31);
+    const bool inside = ml < mcount;
+    const bool v = inside && (!valid || valid[(size_t)p * M + m0 + ml] != 0);
+    vword[w] = (uint32_t)(__ballot(v && lane < 32));
   }
   __syncthreads();
 
@@ -182,81 +222,252 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
       if (j < nvalid) { if (j < 4) vlo |= 1u << (8 * j); else vhi |= 1u << (8 * (j - 4)); }
     }
 
-    float mc[9];
+    auto zero_rows = [&]() {
+      // store-only pass: empty mask rows of the invalid slots.  When the whole row belongs to this block (one chunk) and
+    // rows are 16-byte aligned, each wave zero-fills every fourth invalid row with 16-byte stores (half the store
+    // instructions of the per-lane 8-byte layout, and the width the memory pipeline issues best)
+    if (write_masks) {
+      const bool wide = (DR_K4_ZERO == 1) && (N <= kChunk) && ((N & 15) == 0) && gridDim.y == 1;
+      int seen = 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mc[q] = md[q];
-    for (int ml = 0; ml < mcount; ++ml) {
-      float m[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) m[q] = mc[q];
-      const int nx = (ml + 1 < mcount) ? ml + 1 : ml;   // prefetch the next model through the scalar cache
-#pragma unroll
-      for (int q = 0; q < 9; ++q) mc[q] = md[nx * 9 + q];
-      // scalar-unit finiteness test: largest exponent field over the nine coefficients
-      uint32_t ex = 0;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
-      const bool finite = ex != 0x7f800000u;
-      // slots the solver marked invalid (non-real roots: more than half of the 10 five-point slots) are wave-uniformly
-      // skipped: score 0, empty mask row, no arithmetic
-      if (!((vmask >> ml) & 1u)) {
-        if (write_masks && nvalid > 0) {
-          uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
-          if (row_aligned && nvalid == kPts) *reinterpret_cast<uint2 *>(row) = make_uint2(0u, 0u);
-          else
-            for (int j = 0; j < nvalid; ++j) row[j] = 0;
+      for (int wd = 0; wd < kFastTile / 32; ++wd) {
+        uint32_t inv = ~vword[wd];
+        if (32 * wd + 32 > mcount) inv &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
+        while (inv) {
+          const int ml = 32 * wd + __builtin_ctz(inv);
+          inv &= inv - 1;
+          uint8_t *row0 = masks + ((size_t)p * M + m0 + ml) * N;
+          if (wide) {
+            if ((seen & 3) == wv) {
+              for (int off = lane * 16; off < N; off += 64 * 16)
+                *reinterpret_cast<uint4 *>(row0 + off) = make_uint4(0u, 0u, 0u, 0u);
+            }
+          } else if (nvalid > 0) {
+            uint8_t *row = row0 + n0;
+            if (row_aligned && nvalid == kPts) *reinterpret_cast<uint2 *>(row) = make_uint2(0u, 0u);
+            else
+              for (int j = 0; j < nvalid; ++j) row[j] = 0;
+          }
+          ++seen;
         }
-        continue;
       }
+    }
 
-      v2f acc = splat(0.f);
-      uint32_t sb[kPts];
+    };
+    if (DR_K4_ZERO != 2) zero_rows();
+
+#pragma unroll 1
+    for (int wd = 0; wd < kFastTile / 32; ++wd) {
+      uint32_t live = vword[wd];
+      if (!live) continue;
+      int ml = 32 * wd + __builtin_ctz(live);
+      live &= live - 1;
+      float mc[9];
 #pragma unroll
-      for (int j = 0; j < kPts / 2; ++j) {
-        const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
-        const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
-        const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
-        const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
-        const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
-        const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
-        const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
-        const v2f rr = r * r;
-        v2f rc;
-        rc[0] = __builtin_amdgcn_rcpf(jj[0]);
-        rc[1] = __builtin_amdgcn_rcpf(jj[1]);
-        const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);   // s = d2/thr2 - 1
-        v2f mx;
-        mx[0] = fmaxf(-sv[0], 0.f);
-        mx[1] = fmaxf(-sv[1], 0.f);
-        acc = mx * w[j] + acc;
-        sb[2 * j] = __float_as_uint(sv[0]);
-        sb[2 * j + 1] = __float_as_uint(sv[1]);
+      for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
+      while (true) {
+        float m[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) m[q] = mc[q];
+        const int cur = ml;
+        const bool more = live != 0;
+        if (more) {   // prefetch the next valid model through the scalar cache
+          ml = 32 * wd + __builtin_ctz(live);
+          live &= live - 1;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
+        }
+        // scalar-unit finiteness test: largest exponent field over the nine coefficients
+        uint32_t ex = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
+        const bool finite = ex != 0x7f800000u;
+
+        v2f acc = splat(0.f);
+        uint32_t sb[kPts];
+#pragma unroll
+        for (int j = 0; j < kPts / 2; ++j) {
+          const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
+          const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
+          const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
+          const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
+          const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
+          const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
+          const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
+          const v2f rr = r * r;
+          v2f rc;
+          rc[0] = __builtin_amdgcn_rcpf(jj[0]);
+          rc[1] = __builtin_amdgcn_rcpf(jj[1]);
+          const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);   // s = d2/thr2 - 1
+          v2f mx;
+          mx[0] = fmaxf(-sv[0], 0.f);
+          mx[1] = fmaxf(-sv[1], 0.f);
+          acc = mx * w[j] + acc;
+          sb[2 * j] = __float_as_uint(sv[0]);
+          sb[2 * j + 1] = __float_as_uint(sv[1]);
+        }
+        float a = acc[0] + acc[1];
+        if (write_masks && nvalid > 0) {
+          // top bytes of four s values -> one dword, then sign bit -> bit 0 of each byte
+          const uint32_t t01 = __builtin_amdgcn_perm(sb[1], sb[0], 0x0c0c0703u);  // bytes: [s0.b3, s1.b3, 0, 0]
+          const uint32_t t23 = __builtin_amdgcn_perm(sb[3], sb[2], 0x07030c0cu);  // bytes: [0, 0, s2.b3, s3.b3]
+          const uint32_t t45 = __builtin_amdgcn_perm(sb[5], sb[4], 0x0c0c0703u);
+          const uint32_t t67 = __builtin_amdgcn_perm(sb[7], sb[6], 0x07030c0cu);
+          uint32_t lo = (((t01 | t23) >> 7) & 0x01010101u) & vlo;
+          uint32_t hi = (((t45 | t67) >> 7) & 0x01010101u) & vhi;
+          if (!finite) { lo = 0; hi = 0; }
+          uint8_t *row = masks + ((size_t)p * M + m0 + cur) * N + n0;
+          if (row_aligned && nvalid == kPts) {
+            *reinterpret_cast<uint2 *>(row) = make_uint2(lo, hi);
+          } else {
+            for (int j = 0; j < nvalid; ++j) row[j] = (uint8_t)(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 1u);
+          }
+        }
+        a = wave_sum(a);
+        if (lane == 0) part[wv][cur] += finite ? a : NAN;
+        if (!more) break;
       }
-      float a = acc[0] + acc[1];
-      if (write_masks && nvalid > 0) {
-        // top bytes of four s values -> one dword, then sign bit -> bit 0 of each byte
-        const uint32_t t01 = __builtin_amdgcn_perm(sb[1], sb[0], 0x0c0c0703u);  // bytes: [s0.b3, s1.b3, 0, 0]
-        const uint32_t t23 = __builtin_amdgcn_perm(sb[3], sb[2], 0x07030c0cu);  // bytes: [0, 0, s2.b3, s3.b3]
-        const uint32_t t45 = __builtin_amdgcn_perm(sb[5], sb[4], 0x0c0c0703u);
-        const uint32_t t67 = __builtin_amdgcn_perm(sb[7], sb[6], 0x07030c0cu);
-        uint32_t lo = (((t01 | t23) >> 7) & 0x01010101u) & vlo;
-        uint32_t hi = (((t45 | t67) >> 7) & 0x01010101u) & vhi;
-        if (!finite) { lo = 0; hi = 0; }
-        uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
-        if (row_aligned && nvalid == kPts) {
-          *reinterpret_cast<uint2 *>(row) = make_uint2(lo, hi);
-        } else {
-          for (int j = 0; j < nvalid; ++j) row[j] = (uint8_t)(((j < 4 ? lo : hi) >> (8 * (j & 3))) & 1u);
+    }
+    if (DR_K4_ZERO == 2) zero_rows();
+  }
+  __syncthreads();
+  for (int i = tid; i < mcount; i += kThreads) {
+    const float v = part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    float *dst = scores + (size_t)p * M + m0 + i;
+    if (use_atomic) atomicAdd(dst, v);
+    else *dst = v;
+  }
+}
+
+// ---- f32 fast path, 16 points per lane ---------------------------------------------------------------------------
+// Same algorithm with a lane owning 16 consecutive points (64 VGPRs), 128-thread blocks (two waves cover 2048 points):
+// every mask row segment is one 16-byte store per lane (1 KiB per wave instruction) -- the mask stream is store-ISSUE
+// bound with 8-byte stores.  Requires N % 16 == 0 (otherwise the 8-point kernel above is used).
+constexpr int kT16 = 128, kP16 = 16, kChunk16 = kT16 * kP16;
+
+__global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
+                                                                     const float *__restrict__ models,
+                                                                     const uint8_t *__restrict__ valid,
+                                                                     const float *__restrict__ thr, int M, int N,
+                                                                     float *__restrict__ scores,
+                                                                     uint8_t *__restrict__ masks, int write_masks,
+                                                                     int chunks_per_block, int use_atomic) {
+  constexpr int kTile = 64;
+  __shared__ float part[kT16 / kWave][kTile];
+  const int p = blockIdx.z;
+  const int m0 = blockIdx.x * kTile;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mcount = min(kTile, M - m0);
+  const float t = 1.5f * thr[p];
+  const float inv_thr2 = 1.0f / (t * t);
+  const float *mt = matches + (size_t)p * N * 4;
+  const float *md = models + ((size_t)p * M + m0) * 9;
+  for (int i = tid; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
+  uint32_t vword[kTile / 32];
+#pragma unroll
+  for (int w = 0; w < kTile / 32; ++w) {
+    const int ml = 32 * w + (lane & 31);
+    const bool v = (ml < mcount) && (!valid || valid[(size_t)p * M + m0 + ml] != 0);
+    vword[w] = (uint32_t)(__ballot(v && lane < 32));
+  }
+  __syncthreads();
+
+  const int c_begin = blockIdx.y * chunks_per_block;
+  for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
+    if (c * kChunk16 >= N) break;
+    const int n0 = c * kChunk16 + tid * kP16;
+    const bool have = n0 < N;   // N % 16 == 0: a lane's 16 points are all inside or all outside
+    v2f x1[kP16 / 2], y1[kP16 / 2], x2[kP16 / 2], y2[kP16 / 2];
+#pragma unroll
+    for (int j = 0; j < kP16; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (have) v = reinterpret_cast<const float4 *>(mt)[n0 + j];
+      x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+    }
+    const float wl = have ? 1.f : 0.f;
+
+#pragma unroll 1
+    for (int wd = 0; wd < kTile / 32; ++wd) {
+      uint32_t live = vword[wd];
+      if (!live) continue;
+      int ml = 32 * wd + __builtin_ctz(live);
+      live &= live - 1;
+      float mc[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
+      while (true) {
+        float m[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) m[q] = mc[q];
+        const int cur = ml;
+        const bool more = live != 0;
+        if (more) {
+          ml = 32 * wd + __builtin_ctz(live);
+          live &= live - 1;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
+        }
+        uint32_t ex = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
+        const bool finite = ex != 0x7f800000u;
+        v2f acc = splat(0.f);
+        uint32_t sb[kP16];
+#pragma unroll
+        for (int j = 0; j < kP16 / 2; ++j) {
+          const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
+          const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
+          const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
+          const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
+          const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
+          const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
+          const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
+          const v2f rr = r * r;
+          v2f rc;
+          rc[0] = __builtin_amdgcn_rcpf(jj[0]);
+          rc[1] = __builtin_amdgcn_rcpf(jj[1]);
+          const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);
+          v2f mx;
+          mx[0] = fmaxf(-sv[0], 0.f);
+          mx[1] = fmaxf(-sv[1], 0.f);
+          acc = acc + mx;
+          sb[2 * j] = __float_as_uint(sv[0]);
+          sb[2 * j + 1] = __float_as_uint(sv[1]);
+        }
+        float a = (acc[0] + acc[1]) * wl;
+        if (write_masks && have) {
+          uint32_t wq[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t lo2 = __builtin_amdgcn_perm(sb[4 * g + 1], sb[4 * g], 0x0c0c0703u);
+            const uint32_t hi2 = __builtin_amdgcn_perm(sb[4 * g + 3], sb[4 * g + 2], 0x07030c0cu);
+            wq[g] = finite ? (((lo2 | hi2) >> 7) & 0x01010101u) : 0u;
+          }
+          *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + cur) * N + n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+        }
+        a = wave_sum(a);
+        if (lane == 0) part[wv][cur] += finite ? a : NAN;
+        if (!more) break;
+      }
+    }
+    // empty mask rows of the invalid slots (store-only)
+    if (write_masks && have) {
+#pragma unroll
+      for (int wd = 0; wd < kTile / 32; ++wd) {
+        uint32_t inv = ~vword[wd];
+        if (32 * wd + 32 > mcount) inv &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
+        while (inv) {
+          const int ml = 32 * wd + __builtin_ctz(inv);
+          inv &= inv - 1;
+          *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + ml) * N + n0) = make_uint4(0u, 0u, 0u, 0u);
         }
       }
-      a = wave_sum(a);
-      if (lane == 0) part[wv][ml] += finite ? a : NAN;
     }
   }
   __syncthreads();
-  if (tid < mcount) {
-    const float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
-    float *dst = scores + (size_t)p * M + m0 + tid;
+  for (int i = tid; i < mcount; i += kT16) {
+    const float v = part[0][i] + part[1][i];
+    float *dst = scores + (size_t)p * M + m0 + i;
     if (use_atomic) atomicAdd(dst, v);
     else *dst = v;
   }
@@ -413,8 +624,11 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
 template <typename T>
 int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, const T *thr, int P, int M, int N,
                       T *scores, uint8_t *masks, hipStream_t st) {
-  const int tiles = (M + kModelsPerBlock - 1) / kModelsPerBlock;
-  const int chunks = (N + kChunk - 1) / kChunk;
+  constexpr bool kFast = sizeof(T) == 4;
+  const bool fast16 = kFast && DR_K4_FAST16 && (N % 16 == 0);
+  const int tile = fast16 ? 64 : (kFast ? kFastTile : kModelsPerBlock);
+  const int tiles = (M + tile - 1) / tile;
+  const int chunks = (N + kChunk - 1) / kChunk;   // kChunk16 == kChunk
   // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip
   int ny = 1;
   const long base = (long)P * tiles;
@@ -426,7 +640,13 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
     if (hipMemsetAsync(scores, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
   }
   dim3 grid(tiles, ny, P);
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (kFast) {
+    if (fast16) {
+      hipLaunchKernelGGL(msac_score_kernel_f32_fast16, grid, dim3(kT16), 0, st, (const float *)matches,
+                         (const float *)models, valid, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0,
+                         cpb, use_atomic);
+      return check_launch("msac_score_kernel");
+    }
     hipLaunchKernelGGL(msac_score_kernel_f32_fast, grid, dim3(kThreads), 0, st, (const float *)matches,
                        (const float *)models, valid, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0,
                        cpb, use_atomic);
