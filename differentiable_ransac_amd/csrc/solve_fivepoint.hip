@@ -258,9 +258,11 @@ __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double
 }
 
 // ---- Nister: B(z) from the reduced rows, det B(z), roots, back-substitution -----------------------------
-template <typename T>
+// kPair: two lanes share one sample -- `half` 0 searches |z| <= 1 and fills the slots upwards from 0, `half` 1 searches
+// |z| > 1 and fills downwards from 9; the slots in between become eye(3).
+template <typename T, bool kPair>
 __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const double (&X)[6][10], bool ok, T *__restrict__ models,
-                              uint8_t *__restrict__ valid, bool active) {
+                              uint8_t *__restrict__ valid, bool active, int half = 0) {
   // reduced rows e..j = rows 4..9, right block columns 10..19 hold (x z^2, x z, x | y z^2, y z, y | z^3, z^2, z, 1)
   // k = e - z f, l = g - z h, m = i - z j  ->  B(z) columns (x: deg 3, y: deg 3, 1: deg 4), ascending coefficients
   double bx[3][4], by[3][4], b1[3][5];
@@ -302,7 +304,8 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
   double roots[10];
   int nroots;
   DR_STAGE_BEGIN();
-  real_roots<10>(cs, roots, nroots);
+  if (kPair) real_roots_half<10>(cs, half != 0, roots, nroots);
+  else real_roots<10>(cs, roots, nroots);
   DR_STAGE(3);
   if (!ok) nroots = 0;
 
@@ -332,11 +335,23 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
         if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
       }
     const double x = vx / vw, y = vy / vw;
-    const bool good = finish_solution<T>(nb, x, y, z, has_root && is_finite(x) && is_finite(y), models + 9 * slot, active);
-    if (good && active) valid[slot] = 1;
+    const int dst_slot = (kPair && half) ? 9 - slot : slot;
+    const bool good = finish_solution<T>(nb, x, y, z, has_root && is_finite(x) && is_finite(y) && slot < 10,
+                                         models + 9 * dst_slot, active);
+    if (good && active) valid[dst_slot] = 1;
     slot += good ? 1 : 0;
   }
-  if (active) {
+  if (kPair) {
+    // the partner lane's count; if numerical duplicates ever made the two halves overlap, the upper half wins
+    const int other = __shfl_xor(slot, 1, 64);
+    const int lo = half ? other : slot, hi = half ? slot : other;   // slots [0,lo) and (9-hi, 9] are taken
+    if (active && half == 0) {
+      for (int s = min(lo, 10 - hi); s < 10 - hi; ++s) {
+        write_identity<T>(models + 9 * s);
+        valid[s] = 0;
+      }
+    }
+  } else if (active) {
     for (int s = slot; s < 10; ++s) {
       write_identity<T>(models + 9 * s);
       valid[s] = 0;
@@ -366,8 +381,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   double X[6][10];   // reduced rows e..j = rows 4..9 of A^-1 B
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
   DR_STAGE(2);
-  nister_finish<T>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active);
+  nister_finish<T, false>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active);
   DR_STAGE(5);
+}
+
+// Minimal samples, two lanes per sample (32 samples per 64-lane block).  At the benchmark size there are fewer samples
+// than SIMD lanes on the chip (32 768 vs 65 536), so the redundancy is free: both lanes build the same system (they even
+// share its LDS slot), then each runs ONE of the two root searches and finishes its own roots -- the longest serial
+// stage is cut in half.
+template <typename T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_pair_kernel(
+    const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models,
+    uint8_t *__restrict__ valid) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int half = lane & 1;
+  const int s = blockIdx.x * 32 + (lane >> 1);
+  const bool active = s < Bt;
+  const int sc = active ? s : Bt - 1;
+  LaneWs w{lds + (lane >> 1), 32};
+  const T *pts = samples + (size_t)sc * 20;
+  const T *wts = weights ? weights + (size_t)sc * 5 : nullptr;
+  double nb[4][9];
+  fivepoint_basis_minimal<T>(pts, wts, nb);
+  double e[3][3][4];
+  basis_to_entries(nb, e);
+  double X[6][10];
+  const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
+  nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, half);
 }
 
 // ---- Stewenius ---------------------------------------------------------------------------------------------
@@ -558,15 +599,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st) {
-  // minimal samples only park the 10x10 right block in LDS (100 doubles per lane = 50 KiB per block => three blocks per
-  // CU); the n > 5 fallback needs A^T A + eigenvectors (162 doubles)
-  const size_t smem = sizeof(double) * (n == 5 ? 100 : kFiveWs) * 64;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nister5_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kFiveWs * 64));
     attr_set = true;
   }
+  if (n == 5) {
+    // minimal samples: two lanes per sample, 100 doubles of LDS per SAMPLE (25 KiB per block => six blocks per CU)
+    const size_t smem = sizeof(double) * 100 * 32;
+    hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, weights, Bt, models,
+                       valid);
+    return check_launch("nister5_pair_kernel");
+  }
+  // n > 5 fallback (refit): one lane per sample, A^T A + eigenvectors in LDS (162 doubles)
+  const size_t smem = sizeof(double) * kFiveWs * 64;
   hipLaunchKernelGGL((nister5_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, n, models,
                      valid);
   return check_launch("nister5_kernel");

@@ -13,8 +13,9 @@ namespace dr {
 
 // view of one lane's slice of the block's LDS workspace
 struct LaneWs {
-  double *base;  // &ws[lane]
-  __device__ __forceinline__ double &operator[](int e) const { return base[e * 64]; }
+  double *base;      // &ws[lane]  (or &ws[lane >> 1] when two lanes share one sample)
+  int stride = 64;   // lanes (samples) per block row
+  __device__ __forceinline__ double &operator[](int e) const { return base[e * stride]; }
 };
 
 __device__ __forceinline__ double dsign(double a, double b) { return b >= 0 ? fabs(a) : -fabs(a); }
@@ -241,6 +242,41 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
       for (int i = 0; i < D; ++i) x[i] = y[i];
       mask = has;
     }
+  }
+}
+
+// One half of the search (two lanes per sample: the even lane takes |z| <= 1, the odd lane |z| > 1 through the reversed
+// polynomial).  roots[0..count-1] dense.
+template <int D, int kBisLast = 10, int kNewtLast = 6>
+__device__ __forceinline__ void real_roots_half(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count) {
+  double cmax = 0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
+  const bool ok = is_finite(cmax) && cmax > 0;
+  const double sc = ok ? 1.0 / cmax : 0.0;
+  double ch[D + 1];
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    const double a = ok ? c[i] * sc : (i == 0 ? 1.0 : 0.0);
+    const double b = ok ? c[D - i] * sc : (i == 0 ? 1.0 : 0.0);
+    ch[i] = outer ? b : a;
+  }
+  double x[D];
+  unsigned mk;
+  roots_in_unit<D, kBisLast, kNewtLast>(ch, x, mk, 0.0);
+  if (!ok) mk = 0;
+  count = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) roots[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double v = outer ? 1.0 / x[k] : x[k];
+    const bool take = ((mk >> k) & 1u) && (!outer || (fabs(x[k]) > 1e-9 && fabs(x[k]) < 1.0));
+    if (take) {
+#pragma unroll
+      for (int t = 0; t < D; ++t) roots[t] = (t == count) ? v : roots[t];
+    }
+    count += take ? 1 : 0;
   }
 }
 
