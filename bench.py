@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--profile-kernels", action="store_true", help="per-kernel HIP-event breakdown (extra syncs)")
+    ap.add_argument("--mode", default="test", choices=["test", "train"],
+                    help="test: the headline inference path; train: sampler -> solver -> best-of-10 vs GT -> loss, forward "
+                         "+ backward to the logits (ransac.py:78-108 + train.py:150), reported with the same JSON shape")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps are issued on round-robin: consecutive batches overlap (the latency-bound "
                          "sampler/solver of batch i+1 runs under the throughput-bound scoring of batch i)")
@@ -109,7 +112,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # under torch.distributed.run even a single rank initialises RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -145,8 +148,20 @@ def main():
 
     L.call = timed_call
 
-    def step():
-        return rn(matches, logits, K1, K2)
+    if args.mode == "train":
+        gt = data["gt_E"].to(dev) if args.solver != "f8" else data["gt_F"].to(dev)
+        tr = BatchedRANSAC(args.solver, ransac_batch_size=B, train=True, max_iterations=B, seed=99 + rank)
+        lg = logits.clone().requires_grad_(True)
+
+        def step():
+            lg.grad = None
+            chosen, keep = tr(matches, lg, gt_model=gt)
+            d = torch.minimum(((chosen - gt[:, None]) ** 2).sum((-1, -2)), ((chosen + gt[:, None]) ** 2).sum((-1, -2)))
+            (d * keep).sum().backward()
+            return {"inliers": torch.zeros(P, device=dev), "grad": lg.grad}
+    else:
+        def step():
+            return rn(matches, logits, K1, K2)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
     outs = [None] * len(streams)
@@ -199,6 +214,18 @@ def main():
         e2 = time.perf_counter() - t1
         overlap = {"streams": 2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
 
+    if args.mode == "train":
+        if rank == 0:
+            print(json.dumps({"metric": "hypotheses/sec, train step (forward + backward to the logits)",
+                              "value": job_hyps_per_s, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"{args.solver} train step, {N} pts x {B} hyps per pair, {P} pairs/GPU",
+                                         "mode": "train"},
+                              "grad_finite": bool(torch.isfinite(out["grad"]).all())}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
     flops_per_launch = 39.0 * P * M * N
