@@ -452,3 +452,38 @@ class _SelectClosest(torch.autograd.Function):
 
 def select_closest_autograd(models, valid, gt):
     return _SelectClosest.apply(models, valid, gt)
+
+
+# ------------------------------------------------------------------------------------------ MatchLoss residual (8(f) rank 2)
+class _EpisymSums(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, matches, mask, models, valid):
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        sums = torch.zeros((P, M), device=matches.device, dtype=matches.dtype)
+        mk = None if mask is None else mask.contiguous().view(torch.uint8)
+        v = None if valid is None else valid.contiguous().view(torch.uint8)
+        L.call("dr_episym_fwd_f32", ptr(matches.contiguous()), ptr(mk), ptr(models.contiguous()), ptr(v), c_int(P), c_int(M),
+               c_int(N), ptr(sums), stream())
+        ctx.save_for_backward(matches, models)
+        ctx.aux = (mk, v)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        matches, models = ctx.saved_tensors
+        mk, v = ctx.aux
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        gm = torch.zeros_like(models)
+        L.call("dr_episym_bwd_f32", ptr(matches.contiguous()), ptr(mk), ptr(models.contiguous()), ptr(v),
+               ptr(g.contiguous()), c_int(P), c_int(M), c_int(N), ptr(gm), stream())
+        return None, None, gm, None
+
+
+def episym_sums(matches, mask, models, valid=None):
+    """sum over masked points of min(symmetric epipolar error, 1) for every model: matches [P,N,4], mask [P,N] bool |
+    None, models [P,M,3,3], valid [P,M] bool | None -> [P,M] (differentiable w.r.t. models, f32)."""
+    if matches.dtype != torch.float32:
+        raise L.DransacError("episym_sums is implemented for f32")
+    return _EpisymSums.apply(matches, mask, models.reshape(models.shape[0], -1, 3, 3), valid)

@@ -202,6 +202,19 @@ int dr_ransac_update_f64(const double *matches, const double *models, const uint
                          int max_iterations, double *best_score, double *best_model, uint8_t *best_mask,
                          int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * the training loss right after the path -- MatchLoss (loss.py:107-153) on batch_episym
+ * (cv_utils.py:680-695).  sums [P,M] = sum over the points with mask[p,n] != 0 (NULL = all points) of
+ * min(ys, 1), ys = (x2^T M x1)^2 (1/((Mx1)_0^2+(Mx1)_1^2+1e-15) + 1/((M^T x2)_0^2+(M^T x2)_1^2+1e-15)).
+ * Slots with valid == 0 get 0 (NULL = all valid).  The mean over (models x masked points) and over pairs is the
+ * caller's.  Backward: grad_models [P,M,9] from grad_sums [P,M] (the clamp passes no gradient at ys >= 1;
+ * invalid slots are left untouched -- zero the buffer first).
+ * ------------------------------------------------------------------------------------------ */
+int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid, int P, int M,
+                      int N, float *sums, void *stream);
+int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
+                      const float *grad_sums, int P, int M, int N, float *grad_models, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

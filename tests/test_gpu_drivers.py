@@ -198,3 +198,36 @@ def test_ransac3d_train_matches_reference_run(dev):
     assert (mr - g["mean_residuals"]).abs().max() < 5e-3 * g["mean_residuals"].abs().max()
     sum(means.values()).backward()
     assert torch.isfinite(logits.grad).all() and float(logits.grad.abs().sum()) > 0
+
+
+def test_match_loss_kernel_vs_reference_formula(dev):
+    """dr_episym_fwd/bwd against a torch restatement of loss.py:107-153 / cv_utils.py:680-695 in f64."""
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.loss import MatchLoss
+    P, N, M = 3, 700, 45
+    data = synth.batch_two_view(P, N, seed0=600)
+    gen = torch.Generator().manual_seed(8)
+    models = data["gt_E"][:, None] + 0.05 * torch.randn(P, M, 3, 3, generator=gen)
+    keep = torch.rand(P, M, generator=gen) > 0.3
+    mask = data["inliers"].clone()
+    md = models.to(dev).requires_grad_(True)
+    loss = MatchLoss()(md, data["matches"].to(dev), mask.to(dev), keep.to(dev))
+    loss.backward()
+
+    m64 = models.double().requires_grad_(True)
+    tot = 0
+    for p in range(P):
+        x1 = torch.cat((data["matches"][p, mask[p], :2].double(), torch.ones(int(mask[p].sum()), 1, dtype=torch.float64)), 1)
+        x2 = torch.cat((data["matches"][p, mask[p], 2:].double(), torch.ones(int(mask[p].sum()), 1, dtype=torch.float64)), 1)
+        F = m64[p][keep[p]]
+        Fx1 = torch.einsum("mij,nj->mni", F, x1)
+        Ftx2 = torch.einsum("mji,nj->mni", F, x2)
+        r = (x2[None] * Fx1).sum(-1)
+        ys = r ** 2 * (1 / (Fx1[..., 0] ** 2 + Fx1[..., 1] ** 2 + 1e-15) + 1 / (Ftx2[..., 0] ** 2 + Ftx2[..., 1] ** 2 + 1e-15))
+        tot = tot + torch.clamp(ys, max=1.0).mean()
+    ref = tot / P
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    g, gr = md.grad.cpu().double(), m64.grad
+    assert (g[~keep] == 0).all()
+    assert (g - gr).abs().max() <= 2e-4 * gr.abs().max()
