@@ -226,6 +226,22 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    # informational: the same step followed by the final refit of ransac.py:148-195 (K7: Nister on all points in f64 on a
+    # side stream, re-score, keep if better) -- a per-pair epilogue, not part of the hypothesis loop the metric counts
+    with_refit = None
+    if world == 1:
+        rn_refit = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
+                                 seed=4321, keep_masks=True, refit=True)
+        for _ in range(3):
+            rn_refit(matches, logits, K1, K2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            rn_refit(matches, logits, K1, K2)
+        torch.cuda.synchronize()
+        e3 = time.perf_counter() - t2
+        with_refit = {"value": P * B * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3}
+
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
     flops_per_launch = 39.0 * P * M * N
@@ -274,6 +290,7 @@ def main():
                      "valu_frac_of_157.3": flops_per_launch / (k4_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
         "check": {"mean_inlier_fraction_of_best_model": inl_frac},
         "overlap": overlap,
+        "with_final_refit": with_refit,
     }
     if args.profile_kernels and rank == 0:
         result["kernel_breakdown_ms"] = kernel_breakdown(args, rn, matches, logits, K1, K2, ops)

@@ -1,0 +1,338 @@
+// Device-side building blocks of the five-point solvers, shared by solve_fivepoint.hip (minimal / per-sample kernels)
+// and refit.hip (K7: one cooperative block per image pair).
+#pragma once
+#include "solver_common.hpp"
+
+namespace dr {
+
+constexpr int kFiveWs = 162;   // doubles of LDS per lane: B block (100) for the minimal path, A^T A + V (162) for n > 5
+constexpr int kStewWs = 212;   // Stewenius: 10x20, then Hessenberg 10x10 (0..99) + La Budde polynomials (100..209)
+
+// ---- null-space basis ---------------------------------------------------------------------------------
+// minimal: Householder QR of the 5x9 system (registers).  nb[t][0..8], t = 0..3
+template <typename T>
+__device__ __forceinline__ void fivepoint_basis_minimal(const T *__restrict__ pts, const T *__restrict__ wts,
+                                                        double (&nb)[4][9]) {
+  double A[5][9];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const double w = wts ? (double)wts[r] : 1.0;
+    epipolar_row_5pt((double)pts[4 * r], (double)pts[4 * r + 1], (double)pts[4 * r + 2], (double)pts[4 * r + 3], w, A[r]);
+  }
+  null_space_qr<5>(A, nb);
+}
+
+// non-minimal (n > 5; nister.py:64-65 runs the minimal code on all points): the four eigenvectors of A^T A
+// with the smallest eigenvalues, by cyclic Jacobi in LDS.  Order: nb[0] <-> 4th smallest ... nb[3] <-> smallest,
+// which is the order torch.linalg.svd's Vh[-4:] has.
+template <typename T>
+__device__ __forceinline__ void fivepoint_basis_nonminimal(const T *__restrict__ pts, const T *__restrict__ wts, int n,
+                                           const LaneWs &ws, double (&nb)[4][9]) {
+  LaneWs A{ws.base}, V{ws.base + 81 * 64};
+  for (int e = 0; e < 81; ++e) A[e] = 0.0;
+  for (int r = 0; r < n; ++r) {
+    double row[9];
+    const double w = wts ? (double)wts[r] : 1.0;
+    epipolar_row_5pt((double)pts[4 * r], (double)pts[4 * r + 1], (double)pts[4 * r + 2], (double)pts[4 * r + 3], w, row);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) A[i * 9 + j] += row[i] * row[j];
+  }
+  jacobi_eig_lds<9>(A, V);
+  unsigned used = 0;
+  for (int t = 3; t >= 0; --t) {  // t = 3 takes the smallest
+    int best = 0;
+    double bv = INFINITY;
+    for (int i = 0; i < 9; ++i) {
+      const double ev = A[i * 9 + i];
+      if (!((used >> i) & 1u) && ev < bv) { bv = ev; best = i; }
+    }
+    used |= 1u << best;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double v = V[i * 9 + best];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        if (tt == t) nb[tt][i] = v;
+    }
+  }
+}
+
+// entry polynomial (i,j) of E~(x,y,z) = x N0 + y N1 + z N2 + N3 is (N0..N3)[3j+i]  (nister.py:123, stewenius.py:53)
+__device__ __forceinline__ void basis_to_entries(const double (&nb)[4][9], double (&e)[3][3][4]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) e[i][j][t] = nb[t][3 * j + i];
+}
+
+template <typename T>
+__device__ __forceinline__ void write_identity(T *__restrict__ dst) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) dst[q] = T(q % 4 == 0 ? 1 : 0);
+}
+
+// Gauss-Newton refinement of (x, y, z) on the ten defining constraints 2EE^TE - tr(EE^T)E = 0, det E = 0 with
+// E = x N0 + y N1 + z N2 + N3.  The hidden-variable resultant (Nister) and the action-matrix eigen-problem
+// (Stewenius) can lose digits when roots cluster; the constraint system itself is well conditioned wherever
+// the essential matrix is, so two iterations restore full f64 accuracy (and are basis independent).
+__device__ __forceinline__ void essential_residual(const double (&E)[9], double (&r)[10]) {
+  double G[9];  // E E^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[3 * i + j] = E[3 * i] * E[3 * j] + E[3 * i + 1] * E[3 * j + 1] + E[3 * i + 2] * E[3 * j + 2];
+  const double tr = G[0] + G[4] + G[8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      r[3 * i + j] = 2.0 * (G[3 * i] * E[j] + G[3 * i + 1] * E[3 + j] + G[3 * i + 2] * E[6 + j]) - tr * E[3 * i + j];
+  r[9] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
+}
+
+// Gauss-Newton in HOMOGENEOUS coordinates: E = sum_k u_k N_k with |u| = 1 (so |E|_F = 1: the basis is orthonormal).
+// r(E) is homogeneous of degree 3, hence J u = 3 r ~ 0 and the normal matrix is singular along u; adding u u^T picks the
+// step orthogonal to u.  No chart, no scaling problem when a solution has a vanishing N3 component (|z| -> infinity), and
+// no per-root permutation of the basis (everything is statically indexed).
+__device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&u)[4], bool live) {
+  // two iterations for everybody, then only waves that still hold an unconverged sample go on (max 8)
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    if (it >= 2 && !__any(live)) break;
+    double E[9], r[10];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
+    essential_residual(E, r);
+    double n0 = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
+    double J[4][10];
+    double EEt[9], EtE[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        EEt[3 * i + jx] = E[3 * i] * E[3 * jx] + E[3 * i + 1] * E[3 * jx + 1] + E[3 * i + 2] * E[3 * jx + 2];
+        EtE[3 * i + jx] = E[i] * E[jx] + E[3 + i] * E[3 + jx] + E[6 + i] * E[6 + jx];
+      }
+    const double tr = EEt[0] + EEt[4] + EEt[8];
+    const double cof[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
+                           E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
+                           E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double(&H)[9] = nb[k];
+      double HEt[9];
+      double trEHt = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx)
+          HEt[3 * i + jx] = H[3 * i] * E[3 * jx] + H[3 * i + 1] * E[3 * jx + 1] + H[3 * i + 2] * E[3 * jx + 2];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) trEHt += E[q] * H[q];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx) {
+          const double t1 = H[3 * i] * EtE[jx] + H[3 * i + 1] * EtE[3 + jx] + H[3 * i + 2] * EtE[6 + jx];     // H E^T E
+          const double t2 = HEt[i] * E[jx] + HEt[3 + i] * E[3 + jx] + HEt[6 + i] * E[6 + jx];                  // E H^T E
+          const double t3 = EEt[3 * i] * H[jx] + EEt[3 * i + 1] * H[3 + jx] + EEt[3 * i + 2] * H[6 + jx];     // E E^T H
+          J[k][3 * i + jx] = 2.0 * (t1 + t2 + t3) - 2.0 * trEHt * E[3 * i + jx] - tr * H[3 * i + jx];
+        }
+      double dd = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
+      J[k][9] = dd;
+    }
+    // (J^T J + u u^T) d = J^T r : 4x4 SPD, LDL^T without pivoting
+    double a[4][4], g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g[i] = 0;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) g[i] += J[i][q] * r[q];
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) {
+        double acc = u[i] * u[jx];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) acc += J[i][q] * J[jx][q];
+        a[i][jx] = acc;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double inv = 1.0 / a[c][c];
+#pragma unroll
+      for (int rr = c + 1; rr < 4; ++rr) {
+        const double f = a[rr][c] * inv;
+#pragma unroll
+        for (int k = c; k < 4; ++k) a[rr][k] -= f * a[c][k];
+        g[rr] -= f * g[c];
+      }
+    }
+    double d[4];
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+      double acc = g[c];
+#pragma unroll
+      for (int k = c + 1; k < 4; ++k) acc -= a[c][k] * d[k];
+      d[c] = acc / a[c][c];
+    }
+    double un[4], nn = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { un[k] = u[k] - d[k]; nn += un[k] * un[k]; }
+    const double sc = 1.0 / sqrt(nn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) un[k] *= sc;
+    double E2[9], r2[10], n1 = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) E2[q] = un[0] * nb[0][q] + un[1] * nb[1][q] + un[2] * nb[2][q] + un[3] * nb[3][q];
+    essential_residual(E2, r2);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
+    const bool better = n1 <= n0 && is_finite(n1);
+    if (better && (live || it < 2)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = un[k];
+    }
+    // |E| = 1: stop at rounding level, or when the residual no longer shrinks geometrically
+    live = live && better && (n1 > 1e-28) && (n1 < 0.25 * n0);
+  }
+}
+
+// Final stage shared by both solvers: homogeneous polish of the coefficient vector (x, y, z, 1)/|.|, then a
+// VERIFICATION of the ten constraints on the (unit-norm) matrix.  `valid` therefore means "checked essential matrix
+// through the five points", not "the root finder said so".
+template <typename T>
+__device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double x, double y, double z, bool candidate,
+                                                T *__restrict__ dst, bool store) {
+  const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+  double u[4] = {x * inv, y * inv, z * inv, inv};
+  bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
+  if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
+  polish_homog(nb, u, good);
+  double E[9], r[10];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
+  essential_residual(E, r);
+  double rn = 0;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) rn += r[q] * r[q];
+  good = good && is_finite(rn) && rn <= 1e-14;
+  if (good && store) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) dst[3 * i + jx] = (T)E[3 * jx + i];   // stored transposed (nister.py:407)
+  }
+  return good;
+}
+
+// ---- Nister: B(z) from the reduced rows, det B(z), roots, back-substitution -----------------------------
+// kPair: two lanes share one sample -- `half` 0 searches |z| <= 1 and fills the slots upwards from 0, `half` 1 searches
+// |z| > 1 and fills downwards from 9; the slots in between become eye(3).
+template <typename T, bool kPair>
+__device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const double (&X)[6][10], bool ok, T *__restrict__ models,
+                              uint8_t *__restrict__ valid, bool active, int half = 0) {
+  // reduced rows e..j = rows 4..9, right block columns 10..19 hold (x z^2, x z, x | y z^2, y z, y | z^3, z^2, z, 1)
+  // k = e - z f, l = g - z h, m = i - z j  ->  B(z) columns (x: deg 3, y: deg 3, 1: deg 4), ascending coefficients
+  double bx[3][4], by[3][4], b1[3][5];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double hi[10], lo[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      hi[c] = X[2 * r][c];
+      lo[c] = X[2 * r + 1][c];
+    }
+    // hi = (a2 z^2 + a1 z + a0) with hi[0]=a2,hi[1]=a1,hi[2]=a0 ; minus z*(lo)
+    bx[r][0] = hi[2];          bx[r][1] = hi[1] - lo[2]; bx[r][2] = hi[0] - lo[1]; bx[r][3] = -lo[0];
+    by[r][0] = hi[5];          by[r][1] = hi[4] - lo[5]; by[r][2] = hi[3] - lo[4]; by[r][3] = -lo[3];
+    b1[r][0] = hi[9];          b1[r][1] = hi[8] - lo[9]; b1[r][2] = hi[7] - lo[8]; b1[r][3] = hi[6] - lo[7];
+    b1[r][4] = -lo[6];
+  }
+  // det = sum_r c2[r] * cofactor_r ; minors of columns (x,y): degree 6
+  double cs[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) cs[i] = 0;
+  auto minor_acc = [&](int a, int b, int r, double sgn) {
+    double mn[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) mn[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mn[i + j] += bx[a][i] * by[b][j] - bx[b][i] * by[a][j];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) cs[i + j] += sgn * mn[i] * b1[r][j];
+  };
+  minor_acc(1, 2, 0, 1.0);
+  minor_acc(0, 2, 1, -1.0);
+  minor_acc(0, 1, 2, 1.0);
+
+  double roots[10];
+  int nroots;
+  DR_STAGE_BEGIN();
+  if (kPair) real_roots_half<10>(cs, half != 0, roots, nroots);
+  else real_roots<10>(cs, roots, nroots);
+  DR_STAGE(3);
+  if (!ok) nroots = 0;
+
+  int slot = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    if (!__any(i < nroots)) continue;   // wave-uniform skip; lanes without this root compute and discard
+    const bool has_root = i < nroots;
+    const double z = roots[i];
+    // rows of B(z): (bx(z), by(z), b1(z)) . (x, y, 1) = 0 ; null vector = best-conditioned cross product
+    double rx[3], ry[3], r1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      rx[r] = ((bx[r][3] * z + bx[r][2]) * z + bx[r][1]) * z + bx[r][0];
+      ry[r] = ((by[r][3] * z + by[r][2]) * z + by[r][1]) * z + by[r][0];
+      r1[r] = (((b1[r][4] * z + b1[r][3]) * z + b1[r][2]) * z + b1[r][1]) * z + b1[r][0];
+    }
+    double bestn = -1, vx = 0, vy = 0, vw = 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 3; ++b) {
+        const double cx = ry[a] * r1[b] - r1[a] * ry[b];
+        const double cy = r1[a] * rx[b] - rx[a] * r1[b];
+        const double cw = rx[a] * ry[b] - ry[a] * rx[b];
+        const double nn = cw * cw;  // we divide by the w component: pick the largest
+        if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
+      }
+    const double x = vx / vw, y = vy / vw;
+    const int dst_slot = (kPair && half) ? 9 - slot : slot;
+    const bool good = finish_solution<T>(nb, x, y, z, has_root && is_finite(x) && is_finite(y) && slot < 10,
+                                         models + 9 * dst_slot, active);
+    if (good && active) valid[dst_slot] = 1;
+    slot += good ? 1 : 0;
+  }
+  if (kPair) {
+    // the partner lane's count; if numerical duplicates ever made the two halves overlap, the upper half wins
+    const int other = __shfl_xor(slot, 1, 64);
+    const int lo = half ? other : slot, hi = half ? slot : other;   // slots [0,lo) and (9-hi, 9] are taken
+    if (active && half == 0) {
+      for (int s = min(lo, 10 - hi); s < 10 - hi; ++s) {
+        write_identity<T>(models + 9 * s);
+        valid[s] = 0;
+      }
+    }
+  } else if (active) {
+    for (int s = slot; s < 10; ++s) {
+      write_identity<T>(models + 9 * s);
+      valid[s] = 0;
+    }
+  }
+}
+
+}  // namespace dr

@@ -1,0 +1,223 @@
+// K7 -- final refit of the best model (RANSAC.__call__, ransac.py:148-195), batched over pairs with no host round trip:
+//   essential:    Nister on ALL N points of the pair as one "sample" (what nister.py:64-65 does when pymagsac is absent,
+//                 ransac.py:157-165), in f64;
+//   fundamental:  Hartley-normalised LSQ 8-point on the INLIERS of the best mask (ransac.py:150-155,
+//                 fundamental_matrix_estimator.py:172-174,177-260).
+// One 256-thread block per pair: the four waves accumulate the 9x9 Gram matrix of the (weighted / masked) epipolar rows
+// cooperatively (three passes for F: centroid, mean distances, Gram), then wave 0 -- all 64 lanes redundantly, lane 0
+// stores -- runs the same device code as the per-sample solvers (Jacobi eigen-decomposition, five-point pipeline).
+// The ragged inlier sets never leave the device.
+#include "fivepoint_device.hpp"
+
+namespace dr {
+
+constexpr int kRefT = 256;
+
+__device__ __forceinline__ double block_sum(double v, double *red /* [4] */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// accumulates sum_n w_n * row_n row_n^T (45 unique entries) over this thread's points into gram[81] in LDS
+template <bool kFundamental, typename T>
+__device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const uint8_t *__restrict__ mk, int N,
+                                                const double (&mu)[4], double r1, double r2, double *gram, double *red) {
+  double acc[45];
+#pragma unroll
+  for (int q = 0; q < 45; ++q) acc[q] = 0;
+  for (int n = threadIdx.x; n < N; n += kRefT) {
+    if (mk && !mk[n]) continue;
+    double row[9];
+    if (kFundamental)
+      epipolar_row_f(((double)mt[4 * n] - mu[0]) * r1, ((double)mt[4 * n + 1] - mu[1]) * r1,
+                     ((double)mt[4 * n + 2] - mu[2]) * r2, ((double)mt[4 * n + 3] - mu[3]) * r2, 1.0, row);
+    else
+      epipolar_row_5pt((double)mt[4 * n], (double)mt[4 * n + 1], (double)mt[4 * n + 2], (double)mt[4 * n + 3], 1.0, row);
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = i; j < 9; ++j) acc[q++] += row[i] * row[j];
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = i; j < 9; ++j) {
+      const double s = block_sum(acc[q++], red);
+      if (threadIdx.x == 0) { gram[i * 9 + j] = s; gram[j * 9 + i] = s; }
+    }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kRefT) void refit_essential_kernel(const T *__restrict__ matches,
+                                                                const uint8_t *__restrict__ mask, int N,
+                                                                T *__restrict__ models, uint8_t *__restrict__ valid) {
+  extern __shared__ __align__(16) double lds[];   // [162 * 64] per-lane workspace of wave 0, then gram[81], red[4]
+  double *gram = lds + 162 * 64;
+  double *red = gram + 81;
+  const int p = blockIdx.x;
+  const T *mt = matches + (size_t)p * N * 4;
+  const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
+  const double mu[4] = {0, 0, 0, 0};
+  gram_accumulate<false, T>(mt, mk, N, mu, 1.0, 1.0, gram, red);
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
+  for (int e = 0; e < 81; ++e) A[e] = gram[e];
+  jacobi_eig_lds<9>(A, V);
+  double nb[4][9];
+  unsigned used = 0;
+  for (int t = 3; t >= 0; --t) {
+    int best = 0;
+    double bv = INFINITY;
+    for (int i = 0; i < 9; ++i) {
+      const double ev = A[i * 9 + i];
+      if (!((used >> i) & 1u) && ev < bv) { bv = ev; best = i; }
+    }
+    used |= 1u << best;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double v = V[i * 9 + best];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        if (tt == t) nb[tt][i] = v;
+    }
+  }
+  double e[3][3][4];
+  basis_to_entries(nb, e);
+  LaneWs w{lds + lane};
+  double X[6][10];
+  const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
+  nister_finish<T, false>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane == 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kRefT) void refit_fundamental_kernel(const T *__restrict__ matches,
+                                                                  const uint8_t *__restrict__ mask, int N,
+                                                                  T *__restrict__ models, uint8_t *__restrict__ valid) {
+  extern __shared__ __align__(16) double lds[];
+  double *gram = lds + 162 * 64;
+  double *red = gram + 81;
+  const int p = blockIdx.x;
+  const T *mt = matches + (size_t)p * N * 4;
+  const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
+  // pass 1: centroid of the selected points
+  double s[4] = {0, 0, 0, 0}, cnt = 0;
+  for (int n = threadIdx.x; n < N; n += kRefT) {
+    if (mk && !mk[n]) continue;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) s[d] += (double)mt[4 * n + d];
+    cnt += 1.0;
+  }
+  const double nsel = block_sum(cnt, red);
+  double mu[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) mu[d] = block_sum(s[d], red) / nsel;
+  // pass 2: mean distances
+  double d1 = 0, d2 = 0;
+  for (int n = threadIdx.x; n < N; n += kRefT) {
+    if (mk && !mk[n]) continue;
+    const double a = (double)mt[4 * n] - mu[0], b = (double)mt[4 * n + 1] - mu[1];
+    const double c = (double)mt[4 * n + 2] - mu[2], d = (double)mt[4 * n + 3] - mu[3];
+    d1 += sqrt(a * a + b * b);
+    d2 += sqrt(c * c + d * d);
+  }
+  const double r1 = M_SQRT2 * nsel / block_sum(d1, red), r2 = M_SQRT2 * nsel / block_sum(d2, red);
+  // pass 3: Gram matrix of the normalised rows
+  gram_accumulate<true, T>(mt, mk, N, mu, r1, r2, gram, red);
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
+  for (int e = 0; e < 81; ++e) A[e] = gram[e];
+  jacobi_eig_lds<9>(A, V);
+  int best = 0;
+  double bv = INFINITY;
+  for (int i = 0; i < 9; ++i) {
+    const double ev = A[i * 9 + i];
+    if (ev < bv) { bv = ev; best = i; }
+  }
+  double f[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) f[q] = V[q * 9 + best];
+  double G[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    G[i][0] = f[3 * i] * r1;
+    G[i][1] = f[3 * i + 1] * r1;
+    G[i][2] = -r1 * (f[3 * i] * mu[0] + f[3 * i + 1] * mu[1]) + f[3 * i + 2];
+  }
+  double F[9];
+  bool ok = nsel >= 8.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    F[j] = r2 * G[0][j];
+    F[3 + j] = r2 * G[1][j];
+    F[6 + j] = -r2 * (mu[2] * G[0][j] + mu[3] * G[1][j]) + G[2][j];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) ok = ok && is_finite(F[q]);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) models[(size_t)p * 9 + q] = ok ? (T)F[q] : T(q % 4 == 0 ? 1 : 0);
+    valid[p] = ok;
+  }
+}
+
+template <typename T>
+int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, int P, int N, T *models, uint8_t *valid,
+                 hipStream_t st) {
+  const size_t smem = sizeof(double) * (162 * 64 + 81 + 4);
+  static bool attr_e = false, attr_f = false;
+  if (fundamental) {
+    if (!attr_f) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_fundamental_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_f = true;
+    }
+    hipLaunchKernelGGL((refit_fundamental_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, N, models, valid);
+  } else {
+    if (!attr_e) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_essential_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_e = true;
+    }
+    hipLaunchKernelGGL((refit_essential_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, N, models, valid);
+  }
+  return check_launch("refit_kernel");
+}
+
+}  // namespace dr
+
+extern "C" {
+
+int dr_refit_essential_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
+                           void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && N >= 5, "bad sizes");
+  return dr::refit_launch<float>(false, matches, mask, P, N, models, valid, (hipStream_t)stream);
+}
+int dr_refit_essential_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
+                           void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && N >= 5, "bad sizes");
+  return dr::refit_launch<double>(false, matches, mask, P, N, models, valid, (hipStream_t)stream);
+}
+int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
+                             void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
+  return dr::refit_launch<float>(true, matches, mask, P, N, models, valid, (hipStream_t)stream);
+}
+int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
+                             void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
+  return dr::refit_launch<double>(true, matches, mask, P, N, models, valid, (hipStream_t)stream);
+}
+
+}  // extern "C"

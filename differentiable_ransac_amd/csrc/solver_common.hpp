@@ -70,47 +70,6 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gauss-Jordan with partial pivoting of an R x C matrix in LDS (left R x R block -> identity).
-// Returns false when a pivot underflows rel_tiny * (largest |entry| of the input).
-// ------------------------------------------------------------------------------------------------
-template <int R, int C>
-__device__ __forceinline__ bool gauss_jordan_lds(const LaneWs &w, double rel_tiny = 1e-14) {
-  double amax = 0;
-  for (int e = 0; e < R * C; ++e) amax = fmax(amax, fabs(w[e]));
-  bool ok = amax > 0 && is_finite(amax);
-  const double tiny = rel_tiny * amax;
-#pragma unroll
-  for (int col = 0; col < R; ++col) {
-    int piv = col;
-    double best = fabs(w[col * C + col]);
-    for (int r = col + 1; r < R; ++r) {
-      const double v = fabs(w[r * C + col]);
-      if (v > best) { best = v; piv = r; }
-    }
-    if (!(best > tiny)) ok = false;
-    // bring the pivot row to `col`, normalise it, keep it in registers
-    double prow[C];
-    const double inv = best > 0 ? 1.0 / w[piv * C + col] : 0.0;
-#pragma unroll
-    for (int c = col; c < C; ++c) {
-      const double a = w[piv * C + c];
-      const double b = w[col * C + c];
-      w[piv * C + c] = b;
-      prow[c] = a * inv;
-      w[col * C + c] = prow[c];
-    }
-    for (int r = 0; r < R; ++r) {
-      if (r == col) continue;
-      const double f = w[r * C + col];
-#pragma unroll
-      for (int c = col + 1; c < C; ++c) w[r * C + c] -= f * prow[c];
-      w[r * C + col] = 0.0;
-    }
-  }
-  return ok;
-}
-
-// ------------------------------------------------------------------------------------------------
 // All real roots of a degree-D polynomial (coefficients ascending), robustly in plain arithmetic.
 //   * |z| <= 1 : roots of p in [-1, 1];   |z| > 1 : z = 1/w with w a root of the reversed polynomial in (-1, 1).
 //     Both searches live on [-1, 1], so there is no root bound to estimate and no huge outer bracket to crawl through.
@@ -476,71 +435,6 @@ __device__ __forceinline__ void pmul21_acc(const double (&a)[10], const double (
     for (int j = 0; j < 4; ++j) o[Ord::T.t21[i][j]] += scale * a[i] * b[j];
 }
 
-// Ten cubic constraints on E(x,y,z) = x B0 + y B1 + z B2 + B3 written into the LDS matrix w (10 x 20):
-// rows 0-8 = entries (row-major i,j) of  s*(E E^T E - 1/2 tr(E E^T) E)  (s = 2 for Stewenius' 2EE^TE - tr(EE^T)E),
-// row 9 = det E.   e[i][j][0..3] = entry polynomial (i,j) in (x,y,z,1).
-template <class Ord>
-__device__ void build_constraints(const double (&e)[3][3][4], const LaneWs &w, double s) {
-  // EE^T (symmetric): 6 polynomials of degree 2
-  double eet[3][3][10];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = i; j < 3; ++j) {
-      pmul11<Ord>(e[i][0], e[j][0], eet[i][j]);
-      pmul11<Ord>(e[i][1], e[j][1], eet[i][j], 1.0, true);
-      pmul11<Ord>(e[i][2], e[j][2], eet[i][j], 1.0, true);
-    }
-#pragma unroll
-  for (int i = 1; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < i; ++j)
-#pragma unroll
-      for (int t = 0; t < 10; ++t) eet[i][j][t] = eet[j][i][t];
-  // subtract half the trace from the diagonal:  (EE^T - 1/2 tr I)
-#pragma unroll
-  for (int t = 0; t < 10; ++t) {
-    const double h = 0.5 * (eet[0][0][t] + eet[1][1][t] + eet[2][2][t]);
-    eet[0][0][t] -= h;
-    eet[1][1][t] -= h;
-    eet[2][2][t] -= h;
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double row[20];
-#pragma unroll
-      for (int t = 0; t < 20; ++t) row[t] = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pmul21_acc<Ord>(eet[i][k], e[k][j], row, s);
-#pragma unroll
-      for (int t = 0; t < 20; ++t) w[(3 * i + j) * 20 + t] = row[t];
-    }
-  // determinant
-  double row[20];
-#pragma unroll
-  for (int t = 0; t < 20; ++t) row[t] = 0;
-  double m[10], m2[10];
-  pmul11<Ord>(e[0][1], e[1][2], m);
-  pmul11<Ord>(e[0][2], e[1][1], m2);
-#pragma unroll
-  for (int t = 0; t < 10; ++t) m[t] -= m2[t];
-  pmul21_acc<Ord>(m, e[2][0], row, 1.0);
-  pmul11<Ord>(e[0][2], e[1][0], m);
-  pmul11<Ord>(e[0][0], e[1][2], m2);
-#pragma unroll
-  for (int t = 0; t < 10; ++t) m[t] -= m2[t];
-  pmul21_acc<Ord>(m, e[2][1], row, 1.0);
-  pmul11<Ord>(e[0][0], e[1][1], m);
-  pmul11<Ord>(e[0][1], e[1][0], m2);
-#pragma unroll
-  for (int t = 0; t < 10; ++t) m[t] -= m2[t];
-  pmul21_acc<Ord>(m, e[2][2], row, 1.0);
-#pragma unroll
-  for (int t = 0; t < 20; ++t) w[9 * 20 + t] = row[t];
-}
-
 // ------------------------------------------------------------------------------------------------
 // Constraint system [A | B] (10 x 20) -> selected rows of X = A^-1 B, without pivoting and without run-time
 // indexing: A (left 10 x 10) stays in VGPRs and is factored by Householder QR (backward stable with no
@@ -554,7 +448,9 @@ template <class Ord, int kFirstRow>
 __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], const LaneWs &Bw, double s,
                                    double (&X)[10 - kFirstRow][10]) {
   double A[10][10];
-  // ---- generate the ten rows (same maths as build_constraints), A-part to registers, B-part to LDS
+  // ---- the ten cubic constraints on E(x,y,z) = x B0 + y B1 + z B2 + B3: rows 0-8 = entries (row-major i,j) of
+  //      s*(E E^T E - 1/2 tr(E E^T) E) (s = 2 for Stewenius' 2EE^TE - tr(EE^T)E), row 9 = det E;
+  //      e[i][j][0..3] = entry polynomial (i,j) in (x,y,z,1).  A-part to registers, B-part to LDS
   double tr[10];
   {
     double d0[10], d1[10], d2[10];

@@ -277,6 +277,29 @@ def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torc
     return chosen, which
 
 
+def refit_essential(matches: torch.Tensor, mask: Optional[torch.Tensor] = None):
+    """K7 (E): five-point solver on all (masked) points of every pair as one sample, f64 inside.
+    matches [P,N,4] -> models [P,10,3,3], valid [P,10]."""
+    P, N, _ = matches.shape
+    models = torch.empty((P, 10, 3, 3), device=matches.device, dtype=matches.dtype)
+    valid = torch.empty((P, 10), device=matches.device, dtype=torch.bool)
+    mk = None if mask is None else mask.contiguous().view(torch.uint8)
+    L.call(f"dr_refit_essential_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk), c_int(P), c_int(N),
+           ptr(models), ptr(valid), stream())
+    return models, valid
+
+
+def refit_fundamental(matches: torch.Tensor, mask: Optional[torch.Tensor] = None):
+    """K7 (F): Hartley-normalised LSQ 8-point on the masked points of every pair.  -> F [P,3,3], valid [P]."""
+    P, N, _ = matches.shape
+    models = torch.empty((P, 3, 3), device=matches.device, dtype=matches.dtype)
+    valid = torch.empty((P,), device=matches.device, dtype=torch.bool)
+    mk = None if mask is None else mask.contiguous().view(torch.uint8)
+    L.call(f"dr_refit_fundamental_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk), c_int(P), c_int(N),
+           ptr(models), ptr(valid), stream())
+    return models, valid
+
+
 # ------------------------------------------------------------------------------------------ autograd wrappers
 class _SolveEssential(torch.autograd.Function):
     """Five-point solve with implicit-function backward (dr_solve_nister5_bwd): at a returned model E the five

@@ -229,6 +229,7 @@ class BatchedRANSAC(object):
         self.refit = refit
         self.eps = eps
         self.fmat = solver in ("f8", "f7")
+        self._side = None
 
     def _next_seed(self):
         s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
@@ -275,6 +276,16 @@ class BatchedRANSAC(object):
             st = ops.RansacState(P, N, self.max_iterations, dev, dt)
             all_masks = None
             matches = matches.contiguous()
+            # The essential-matrix refit candidate (Nister on ALL points, ransac.py:157-165) depends on the matches only:
+            # it is issued up front on a side stream (32 latency-bound blocks) and joins before the final scoring.
+            pre = None
+            if self.refit and not self.fmat:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    pre = ops.refit_essential(matches)
+                    matches.record_stream(self._side)
             for r in range(rounds):
                 g = None if gumbels is None else (gumbels[r] if r < len(gumbels) else None)
                 if gumbels is not None and g is None:
@@ -294,17 +305,15 @@ class BatchedRANSAC(object):
                                                                   st.best_inliers, st.iters.long())
             if self.refit:
                 if self.fmat:
-                    cand = []
-                    for p in range(P):  # ragged inlier sets: one LSQ per pair
-                        pts = matches[p][best_mask[p]]
-                        cand.append(ops.solve_f8(pts.unsqueeze(0))[0] if pts.shape[0] >= 8 else
-                                    torch.eye(3, device=dev, dtype=dt).unsqueeze(0))
-                    cand = torch.stack(cand)  # [P,1,3,3]
+                    F, fvalid = ops.refit_fundamental(matches, best_mask)   # LSQ on the inliers of the best mask
+                    cand, cvalid = F.unsqueeze(1), fvalid.unsqueeze(1)
                 else:
-                    cand, cvalid = ops.solve_nister5(matches.double())  # all N points as one f64 sample per pair
-                    cand = cand.to(dt)
+                    torch.cuda.current_stream().wait_stream(self._side)
+                    cand, cvalid = pre
+                    cand.record_stream(torch.cuda.current_stream())
+                    cvalid.record_stream(torch.cuda.current_stream())
                 cs, _ = ops.msac_score(matches, cand, thr, want_masks=False)
-                ci, cbs, cbm, cmask, cinl = ops.select_best(matches, cand, cs, thr, None if self.fmat else cvalid)
+                ci, cbs, cbm, cmask, cinl = ops.select_best(matches, cand, cs, thr, cvalid)
                 better = (cbs > best_score) & (ci >= 0)
                 best_model = torch.where(better[:, None, None], cbm, best_model)
                 best_score = torch.where(better, cbs, best_score)

@@ -203,6 +203,24 @@ int dr_ransac_update_f64(const double *matches, const double *models, const uint
                          int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K7  final refit, RANSAC.__call__ ransac.py:148-195, batched over pairs (one cooperative block per pair, the ragged
+ *     inlier sets stay on the device).  mask [P,N] uint8 selects the points (NULL = all).
+ *   dr_refit_essential    five-point solver on all selected points as ONE sample (nister.py:64-65, the path taken
+ *                         when pymagsac is absent; ransac.py:157-165 passes ALL points => mask = NULL), computed in
+ *                         f64; models [P,10,9], valid [P,10].
+ *   dr_refit_fundamental  Hartley-normalised LSQ 8-point on the selected points (ransac.py:150-155 passes the inliers
+ *                         of the best mask); models [P,9], valid [P] (0 when fewer than 8 points are selected).
+ * ------------------------------------------------------------------------------------------ */
+int dr_refit_essential_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
+                           void *stream);
+int dr_refit_essential_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
+                           void *stream);
+int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
+                             void *stream);
+int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
+                             void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * the training loss right after the path -- MatchLoss (loss.py:107-153) on batch_episym
  * (cv_utils.py:680-695).  sums [P,M] = sum over the points with mask[p,n] != 0 (NULL = all points) of
  * min(ys, 1), ys = (x2^T M x1)^2 (1/((Mx1)_0^2+(Mx1)_1^2+1e-15) + 1/((M^T x2)_0^2+(M^T x2)_1^2+1e-15)).

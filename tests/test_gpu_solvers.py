@@ -240,3 +240,43 @@ def test_select_closest(dev):
     assert torch.equal(chosen.cpu()[0, 0], torch.eye(3))
     c2, w2 = ops.select_closest(models.to(dev), None, gt.to(dev))
     assert torch.equal(w2.cpu().long(), torch.linalg.norm(models - gt[:, None, None], dim=(-1, -2)).argmin(-1))
+
+
+def test_batched_refit_kernels(dev):
+    """K7: cooperative per-pair refit kernels vs the oracle (and the reference's non-minimal golden vector)."""
+    from differentiable_ransac_amd import ops, synth
+    g = load_golden("nister_nonminimal")
+    for dt, tol in ((torch.float64, 1e-6), (torch.float32, TOL)):
+        E, valid = ops.refit_essential(g["matches"].to(dt).unsqueeze(0).to(dev))
+        d = O.match_solution_sets(E[0].cpu().double(), valid[0].cpu(), g["models"], torch.ones(10, dtype=torch.bool))
+        assert d.numel() >= 1 and d.max() < tol
+    P, N = 5, 2000
+    data = synth.batch_two_view(P, N, seed0=700)
+    E, valid = ops.refit_essential(data["matches"].to(dev))
+    for p in range(P):
+        Eo, ok, real = O.nister_5pt(data["matches"][p].double().unsqueeze(0))
+        fw = O.match_solution_sets(E[p].cpu().double(), valid[p].cpu(), Eo[0], real[0])
+        bw = O.match_solution_sets(Eo[0], real[0], E[p].cpu().double(), valid[p].cpu())
+        assert fw.numel() == bw.numel() and (fw.numel() == 0 or max(fw.max(), bw.max()) < TOL)
+    # masked variant == the per-sample kernel on the gathered points
+    mask = torch.rand(P, N, generator=torch.Generator().manual_seed(1)) > 0.6
+    Em, vm = ops.refit_essential(data["matches"].to(dev), mask.to(dev))
+    for p in range(2):
+        Es, vs = ops.solve_nister5(data["matches"][p][mask[p]].unsqueeze(0).to(dev))
+        fw = O.match_solution_sets(Em[p].cpu().double(), vm[p].cpu(), Es[0].cpu().double(), vs[0].cpu())
+        assert int(vm[p].sum()) == int(vs[0].sum()) and (fw.numel() == 0 or fw.max() < TOL)
+    # fundamental: LSQ on the inliers of a mask, ragged over pairs
+    dF = synth.batch_two_view(P, N, seed0=710, pixel=True)
+    mask = dF["inliers"].clone()
+    mask[3, 1500:] = False
+    F, fv = ops.refit_fundamental(dF["matches"].to(dev), mask.to(dev))
+    assert fv.all()
+    for p in range(P):
+        Fo = O.fundamental_8pt(dF["matches"][p][mask[p]].double().unsqueeze(0))[0]
+        s = torch.sign((F[p].cpu().double() * Fo).sum())
+        assert ((F[p].cpu().double() * s - Fo).abs().max() / Fo.abs().max()) < 1e-3
+        assert (O.canonical(F[p].cpu().double()) - O.canonical(dF["gt_F"][p].double())).abs().max() < 0.05
+    few = torch.zeros(P, N, dtype=torch.bool)
+    few[:, :5] = True
+    F, fv = ops.refit_fundamental(dF["matches"].to(dev), few.to(dev))
+    assert not fv.any() and (F.cpu() == torch.eye(3)).all()
