@@ -15,6 +15,8 @@
 //           pathological rows (> 64 candidates: massive ties) take a k-round arg-max slow path.
 // HBM traffic in fused mode: 4N bytes of logits (L2-resident across the B rows of a pair) in,
 // B(8k+4) bytes out.
+#include <algorithm>
+
 #include "dr_common.hpp"
 
 namespace dr {
@@ -286,9 +288,11 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
 template <typename T>
 __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const int32_t *__restrict__ idx,
                                                          const T *__restrict__ lse, const T *__restrict__ a_sel,
-                                                         T *__restrict__ grad_logits) {
-  // one thread per 4-point group of pair p (one Philox call regenerates its noise); loops over the B rows,
-  // 256 at a time, whose k winners / a values / <y,a> are staged in LDS by the block.
+                                                         T *__restrict__ grad_logits, int rows_per_block) {
+  // one thread per 4-point group of pair p (one Philox call regenerates its noise); blockIdx.z owns a chunk of
+  // `rows_per_block` hypothesis rows (their k winners / a values / <y,a> are staged in LDS) and adds its partial sums
+  // into grad_logits with one atomicAdd per point: (groups/256) x P x (B/rows_per_block) blocks fill the chip, where a
+  // single block per point group would leave 3/4 of the CUs idle at C2.
   const int p = blockIdx.y;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -303,8 +307,9 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
     const int n = 4 * q + j;
     l[j] = (n < a.N) ? (a.logits ? a.logits[(size_t)p * a.N + n] : T(1)) : T(0);
   }
-  for (int b0 = 0; b0 < a.B; b0 += 256) {
-    const int nb = min(256, a.B - b0);
+  const int b_lo = blockIdx.z * rows_per_block, b_hi = min(a.B, b_lo + rows_per_block);
+  for (int b0 = b_lo; b0 < b_hi; b0 += 256) {
+    const int nb = min(256, b_hi - b0);
     __syncthreads();
     if ((int)threadIdx.x < nb) {
       const size_t row = (size_t)p * a.B + b0 + threadIdx.x;
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (4 * q + j < a.N) grad_logits[(size_t)p * a.N + 4 * q + j] = acc[j] / a.tau;
+    if (4 * q + j < a.N) atomicAdd(grad_logits + (size_t)p * a.N + 4 * q + j, acc[j] / a.tau);
 }
 
 // ---- K1u: uniform indices in [0, N-2]
@@ -448,8 +453,15 @@ int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t se
   DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
   dr::GumbelArgs<float> a{logits, gumbel, seed, tau, P, B, N, k};
   const size_t smem = sizeof(float) * (256 * 2 + 256 * dr::kMaxK) + sizeof(int) * 256 * dr::kMaxK;
-  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(((N + 3) / 4 + 255) / 256, P), dim3(256), smem,
-                     (hipStream_t)stream, a, idx, lse, a_sel, grad_logits);
+  const int gx = ((N + 3) / 4 + 255) / 256;
+  // enough row chunks to put >= ~2048 blocks on the chip, at least 32 rows each
+  int chunks = (int)std::min<long>((B + 31) / 32, std::max<long>(1, 2048 / std::max<long>(1, (long)gx * P)));
+  const int rows_per_block = (B + chunks - 1) / chunks;
+  chunks = (B + rows_per_block - 1) / rows_per_block;
+  if (hipMemsetAsync(grad_logits, 0, sizeof(float) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
+    return dr::check_launch("memset");
+  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
+                     lse, a_sel, grad_logits, rows_per_block);
   return dr::check_launch("gumbel_bwd_kernel");
 }
 

@@ -17,6 +17,8 @@
 // Measured A/B (scratch/ab_k4.py, P=32, N=2000, M=10240, 44.5 % valid slots, masks on): 32-slot tiles +
 // 8-byte stores 279 us; 64-slot tiles 264 us; zero rows after the evaluations 259 us; 16 points per lane +
 // 16-byte stores 229 us (the mask stream is store-issue bound: halving the store count is worth 30 us).
+// Tried and dropped: dividing only where the wave holds an inlier (ballot-guarded rcp): 252 us -- the branch costs more
+// than the quarter-rate reciprocals it saves, because the VALID models nearly always have inliers somewhere in a wave.
 #include "dr_common.hpp"
 
 namespace dr {
