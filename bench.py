@@ -244,7 +244,11 @@ def main():
 
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
-    flops_per_launch = 39.0 * P * M * N
+    # executed flops: only the slots the solver marked valid are evaluated
+    with torch.no_grad():
+        _, v_, _ = rn.hypotheses(matches, logits)
+    valid_frac = float(v_.float().mean())
+    flops_per_launch = 39.0 * P * M * N * valid_frac
     achieved = bytes_per_launch / (k4_ms * 1e-3) / 1e9
 
     # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (profiles/, collected with
@@ -252,7 +256,8 @@ def main():
     traffic, traffic_note = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_fetch_write.json")
     if os.path.exists(pmc_path) and (P, N, B, args.solver) == (32, 2000, 1024, "nister"):
-        pmc = json.load(open(pmc_path)).get("dr::msac_score_kernel_f32_fast", {})
+        pmc_all = json.load(open(pmc_path))
+        pmc = pmc_all.get("dr::msac_score_kernel_f32_fast16", pmc_all.get("dr::msac_score_kernel_f32_fast", {}))
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             # gfx950: FETCH_SIZE shows half the bytes of 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled (upper bound:
             # most of this kernel's reads are scalar-cache model loads); WRITE_SIZE taken as is (matches the mask bytes to 0.2 %)
@@ -281,7 +286,7 @@ def main():
                    "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective",
                    "streams": len(streams)},
         "pairs_per_s": world * P * args.steps / elapsed,
-        "roofline": {"bound": "hbm", "kernel": "msac_score_kernel<float,true>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "msac_score_kernel_f32_fast16", "valid_slot_fraction": valid_frac, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
