@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--mode", default="test", choices=["test", "train"],
                     help="test: the headline inference path; train: sampler -> solver -> best-of-10 vs GT -> loss, forward "
                          "+ backward to the logits (ransac.py:78-108 + train.py:150), reported with the same JSON shape")
+    ap.add_argument("--extras", action="store_true",
+                    help="after the official timed region also measure (a) two-stream overlap of consecutive batches and "
+                         "(b) the step followed by the final refit; off by default so that a profiler sees only the official loop")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps are issued on round-robin: consecutive batches overlap (the latency-bound "
                          "sampler/solver of batch i+1 runs under the throughput-bound scoring of batch i)")
@@ -199,7 +202,7 @@ def main():
     # sampler/solver of batch i+1 overlaps the scoring of batch i (a serving loop would do this; it is not the headline
     # number because it blurs the per-kernel roofline attribution)
     overlap = None
-    if len(streams) == 1 and world == 1:
+    if args.extras and len(streams) == 1 and world == 1:
         s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
         keep = [None, None]
         for i in range(4):                       # warm the per-stream allocator pools
@@ -229,7 +232,7 @@ def main():
     # informational: the same step followed by the final refit of ransac.py:148-195 (K7: Nister on all points in f64 on a
     # side stream, re-score, keep if better) -- a per-pair epilogue, not part of the hypothesis loop the metric counts
     with_refit = None
-    if world == 1:
+    if args.extras and world == 1:
         rn_refit = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
                                  seed=4321, keep_masks=True, refit=True)
         for _ in range(3):

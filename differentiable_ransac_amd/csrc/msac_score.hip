@@ -18,7 +18,10 @@
 // 8-byte stores 279 us; 64-slot tiles 264 us; zero rows after the evaluations 259 us; 16 points per lane +
 // 16-byte stores 229 us (the mask stream is store-issue bound: halving the store count is worth 30 us).
 // Tried and dropped: dividing only where the wave holds an inlier (ballot-guarded rcp): 252 us -- the branch costs more
-// than the quarter-rate reciprocals it saves, because the VALID models nearly always have inliers somewhere in a wave.
+// than the quarter-rate reciprocals it saves, because the VALID models nearly always have inliers somewhere in a wave;
+// model coefficients staged in LDS + in-order VGPR prefetch instead of scalar-cache loads: 231 vs 235 us (noise: the
+// scalar-load latency is already hidden by occupancy); unpacked v_fma_f32 instead of v_pk_fma_f32: 224 vs 177 us with the
+// masks off -- packing is worth 1.27x here.
 #include "dr_common.hpp"
 
 namespace dr {

@@ -54,7 +54,7 @@ __device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const 
 }
 
 template <typename T>
-__global__ __launch_bounds__(kRefT) void refit_essential_kernel(const T *__restrict__ matches,
+__global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) void refit_essential_kernel(const T *__restrict__ matches,
                                                                 const uint8_t *__restrict__ mask, int N,
                                                                 T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];   // [162 * 64] per-lane workspace of wave 0, then gram[81], red[4]
@@ -67,26 +67,20 @@ __global__ __launch_bounds__(kRefT) void refit_essential_kernel(const T *__restr
   gram_accumulate<false, T>(mt, mk, N, mu, 1.0, 1.0, gram, red);
   if (threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
-  LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
-  for (int e = 0; e < 81; ++e) A[e] = gram[e];
-  jacobi_eig_lds<9>(A, V);
   double nb[4][9];
-  unsigned used = 0;
-  for (int t = 3; t >= 0; --t) {
-    int best = 0;
-    double bv = INFINITY;
-    for (int i = 0; i < 9; ++i) {
-      const double ev = A[i * 9 + i];
-      if (!((used >> i) & 1u) && ev < bv) { bv = ev; best = i; }
-    }
-    used |= 1u << best;
+  {
+    double A[9][9], V[9][9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const double v = V[i * 9 + best];
+    for (int i = 0; i < 9; ++i)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-        if (tt == t) nb[tt][i] = v;
-    }
+      for (int j = 0; j < 9; ++j) A[i][j] = gram[i * 9 + j];
+    jacobi_eig9_reg(A, V);
+    unsigned used = 0;
+    // nb[3] <-> smallest eigenvalue ... nb[0] <-> fourth smallest (the order of torch.linalg.svd's Vh[-4:])
+    smallest_eigvec9(A, V, used, nb[3]);
+    smallest_eigvec9(A, V, used, nb[2]);
+    smallest_eigvec9(A, V, used, nb[1]);
+    smallest_eigvec9(A, V, used, nb[0]);
   }
   double e[3][3][4];
   basis_to_entries(nb, e);
@@ -97,7 +91,7 @@ __global__ __launch_bounds__(kRefT) void refit_essential_kernel(const T *__restr
 }
 
 template <typename T>
-__global__ __launch_bounds__(kRefT) void refit_fundamental_kernel(const T *__restrict__ matches,
+__global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) void refit_fundamental_kernel(const T *__restrict__ matches,
                                                                   const uint8_t *__restrict__ mask, int N,
                                                                   T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
@@ -132,18 +126,17 @@ __global__ __launch_bounds__(kRefT) void refit_fundamental_kernel(const T *__res
   gram_accumulate<true, T>(mt, mk, N, mu, r1, r2, gram, red);
   if (threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
-  LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
-  for (int e = 0; e < 81; ++e) A[e] = gram[e];
-  jacobi_eig_lds<9>(A, V);
-  int best = 0;
-  double bv = INFINITY;
-  for (int i = 0; i < 9; ++i) {
-    const double ev = A[i * 9 + i];
-    if (ev < bv) { bv = ev; best = i; }
-  }
   double f[9];
+  {
+    double A[9][9], V[9][9];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) f[q] = V[q * 9 + best];
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) A[i][j] = gram[i * 9 + j];
+    jacobi_eig9_reg(A, V);
+    unsigned used = 0;
+    smallest_eigvec9(A, V, used, f);
+  }
   double G[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {

@@ -325,6 +325,81 @@ __device__ __forceinline__ void jacobi_eig_lds(const LaneWs &A, const LaneWs &V)
   }
 }
 
+// Cyclic Jacobi of a symmetric 9x9 matrix entirely in VGPRs (162 doubles; for kernels that run one wave per SIMD).
+// The (p,q) schedule is static, so nothing needs run-time indexing; used where a single wave would otherwise crawl
+// through LDS latency (K7 refit: one sample per block).  column(V, c) extraction is a 9-way select.
+__device__ __forceinline__ void jacobi_eig9_reg(double (&A)[9][9], double (&V)[9][9]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0, dg = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      dg += A[i][i] * A[i][i];
+#pragma unroll
+      for (int j = i + 1; j < 9; ++j) off += A[i][j] * A[i][j];
+    }
+    const bool done = !(off > 1e-34 * dg);
+    if (__all(done)) break;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < 9; ++q) {
+        const double apq = A[p][q];
+        double c = 1.0, s = 0.0;
+        if (fabs(apq) > 1e-300 && !done) {
+          const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+          const double t = dsign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          s = t * c;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+    }
+  }
+}
+
+// index of the smallest diagonal entry not yet in `used` (bit mask), and that eigenvector
+__device__ __forceinline__ int smallest_eigvec9(const double (&A)[9][9], const double (&V)[9][9], unsigned &used,
+                                                double (&out)[9]) {
+  int best = 0;
+  double bv = INFINITY;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const bool free_ = !((used >> i) & 1u);
+    if (free_ && A[i][i] < bv) { bv = A[i][i]; best = i; }
+  }
+  used |= 1u << best;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    double v = V[r][0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) v = (c == best) ? V[r][c] : v;
+    out[r] = v;
+  }
+  return best;
+}
+
 // symmetric 3x3 Jacobi in registers; eigenvalues in d[], eigenvectors = columns of V
 __device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3], double (&d)[3]) {
 #pragma unroll
