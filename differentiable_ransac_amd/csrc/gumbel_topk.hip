@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
   sm *= (mx == -INFINITY) ? T(0) : exp_t<T>(mx - wmx);
   sm = wave_sum(sm);
   const T lse = wmx + log_t<T>(sm);
+  const T inv_sm = T(1) / sm;   // y = exp(g - max) / sum: exact to rounding even when |g| is huge (lse alone is not)
 
   // ---------------- threshold: k-th largest lane maximum
   T v = lmax, thr = -INFINITY;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
     }
     if (win) {
       idx[row * a.k + pos] = ci;
-      y_sel[row * a.k + pos] = exp_t<T>(cv - lse);
+      y_sel[row * a.k + pos] = exp_t<T>(cv - wmx) * inv_sm;
       s_win[wv][pos] = ci;
     }
   } else {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
       int pos = 0;
       for (int r = 0; r < a.k; ++r) pos += won[r] < me;
       idx[row * a.k + pos] = me;
-      y_sel[row * a.k + pos] = exp_t<T>(mg - lse);
+      y_sel[row * a.k + pos] = exp_t<T>(mg - wmx) * inv_sm;
       s_win[wv][pos] = me;
     }
   }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
       for (int j = 0; j < 4; ++j) {
         const int n = 4 * q + j;
         if (n >= a.N) continue;
-        const T y = exp_t<T>(g[j] - lse);
+        const T y = exp_t<T>(g[j] - wmx) * inv_sm;
         bool sel = false;
 #pragma unroll
         for (int r = 0; r < kMaxK; ++r) sel = sel || (mine[r] == n);

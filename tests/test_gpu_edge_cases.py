@@ -1,0 +1,86 @@
+"""Ragged / tiny / extreme inputs through every kernel (the reference has no tests; these are the edge cases its code
+paths imply: empty tails, N not a multiple of the vector width, a single pair, a single hypothesis, huge logits)."""
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P,N,B", [(1, 5, 1), (3, 37, 5), (2, 1023, 33), (1, 2050, 7), (4, 16, 65)])
+def test_batched_pipeline_odd_sizes_match_oracle(dev, P, N, B):
+    from differentiable_ransac_amd import ops, synth
+    data = synth.batch_two_view(P, N, seed0=800 + N)
+    m, lg = data["matches"].to(dev), data["logits"].to(dev)
+    noise = synth.gumbel_noise((P, B, N), seed=N)
+    r = ops.gumbel_topk(lg, B, 5, 1.0, noise.to(dev), dense=True)
+    smp = ops.gather(m, r["idx"], r["y_sel"])
+    E, valid = ops.solve_nister5(smp)
+    flat, vflat = E.reshape(P, B * 10, 3, 3), valid.reshape(P, B * 10)
+    thr = torch.linspace(5e-4, 2e-3, P).to(dev)
+    sc, mk = ops.msac_score(m, flat, thr, True, vflat)
+    sc2, _ = ops.msac_score(m, flat, thr, False, vflat)
+    assert torch.allclose(sc, sc2, rtol=1e-6, atol=1e-6)
+    st = ops.RansacState(P, N, 5000, dev, torch.float32)
+    ops.ransac_update(st, m, flat, vflat, sc, thr, B, 5)
+    for p in range(P):
+        idx, ret, ys = O.gumbel_topk(data["logits"][p], noise[p], 1.0, 5)
+        assert torch.equal(r["idx"][p].cpu().long(), idx)
+        assert torch.equal(r["ret"][p].cpu() != 0, ret != 0)
+        Eo, ok, real = O.nister_5pt(O.gather_samples(data["matches"][p], ret).double())
+        n_hip, n_or = int(valid[p].sum()), int(real[ok].sum())
+        assert abs(n_hip - n_or) <= max(2, 0.02 * n_or)
+        so, mo = O.msac_score(data["matches"][p].double(), flat[p].cpu().double(), float(thr[p]))
+        v = vflat[p].cpu()
+        if v.any():
+            assert ((sc[p].cpu().double() - so).abs()[v] <= 1e-4 * so.abs().clamp(min=1)[v]).all()
+            assert (mk[p].cpu()[v] != mo[v]).float().mean() < 1e-3
+            best = int(torch.where(v, so, torch.full_like(so, -1)).argmax())
+            assert abs(float(st.best_score[p]) - float(so[best])) <= 1e-4 * max(1.0, float(so[best]))
+        assert (sc[p].cpu()[~v] == 0).all() and not mk[p].cpu()[~v].any()
+        assert int(st.iters[p]) == B
+
+
+def test_extreme_logits_and_all_points_selected(dev):
+    from differentiable_ransac_amd import ops
+    N, B = 8, 4
+    logits = torch.tensor([[1e4, -1e4, 50.0, 0.0, -3.0, 2.0, 1e4, 7.0]])
+    r = ops.gumbel_topk(logits.to(dev), B, 8, 1.0, None, seed=3, dense=True)      # k == N: every point is selected
+    assert torch.equal(r["idx"].cpu(), torch.arange(8, dtype=torch.int32).expand(1, B, 8))
+    assert torch.isfinite(r["lse"]).all() and torch.isfinite(r["y_soft"]).all()
+    assert (r["y_soft"].sum(-1) - 1).abs().max() < 1e-5
+    r = ops.gumbel_topk(logits.to(dev), B, 2, 1.0, None, seed=3)
+    assert set(r["idx"].cpu().flatten().tolist()) <= {0, 6}                        # the two 1e4 logits always win
+
+
+def test_wrong_device_dtype_and_shapes_raise(dev):
+    from differentiable_ransac_amd import ops
+    from differentiable_ransac_amd._lib import DransacError
+    m = torch.rand(1, 16, 4)
+    with pytest.raises(DransacError):
+        ops.msac_score(m, torch.rand(1, 3, 3, 3), 1e-3)                            # CPU tensors: no fallback
+    with pytest.raises(DransacError):
+        ops.msac_score(m.half().to(dev), torch.rand(1, 3, 3, 3).half().to(dev), 1e-3)   # f16 unsupported (Q15)
+    with pytest.raises(DransacError):
+        ops.gumbel_topk(torch.rand(1, 16).to(dev), 4, 9, 1.0)                      # k > 8
+    with pytest.raises(DransacError):
+        ops.solve_stewenius5(torch.rand(3, 6, 4).to(dev))
+
+
+def test_f64_end_to_end(dev):
+    """`-pr 2`: the f64 entry points through the batched driver (Q17)."""
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    P, N, B = 2, 300, 64
+    data = synth.batch_two_view(P, N, seed0=60, dtype=torch.float64)
+    noise = [synth.gumbel_noise((P, B, N), seed=5, dtype=torch.float64).to(dev)]
+    rn = BatchedRANSAC("nister", ransac_batch_size=B, threshold=0.75, max_iterations=B, refit=True)
+    out = rn(data["matches"].to(dev), data["logits"].to(dev), data["K1"].to(dev), data["K2"].to(dev), gumbels=noise)
+    assert out["model"].dtype == torch.float64
+    for p in range(P):
+        m, mask, score, it = O.ransac_test(data["matches"][p], data["logits"][p], [noise[0][p].cpu()], data["K1"][p],
+                                           data["K2"][p], "nister", max_iterations=B)
+        assert abs(float(out["score"][p]) - score) <= 1e-6 * max(1.0, score)
+        assert torch.equal(out["mask"][p].cpu(), mask)
+        assert (O.canonical(out["model"][p].cpu()) - O.canonical(m)).abs().max() < 1e-6
