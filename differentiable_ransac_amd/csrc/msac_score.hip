@@ -21,7 +21,11 @@
 // than the quarter-rate reciprocals it saves, because the VALID models nearly always have inliers somewhere in a wave;
 // model coefficients staged in LDS + in-order VGPR prefetch instead of scalar-cache loads: 231 vs 235 us (noise: the
 // scalar-load latency is already hidden by occupancy); unpacked v_fma_f32 instead of v_pk_fma_f32: 224 vs 177 us with the
-// masks off -- packing is worth 1.27x here.
+// masks off -- packing is worth 1.27x here; zero rows drip-fed between the evaluations instead of after them: 242 vs
+// 241 us (the cost is the store stream itself, not its burstiness).  Store-pattern micro-benchmark
+// (scratch/store_patterns.py): this row-after-row 1 KiB pattern streams zeros at 3.96 TB/s, a block flushing 16 rows as
+// one contiguous range at 5.5 TB/s; but staging 16-slot windows in LDS to flush them that way costs two block barriers
+// per window and un-overlaps the flush: 306 us.  The mask stream therefore keeps costing ~50 us on top of the VALU time.
 #include "dr_common.hpp"
 
 namespace dr {

@@ -46,3 +46,23 @@ for mode in ((True, True), (False, True), (True, False)):
         chk = (float(scores.nan_to_num().sum()), int(masks.sum()) if mode[0] else -1)
         t = sorted(res[v])
         print(f'masks={mode[0]} valid={mode[1]} variant {v}: median {t[len(t)//2]*1e3:.1f} us  min {t[0]*1e3:.1f} us  check {chk}')
+# store-only floor: all slots invalid -> the kernel only zero-fills the 655 MB mask tensor
+vz = torch.zeros_like(vflat)
+for v in variants:
+    lib = libs[v]
+    def run0():
+        lib.dr_msac_score_f32(ctypes.c_void_p(mt.data_ptr()), ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(vz.data_ptr()),
+                              ctypes.c_void_p(thr.data_ptr()), P, M, N, ctypes.c_void_p(scores.data_ptr()),
+                              ctypes.c_void_p(masks.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    run0(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20): run0()
+    b.record(); torch.cuda.synchronize()
+    t = a.elapsed_time(b) / 20
+    print(f'variant {v}: zero-fill only {t*1e3:.1f} us = {masks.numel()/t/1e9:.0f} GB/s')
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+masks.zero_(); torch.cuda.synchronize(); a.record()
+for _ in range(20): masks.zero_()
+b.record(); torch.cuda.synchronize(); t = a.elapsed_time(b) / 20
+print(f'torch memset of the mask tensor: {t*1e3:.1f} us = {masks.numel()/t/1e9:.0f} GB/s')
