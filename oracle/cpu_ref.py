@@ -17,6 +17,7 @@ taken as an explicit input -- of the reference functions on the hot path:
     K5   train-mode best-of-S selection       ransac.py:78-108
     K6   test-mode arg-max + adaptive stop    ransac.py:109-144, 202-215
     K7   final refit                          ransac.py:148-195
+    L    MatchLoss residual (8(f) rank 2)     loss.py:107-153, cv_utils.py:680-695
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
 The product package (differentiable_ransac_amd) never does: its ops fail loudly when
@@ -560,6 +561,22 @@ def ransac3d_train_batch(matches, logits, gumbels, tau: float = 1.0, flag: bool 
     model, R, t, scale, ok = rigid_svd(samples, flag=flag)
     res, mean_res, mask = rigid_squared_residual(matches[:, :3], matches[:, 3:], model[:, :3, :].transpose(-1, -2))
     return model[ok], res, mean_res, mask, idx
+
+
+def episym(x1, x2, F):
+    """batch_episym, cv_utils.py:680-695: x1, x2 [n,2], F [M,3,3] -> ys [M,n] (symmetric epipolar error)."""
+    one = torch.ones(x1.shape[0], 1, dtype=x1.dtype)
+    h1, h2 = torch.cat((x1, one), 1), torch.cat((x2, one), 1)
+    Fx1 = torch.einsum("mij,nj->mni", F, h1)
+    Ftx2 = torch.einsum("mji,nj->mni", F, h2)
+    r = (h2[None] * Fx1).sum(-1)
+    return r ** 2 * (1.0 / (Fx1[..., 0] ** 2 + Fx1[..., 1] ** 2 + 1e-15) + 1.0 / (Ftx2[..., 0] ** 2 + Ftx2[..., 1] ** 2 + 1e-15))
+
+
+def match_loss(models, matches, gt_mask):
+    """MatchLoss.forward for one pair given the GT-inlier mask (loss.py:137-153): mean of min(ys, 1)."""
+    ys = episym(matches[gt_mask, :2], matches[gt_mask, 2:], models)
+    return torch.clamp(ys, max=1.0).mean()
 
 
 # --------------------------------------------------------------------------- #

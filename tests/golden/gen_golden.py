@@ -30,6 +30,7 @@ from estimators.essential_matrix_estimator_stewenius import EssentialMatrixEstim
 from estimators.fundamental_matrix_estimator import FundamentalMatrixEstimatorNew  # noqa: E402
 from estimators.rigid_transformation_SVD_based_solver import RigidTransformationSVDBasedSolver  # noqa: E402
 from ransac import RANSAC, RANSAC3D  # noqa: E402
+from cv_utils import batch_episym  # noqa: E402  (8(f) rank 2: the residual inside MatchLoss, loss.py:107-153)
 
 from differentiable_ransac_amd import synth  # noqa: E402
 
@@ -192,6 +193,17 @@ def main():
     chosen = torch.cat([model[k] for k in sorted(model.keys())])
     save("ransac_train_f8_weighted", matches=pairFp["matches"], logits=pairFp["logits"], gumbels=torch.stack(draws),
          chosen=chosen)
+
+    # ---------------------------------------------------------------- MatchLoss residual (batch_episym, cv_utils.py:680-695)
+    pair = synth.two_view_pair(13, 200, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(14)
+    Fs = pair["gt_E"][None] + 0.05 * torch.randn(24, 3, 3, generator=gen, dtype=torch.float64)
+    x1 = pair["matches"][pair["inliers"], :2]
+    x2 = pair["matches"][pair["inliers"], 2:]
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        out[f"ys_{tag}"] = batch_episym(x1.to(dt).repeat(24, 1, 1), x2.to(dt).repeat(24, 1, 1), Fs.to(dt))
+    save("episym", matches=pair["matches"], inliers=pair["inliers"], models=Fs, **out)
 
     rp = synth.rigid_pair(9, 256)
     smp = GumbelSoftmaxSampler(32, 3, device="cpu", data_type=torch.float32)

@@ -231,3 +231,13 @@ def test_match_loss_kernel_vs_reference_formula(dev):
     g, gr = md.grad.cpu().double(), m64.grad
     assert (g[~keep] == 0).all()
     assert (g - gr).abs().max() <= 2e-4 * gr.abs().max()
+
+
+def test_match_loss_kernel_vs_reference_golden(dev):
+    """the fused residual kernel against the reference's own batch_episym output (tests/golden/episym.npz)"""
+    from differentiable_ransac_amd import ops
+    g = load_golden("episym")
+    m = g["matches"].float()[None].to(dev)
+    sums = ops.episym_sums(m, g["inliers"][None].to(dev), g["models"].float()[None].to(dev))
+    ref = torch.clamp(g["ys_f64"], max=1.0).sum(1)
+    assert ((sums[0].cpu().double() - ref).abs() / ref).max() < 1e-4

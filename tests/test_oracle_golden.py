@@ -211,3 +211,13 @@ def test_ransac3d_matches_reference():
     _close(torch.cat(models), g["models"], 2e-5)
     assert ((torch.cat(residuals) - g["residuals"]).abs() / g["residuals"].abs()).max() < 1e-4
     _close(torch.stack(means), g["mean_residuals"], 1e-5)
+
+
+def test_episym_matches_reference():
+    g = load_golden("episym")
+    for tag, dt, tol in (("f64", torch.float64, 1e-12), ("f32", torch.float32, 1e-4)):
+        m = g["matches"].to(dt)
+        ys = O.episym(m[g["inliers"], :2], m[g["inliers"], 2:], g["models"].to(dt))
+        ref = g[f"ys_{tag}"]
+        assert ys.shape == ref.shape
+        assert ((ys - ref).abs() / ref.abs().clamp(min=1e-12)).max() < tol
