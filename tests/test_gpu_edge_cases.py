@@ -66,6 +66,13 @@ def test_wrong_device_dtype_and_shapes_raise(dev):
         ops.gumbel_topk(torch.rand(1, 16).to(dev), 4, 9, 1.0)                      # k > 8
     with pytest.raises(DransacError):
         ops.solve_stewenius5(torch.rand(3, 6, 4).to(dev))
+    # empty inputs are rejected with DR_EINVAL (no kernel is launched), never a crash
+    with pytest.raises(DransacError, match="bad sizes"):
+        ops.msac_score(torch.rand(1, 16, 4).to(dev), torch.rand(1, 0, 3, 3).to(dev), 1e-3)
+    with pytest.raises(DransacError):
+        ops.solve_nister5(torch.rand(0, 5, 4).to(dev))
+    with pytest.raises(DransacError):
+        ops.gumbel_topk(torch.rand(1, 4).to(dev), 4, 5, 1.0)                       # k > N
 
 
 def test_f64_end_to_end(dev):
