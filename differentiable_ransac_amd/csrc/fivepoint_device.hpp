@@ -6,7 +6,6 @@
 namespace dr {
 
 constexpr int kFiveWs = 162;   // doubles of LDS per lane: B block (100) for the minimal path, A^T A + V (162) for n > 5
-constexpr int kStewWs = 212;   // Stewenius: 10x20, then Hessenberg 10x10 (0..99) + La Budde polynomials (100..209)
 
 // ---- null-space basis ---------------------------------------------------------------------------------
 // minimal: Householder QR of the 5x9 system (registers).  nb[t][0..8], t = 0..3

@@ -70,23 +70,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // (stewenius.py:64-72).  M v = lambda v with v ~ (x^2, xy, y^2, xz, yz, z^2, x, y, z, 1), lambda = -x.
 // Eigenvalues: Householder-Hessenberg + La Budde's recurrence give the characteristic polynomial, whose real
 // roots come from the same root finder; the eigenvector follows from rows 0-5 of (M - lambda I) v = 0 with
-// the structural rows substituted (unknowns y^2, yz, z^2, y, z).
+// the structural rows substituted (unknowns y^2, yz, z^2, y, z), solved in the least-squares sense by Householder
+// QR.  Everything after the constraint solve is statically indexed and lives in VGPRs; like the Nister kernel, two
+// lanes share one sample and each takes one half of the root search.
 template <typename T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_kernel(const T *__restrict__ samples, int Bt,
-                                                        T *__restrict__ models, uint8_t *__restrict__ valid) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_pair_kernel(
+    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
-  const int s = blockIdx.x * 64 + lane;
+  const int half = lane & 1;
+  const int s = blockIdx.x * 32 + (lane >> 1);
   const bool active = s < Bt;
   const int sc = active ? s : Bt - 1;
-  LaneWs w{lds + lane};
+  LaneWs w{lds + (lane >> 1), 32};
   double nb[4][9];
   fivepoint_basis_minimal<T>(samples + (size_t)sc * 20, nullptr, nb);
-  double e[3][3][4];
-  basis_to_entries(nb, e);
   double g[6][10];   // G rows (right block) needed by the action matrix: r in {0,1,2,4,5,7}
   bool ok;
   {
+    double e[3][3][4];
+    basis_to_entries(nb, e);
     double X[10][10];
     ok = constraints_reduce<GrevlexOrder, 0>(e, w, 2.0, X);
     const int src[6] = {0, 1, 2, 4, 5, 7};
@@ -95,105 +98,95 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int c = 0; c < 10; ++c) g[r][c] = X[src[r]][c];
   }
-  // H = action matrix in LDS (elements 0..99), reduce to upper Hessenberg by Householder similarity
-  LaneWs H{w.base};
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 10; ++c) H[r * 10 + c] = g[r][c];
-  for (int r = 6; r < 10; ++r)
-    for (int c = 0; c < 10; ++c) H[r * 10 + c] = 0.0;
-  H[6 * 10 + 0] = -1.0; H[7 * 10 + 1] = -1.0; H[8 * 10 + 3] = -1.0; H[9 * 10 + 6] = -1.0;
-  for (int k = 0; k < 8; ++k) {
-    double v[10];
-    double nrm2 = 0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      v[i] = (i > k) ? H[i * 10 + k] : 0.0;
-      nrm2 += v[i] * v[i];
-    }
-    double x0 = 0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) if (i == k + 1) x0 = v[i];
-    const double alpha = -dsign(sqrt(nrm2), x0);
-    const double v0 = x0 - alpha;
-    const double vtv = v0 * v0 + (nrm2 - x0 * x0);
-    const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) if (i == k + 1) v[i] = v0;
-    // H <- (I - beta v v^T) H (I - beta v v^T)
-    for (int c = 0; c < 10; ++c) {
-      double dot = 0;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) dot += v[i] * H[i * 10 + c];
-      dot *= beta;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) if (i > k) H[i * 10 + c] -= dot * v[i];
-    }
-    for (int r = 0; r < 10; ++r) {
-      double dot = 0;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) dot += H[r * 10 + i] * v[i];
-      dot *= beta;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) if (i > k) H[r * 10 + i] -= dot * v[i];
-    }
-  }
-  // La Budde: p_0 = 1, p_i(l) = (l - h_ii) p_{i-1} - sum_{m=1}^{i-1} h_{i-m,i} (prod_{j=i-m+1}^{i} h_{j,j-1}) p_{i-m-1}
-  // (1-based).  Coefficients ascending, P[i][0..i] stored in LDS elements 100 + i*11 ...
-  LaneWs P{w.base + 100 * 64};
-  for (int e2 = 0; e2 < 110; ++e2) P[e2] = 0.0;
-  P[0] = 1.0;  // p_0
-  for (int i = 1; i <= 9; ++i) {
-    // p_i for i = 1..9 kept in LDS; p_10 assembled in registers below
-    const double hii = H[(i - 1) * 10 + (i - 1)];
-    for (int t = 0; t <= i; ++t) {
-      const double up = (t > 0) ? P[(i - 1) * 11 + t - 1] : 0.0;
-      const double same = (t <= i - 1) ? P[(i - 1) * 11 + t] : 0.0;
-      P[i * 11 + t] = up - hii * same;
-    }
-    double prod = 1.0;
-    for (int m = 1; m <= i - 1; ++m) {
-      prod *= H[(i - m) * 10 + (i - m - 1)];  // h_{i-m+1, i-m} (1-based) = H[i-m][i-m-1] (0-based)
-      const double coef = H[(i - m - 1) * 10 + (i - 1)] * prod;  // h_{i-m, i}
-      for (int t = 0; t <= i - m - 1; ++t) P[i * 11 + t] -= coef * P[(i - m - 1) * 11 + t];
-    }
-  }
+  // characteristic polynomial of the action matrix
   double cs[11];
   {
-    const int i = 10;
-    const double hii = H[9 * 10 + 9];
+    double H[10][10];
 #pragma unroll
-    for (int t = 0; t <= 10; ++t) {
-      const double up = (t > 0) ? P[9 * 11 + t - 1] : 0.0;
-      const double same = (t <= 9) ? P[9 * 11 + t] : 0.0;
-      cs[t] = up - hii * same;
-    }
-    double prod = 1.0;
-    for (int m = 1; m <= i - 1; ++m) {
-      prod *= H[(i - m) * 10 + (i - m - 1)];
-      const double coef = H[(i - m - 1) * 10 + (i - 1)] * prod;
+    for (int r = 0; r < 10; ++r)
 #pragma unroll
-      for (int t = 0; t <= 10; ++t)
-        if (t <= i - m - 1) cs[t] -= coef * P[(i - m - 1) * 11 + t];
+      for (int c = 0; c < 10; ++c) H[r][c] = (r < 6) ? g[r][c] : 0.0;
+    H[6][0] = -1.0; H[7][1] = -1.0; H[8][3] = -1.0; H[9][6] = -1.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double v[10];
+      double nrm2 = 0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        v[i] = (i > k) ? H[i][k] : 0.0;
+        nrm2 += v[i] * v[i];
+      }
+      const double x0 = v[k + 1];
+      const double alpha = -dsign(sqrt(nrm2), x0);
+      const double v0 = x0 - alpha;
+      const double vtv = v0 * v0 + (nrm2 - x0 * x0);
+      const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+      v[k + 1] = v0;
+      // H <- (I - beta v v^T) H (I - beta v v^T)
+#pragma unroll
+      for (int c = 0; c < 10; ++c) {
+        double dot = 0;
+#pragma unroll
+        for (int i = k + 1; i < 10; ++i) dot += v[i] * H[i][c];
+        dot *= beta;
+#pragma unroll
+        for (int i = k + 1; i < 10; ++i) H[i][c] -= dot * v[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 10; ++r) {
+        double dot = 0;
+#pragma unroll
+        for (int i = k + 1; i < 10; ++i) dot += H[r][i] * v[i];
+        dot *= beta;
+#pragma unroll
+        for (int i = k + 1; i < 10; ++i) H[r][i] -= dot * v[i];
+      }
     }
+    // La Budde: p_0 = 1, p_i(l) = (l - h_ii) p_{i-1} - sum_{m=1}^{i-1} h_{i-m,i} (prod_{j=i-m+1}^{i} h_{j,j-1}) p_{i-m-1}
+    // (1-based indices), coefficients ascending: P[i][0..i]
+    double P[11][11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i)
+#pragma unroll
+      for (int t = 0; t < 11; ++t) P[i][t] = 0.0;
+    P[0][0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= 10; ++i) {
+      const double hii = H[i - 1][i - 1];
+#pragma unroll
+      for (int t = 0; t <= i; ++t) {
+        const double up = (t > 0) ? P[i - 1][t - 1] : 0.0;
+        const double same = (t <= i - 1) ? P[i - 1][t] : 0.0;
+        P[i][t] = up - hii * same;
+      }
+      double prod = 1.0;
+#pragma unroll
+      for (int m = 1; m <= i - 1; ++m) {
+        prod *= H[i - m][i - m - 1];
+        const double coef = H[i - m - 1][i - 1] * prod;
+#pragma unroll
+        for (int t = 0; t <= i - m - 1; ++t) P[i][t] -= coef * P[i - m - 1][t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t <= 10; ++t) cs[t] = P[10][t];
   }
   double roots[10];
   int nroots;
-  real_roots<10>(cs, roots, nroots);
+  real_roots_half<10>(cs, half != 0, roots, nroots);
   if (!ok) nroots = 0;
 
   T *mdl = models + (size_t)sc * 90;
   uint8_t *vld = valid + (size_t)sc * 10;
   int slot = 0;
-  LaneWs K{w.base};  // 6 x 6 augmented system, reuses the Hessenberg area
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     if (!__any(i < nroots)) continue;
     const bool has = i < nroots;
     const double lam = roots[i];
     const double l2 = lam * lam;
-    // unknown order u = (v2, v4, v5, v7, v8) ; column 5 = right-hand side (minus the constant term)
+    // unknown order u = (v2, v4, v5, v7, v8); column 5 = right-hand side (minus the constant term)
+    double K[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       double c2 = g[r][2], c4 = g[r][4], c5 = g[r][5];
@@ -206,45 +199,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       if (r == 3) c8 += l2;          // -lam * v3,  v3 = -lam v8
       if (r == 4) c4 -= lam;
       if (r == 5) c5 -= lam;
-      K[r * 6 + 0] = c2; K[r * 6 + 1] = c4; K[r * 6 + 2] = c5; K[r * 6 + 3] = c7; K[r * 6 + 4] = c8; K[r * 6 + 5] = -k0;
+      K[r][0] = c2; K[r][1] = c4; K[r][2] = c5; K[r][3] = c7; K[r][4] = c8; K[r][5] = -k0;
     }
-    // Gaussian elimination with partial pivoting over the 6 rows, 5 unknowns
+    // least squares of the consistent 6x5 system by Householder QR (no pivoting => static indexing)
     bool solvable = true;
-    for (int col = 0; col < 5; ++col) {
-      int piv = col;
-      double best = fabs(K[col * 6 + col]);
-      for (int r = col + 1; r < 6; ++r) {
-        const double vv = fabs(K[r * 6 + col]);
-        if (vv > best) { best = vv; piv = r; }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      double nrm2 = 0;
+#pragma unroll
+      for (int r = c; r < 6; ++r) nrm2 += K[r][c] * K[r][c];
+      const double nrm = sqrt(nrm2);
+      const double alpha = -dsign(nrm, K[c][c]);
+      const double v0 = K[c][c] - alpha;
+      const double vtv = v0 * v0 + (nrm2 - K[c][c] * K[c][c]);
+      const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+      if (!(nrm > 0)) solvable = false;
+      double v[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) v[r] = (r > c) ? K[r][c] : 0.0;
+      v[c] = v0;
+#pragma unroll
+      for (int cc = c + 1; cc < 6; ++cc) {
+        double dot = 0;
+#pragma unroll
+        for (int r = c; r < 6; ++r) dot += v[r] * K[r][cc];
+        dot *= beta;
+#pragma unroll
+        for (int r = c; r < 6; ++r) K[r][cc] -= dot * v[r];
       }
-      if (!(best > 0)) solvable = false;
-      for (int c = 0; c < 6; ++c) {
-        const double a = K[piv * 6 + c], b = K[col * 6 + c];
-        K[piv * 6 + c] = b;
-        K[col * 6 + c] = a;
-      }
-      const double inv = best > 0 ? 1.0 / K[col * 6 + col] : 0.0;
-      for (int r = col + 1; r < 6; ++r) {
-        const double f = K[r * 6 + col] * inv;
-        for (int c = col; c < 6; ++c) K[r * 6 + c] -= f * K[col * 6 + c];
-      }
+      K[c][c] = alpha;
     }
     double u[5];
 #pragma unroll
-    for (int col = 4; col >= 0; --col) {
-      double acc = K[col * 6 + 5];
+    for (int c = 4; c >= 0; --c) {
+      double acc = K[c][5];
 #pragma unroll
-      for (int c = 4; c > col; --c) acc -= K[col * 6 + c] * u[c];
-      u[col] = acc / K[col * 6 + col];
+      for (int cc = 4; cc > c; --cc) acc -= K[c][cc] * u[cc];
+      u[c] = acc / K[c][c];
     }
     const double x = -lam, y = u[3], z = u[4];
-    const bool good = finish_solution<T>(nb, x, y, z, has && solvable && is_finite(y) && is_finite(z), mdl + 9 * slot,
-                                         active);
-    if (good && active) vld[slot] = 1;
+    const int dst_slot = half ? 9 - slot : slot;
+    const bool good = finish_solution<T>(nb, x, y, z, has && solvable && is_finite(y) && is_finite(z) && slot < 10,
+                                         mdl + 9 * dst_slot, active);
+    if (good && active) vld[dst_slot] = 1;
     slot += good ? 1 : 0;
   }
-  if (active) {
-    for (int q = slot; q < 10; ++q) {
+  const int other = __shfl_xor(slot, 1, 64);
+  const int lo = half ? other : slot, hi = half ? slot : other;
+  if (active && half == 0) {
+    for (int q = min(lo, 10 - hi); q < 10 - hi; ++q) {
       write_identity<T>(mdl + 9 * q);
       vld[q] = 0;
     }
@@ -275,15 +278,9 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
 
 template <typename T>
 int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st) {
-  const size_t smem = sizeof(double) * kStewWs * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&stewenius5_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((stewenius5_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, Bt, models, valid);
-  return check_launch("stewenius5_kernel");
+  const size_t smem = sizeof(double) * 100 * 32;   // the right 10x10 block of 32 samples
+  hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, Bt, models, valid);
+  return check_launch("stewenius5_pair_kernel");
 }
 
 }  // namespace dr
