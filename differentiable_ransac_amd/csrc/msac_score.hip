@@ -26,6 +26,15 @@
 // (scratch/store_patterns.py): this row-after-row 1 KiB pattern streams zeros at 3.96 TB/s, a block flushing 16 rows as
 // one contiguous range at 5.5 TB/s; but staging 16-slot windows in LDS to flush them that way costs two block barriers
 // per window and un-overlaps the flush: 306 us.  The mask stream therefore keeps costing ~50 us on top of the VALU time.
+// Second pass (same harness): soft score accumulated as min_i32(bits(sv), 0) instead of fmaxf(-sv, 0) (the compiler
+// canonicalises fmaxf's operand: two instructions per point): 237 -> 223 us with masks, 180 -> 163 us without.  One
+// reciprocal per two points (rcp(jj0*jj1) * jj1, * jj0): 221 us -- v_rcp_f32 measures 7 clk per wave and overlaps the FMA
+// pipe (scratch/valu_rate.py), not the 16 clk of a quarter-rate op, so there is little to save; dropped (a degenerate
+// point would poison its neighbour).  A wave-per-row kernel (32 points per lane, 8-row windows assembled in wave-private
+// LDS and flushed as one line-aligned contiguous range: 5.4 TB/s as a pure store pattern) runs at 2 waves/SIMD and loses:
+// 278 us.  Mask rows padded to a 2048-byte stride (every row store a whole number of lines): 226 us, no gain -- the row
+// alignment is not what the stream costs.  Decomposition at 224 us: arithmetic alone 165 us, + packing/storing the valid
+// rows 26 us, + zero rows of the invalid slots 33 us.
 #include "dr_common.hpp"
 
 namespace dr {
@@ -308,14 +317,14 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
           rc[0] = __builtin_amdgcn_rcpf(jj[0]);
           rc[1] = __builtin_amdgcn_rcpf(jj[1]);
           const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);   // s = d2/thr2 - 1
-          v2f mx;
-          mx[0] = fmaxf(-sv[0], 0.f);
-          mx[1] = fmaxf(-sv[1], 0.f);
-          acc = mx * w[j] + acc;
           sb[2 * j] = __float_as_uint(sv[0]);
           sb[2 * j + 1] = __float_as_uint(sv[1]);
+          v2f mn;   // min(sv, 0) by one integer instruction each (see msac_eval16); acc holds the negated sum
+          mn[0] = __int_as_float(min((int)sb[2 * j], 0));
+          mn[1] = __int_as_float(min((int)sb[2 * j + 1], 0));
+          acc = mn * w[j] + acc;
         }
-        float a = acc[0] + acc[1];
+        float a = -(acc[0] + acc[1]);
         if (write_masks && nvalid > 0) {
           // top bytes of four s values -> one dword, then sign bit -> bit 0 of each byte
           const uint32_t t01 = __builtin_amdgcn_perm(sb[1], sb[0], 0x0c0c0703u);  // bytes: [s0.b3, s1.b3, 0, 0]
@@ -346,6 +355,44 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
     if (use_atomic) atomicAdd(dst, v);
     else *dst = v;
   }
+}
+
+// Sixteen points of one lane against one model: mask bytes (uint4) + the lane's NEGATED soft-score partial.
+//   sv = d2/thr2 - 1 (inlier <=> sv < 0); the soft score max(-sv, 0) is accumulated as min(sv, 0) with ONE integer
+//   instruction per point: for IEEE bit patterns min_i32(bits(sv), 0) is sv when the sign bit is set and +0 otherwise
+//   (fmaxf costs two -- the compiler has to canonicalise its operand first); a 0/0 point (sv = +NaN) contributes 0.
+__device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)[8], const v2f (&x2)[8], const v2f (&y2)[8],
+                                            const float (&m)[9], float inv_thr2, bool finite, v2f &nacc) {
+  uint32_t sb[16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
+    const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
+    const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
+    const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
+    const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
+    const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
+    const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
+    const v2f rr = r * r;
+    v2f rc;
+    rc[0] = __builtin_amdgcn_rcpf(jj[0]);
+    rc[1] = __builtin_amdgcn_rcpf(jj[1]);
+    const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);
+    sb[2 * j] = __float_as_uint(sv[0]);
+    sb[2 * j + 1] = __float_as_uint(sv[1]);
+    v2f mn;
+    mn[0] = __int_as_float(min((int)sb[2 * j], 0));
+    mn[1] = __int_as_float(min((int)sb[2 * j + 1], 0));
+    nacc = nacc + mn;
+  }
+  uint32_t wq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t lo2 = __builtin_amdgcn_perm(sb[4 * g + 1], sb[4 * g], 0x0c0c0703u);
+    const uint32_t hi2 = __builtin_amdgcn_perm(sb[4 * g + 3], sb[4 * g + 2], 0x07030c0cu);
+    wq[g] = finite ? (((lo2 | hi2) >> 7) & 0x01010101u) : 0u;
+  }
+  return make_uint4(wq[0], wq[1], wq[2], wq[3]);
 }
 
 // ---- f32 fast path, 16 points per lane ---------------------------------------------------------------------------
@@ -393,7 +440,6 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
       if (have) v = reinterpret_cast<const float4 *>(mt)[n0 + j];
       x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
     }
-    const float wl = have ? 1.f : 0.f;
 
 #pragma unroll 1
     for (int wd = 0; wd < kTile / 32; ++wd) {
@@ -420,40 +466,10 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
 #pragma unroll
         for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
         const bool finite = ex != 0x7f800000u;
-        v2f acc = splat(0.f);
-        uint32_t sb[kP16];
-#pragma unroll
-        for (int j = 0; j < kP16 / 2; ++j) {
-          const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
-          const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
-          const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
-          const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
-          const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
-          const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
-          const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
-          const v2f rr = r * r;
-          v2f rc;
-          rc[0] = __builtin_amdgcn_rcpf(jj[0]);
-          rc[1] = __builtin_amdgcn_rcpf(jj[1]);
-          const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);
-          v2f mx;
-          mx[0] = fmaxf(-sv[0], 0.f);
-          mx[1] = fmaxf(-sv[1], 0.f);
-          acc = acc + mx;
-          sb[2 * j] = __float_as_uint(sv[0]);
-          sb[2 * j + 1] = __float_as_uint(sv[1]);
-        }
-        float a = (acc[0] + acc[1]) * wl;
-        if (write_masks && have) {
-          uint32_t wq[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const uint32_t lo2 = __builtin_amdgcn_perm(sb[4 * g + 1], sb[4 * g], 0x0c0c0703u);
-            const uint32_t hi2 = __builtin_amdgcn_perm(sb[4 * g + 3], sb[4 * g + 2], 0x07030c0cu);
-            wq[g] = finite ? (((lo2 | hi2) >> 7) & 0x01010101u) : 0u;
-          }
-          *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + cur) * N + n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
-        }
+        v2f nacc = splat(0.f);
+        const uint4 q = msac_eval16(x1, y1, x2, y2, m, inv_thr2, finite, nacc);
+        float a = have ? -(nacc[0] + nacc[1]) : 0.f;
+        if (write_masks && have) *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + cur) * N + n0) = q;
         a = wave_sum(a);
         if (lane == 0) part[wv][cur] += finite ? a : NAN;
         if (!more) break;
@@ -676,15 +692,15 @@ extern "C" {
 
 int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
                       int M, int N, float *scores, uint8_t *masks, void *stream) {
-  DR_REQUIRE(matches && models && thr && scores, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && thr && scores, "null pointer");
   return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
 }
 
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,
                       int M, int N, double *scores, uint8_t *masks, void *stream) {
-  DR_REQUIRE(matches && models && thr && scores, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && thr && scores, "null pointer");
   return dr::msac_score_launch<double>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
 }
 

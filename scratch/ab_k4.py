@@ -8,7 +8,7 @@ variants = [int(a) for a in args] or [0]
 if '--build' in sys.argv:
     for v in variants:
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-                               '-ffp-contract=fast', f'-DDR_K4_VARIANT={v}', *(['-fno-slp-vectorize'] if v == 9 else []), '-o', f'scratch/libk4_v{v}.so',
+                               '-ffp-contract=fast', f'-DDR_K4_VARIANT={v % 100}', f'-DDR_K4_DBG={v // 100}', *(['-fno-slp-vectorize'] if v == 9 else []), '-o', f'scratch/libk4_v{v}.so',
                                'differentiable_ransac_amd/csrc/msac_score.hip', 'differentiable_ransac_amd/csrc/dr_core.hip'])
     sys.exit(0)
 import torch
@@ -46,6 +46,25 @@ for mode in ((True, True), (False, True), (True, False)):
         chk = (float(scores.nan_to_num().sum()), int(masks.sum()) if mode[0] else -1)
         t = sorted(res[v])
         print(f'masks={mode[0]} valid={mode[1]} variant {v}: median {t[len(t)//2]*1e3:.1f} us  min {t[0]*1e3:.1f} us  check {chk}')
+# padded mask rows (stride 2048): every row store is a whole number of 128-byte lines
+mp = torch.empty(P, M, 2048, device=dev, dtype=torch.uint8)
+for v in variants:
+    lib = libs[v]
+    if not hasattr(lib, 'dr_msac_score_strided_f32'): continue
+    def runs():
+        return lib.dr_msac_score_strided_f32(ctypes.c_void_p(mt.data_ptr()), ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(vflat.data_ptr()),
+                              ctypes.c_void_p(thr.data_ptr()), P, M, N, ctypes.c_void_p(scores.data_ptr()),
+                              ctypes.c_void_p(mp.data_ptr()), 2048, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert runs() == 0; torch.cuda.synchronize()
+    ts = []
+    for rep in range(12):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5): runs()
+        b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / 5)
+    ts.sort()
+    print(f'variant {v}: stride-2048 masks median {ts[6]*1e3:.1f} us min {ts[0]*1e3:.1f} us check {(float(scores.nan_to_num().sum()), int(mp[..., :N].sum()), int(mp[..., N:].sum()))}')
 # store-only floor: all slots invalid -> the kernel only zero-fills the 655 MB mask tensor
 vz = torch.zeros_like(vflat)
 for v in variants:
