@@ -48,9 +48,10 @@ def parse():
     ap.add_argument("--extras", action="store_true",
                     help="after the official timed region also measure (a) two-stream overlap of consecutive batches and "
                          "(b) the step followed by the final refit; off by default so that a profiler sees only the official loop")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the steps are issued on round-robin: consecutive batches overlap (the latency-bound "
-                         "sampler/solver of batch i+1 runs under the throughput-bound scoring of batch i)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the K steps are issued on round-robin (default 2: two batches in flight, the "
+                         "latency-bound sampler/solver of batch i+1 runs under the VALU-bound scoring of batch i); "
+                         "1 = strictly one kernel at a time")
     return ap.parse_args()
 
 
@@ -198,24 +199,25 @@ def main():
     from differentiable_ransac_amd import sharding
     job_hyps_per_s, elapsed = sharding.job_throughput(P * B * args.steps, elapsed, dist, dev)
 
-    # informational second region: the same K steps issued round-robin on two streams, so that the latency-bound
-    # sampler/solver of batch i+1 overlaps the scoring of batch i (a serving loop would do this; it is not the headline
-    # number because it blurs the per-kernel roofline attribution)
+    # informational second region (--extras): the same K steps with the other issue policy -- strictly serial on one
+    # stream when the official region ran two batches in flight, and vice versa
     overlap = None
-    if args.extras and len(streams) == 1 and world == 1:
-        s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        keep = [None, None]
-        for i in range(4):                       # warm the per-stream allocator pools
-            with torch.cuda.stream(s2[i % 2]):
-                keep[i % 2] = step()
+    if args.extras and world == 1:
+        n2 = 1 if len(streams) > 1 else 2
+        s2 = [torch.cuda.Stream(device=dev) for _ in range(n2)]
+        keep = [None] * n2
+        for i in range(2 * n2):                  # warm the per-stream allocator pools
+            with torch.cuda.stream(s2[i % n2]):
+                keep[i % n2] = step()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            with torch.cuda.stream(s2[i % 2]):
-                keep[i % 2] = step()
+            with torch.cuda.stream(s2[i % n2]):
+                keep[i % n2] = step()
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t1
-        overlap = {"streams": 2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
+        overlap = {"streams": n2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
+        del keep
 
     if args.mode == "train":
         if rank == 0:
@@ -246,6 +248,18 @@ def main():
         with_refit = {"value": P * B * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3}
 
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    # the same launch with nothing else on the GPU (one stream, a few extra untimed steps): with two batches in flight
+    # the scoring kernel shares the CUs with the next batch's sampler/solver, so its wall duration above is longer than
+    # its own cost; both are reported
+    iso_ms = k4_ms
+    if len(streams) > 1:
+        n_iso = min(10, args.steps)
+        for i in range(n_iso):
+            state["i"] = i
+            step()
+        torch.cuda.synchronize()
+        state["i"] = -1
+        iso_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(n_iso)) / n_iso
     bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
     # executed flops: only the slots the solver marked valid are evaluated
     with torch.no_grad():
@@ -287,17 +301,21 @@ def main():
                                f"Philox), MSAC scoring with masks, test mode, {P} pairs/GPU/step",
                    "pairs_per_gpu": P, "points": N, "hypotheses_per_pair": B, "models_per_pair": M,
                    "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective",
-                   "streams": len(streams)},
+                   "streams": len(streams),
+                   "issue": f"{len(streams)} batch(es) in flight, round-robin over {len(streams)} HIP stream(s)"},
         "pairs_per_s": world * P * args.steps / elapsed,
         "roofline": {"bound": "hbm", "kernel": "msac_score_kernel_f32_fast16", "valid_slot_fraction": valid_frac, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "isolated": {"avg_launch_ms": iso_ms, "achieved": bytes_per_launch / (iso_ms * 1e-3) / 1e9,
+                                  "frac": bytes_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "same launch, one stream, nothing else resident"},
                      "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                     "valu_tflops": flops_per_launch / (k4_ms * 1e-3) / 1e12,
-                     "valu_frac_of_157.3": flops_per_launch / (k4_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+                     "valu_tflops": flops_per_launch / (iso_ms * 1e-3) / 1e12,
+                     "valu_frac_of_157.3": flops_per_launch / (iso_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
         "check": {"mean_inlier_fraction_of_best_model": inl_frac},
-        "overlap": overlap,
+        "other_issue_policy": overlap,
         "with_final_refit": with_refit,
     }
     if args.profile_kernels and rank == 0:

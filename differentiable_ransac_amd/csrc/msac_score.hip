@@ -646,6 +646,35 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
   if (tid == 0) iters[p] = it0 + B;
 }
 
+// ---- K6 state set-up: the normalised threshold of ransac.py:49-53 and the per-pair test-mode state, one launch ----
+// (as torch ops this is ~17 tiny kernels per call: 75 us of the 0.49 ms benchmark step)
+template <typename T>
+__global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ K1, const T *__restrict__ K2, int k_stride,
+                                                         T threshold, int N, int max_iterations, T *__restrict__ thr,
+                                                         T *__restrict__ best_score, T *__restrict__ best_model,
+                                                         uint8_t *__restrict__ best_mask,
+                                                         int32_t *__restrict__ best_inliers, int32_t *__restrict__ iters,
+                                                         double *__restrict__ max_iters) {
+  const int p = blockIdx.x;
+  if (threadIdx.x == 0) {
+    T th = threshold;
+    if (K1) {
+      const T *a = K1 + (size_t)p * k_stride, *b = K2 + (size_t)p * k_stride;
+      // (K1[0,0] + K1[1,1] + K1[0,0] + K2[1,1]) / 4 -- K1[0,0] twice, K2[0,0] never (ransac.py:52);
+      // threshold / f evaluated as torch does for scalar / tensor: reciprocal, then multiply
+      const T f = (((a[0] + a[4]) + a[0]) + b[4]) / T(4);
+      th = (T(1) / f) * threshold;
+    }
+    thr[p] = th;
+    best_score[p] = T(0);
+    best_inliers[p] = 0;
+    iters[p] = 0;
+    max_iters[p] = (double)max_iterations;
+  }
+  if (threadIdx.x < 9) best_model[(size_t)p * 9 + threadIdx.x] = (threadIdx.x % 4 == 0) ? T(1) : T(0);
+  for (int n = threadIdx.x; n < N; n += blockDim.x) best_mask[(size_t)p * N + n] = 0;
+}
+
 template <typename T>
 int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, const T *thr, int P, int M, int N,
                       T *scores, uint8_t *masks, hipStream_t st) {
@@ -712,6 +741,30 @@ int dr_select_best_f32(const float *matches, const float *models, const uint8_t 
   hipLaunchKernelGGL((dr::select_best_kernel<float>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches,
                      models, valid, scores, thr, M, N, best_idx, best_score, best_model, best_mask, inliers);
   return dr::check_launch("select_best_kernel");
+}
+
+int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,
+                       int max_iterations, float *thr, float *best_score, float *best_model, uint8_t *best_mask,
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+  DR_REQUIRE(P > 0 && N > 0 && (k_stride == 0 || k_stride == 9), "bad sizes");
+  DR_REQUIRE(thr && best_score && best_model && best_mask && best_inliers && iters && max_iters && (!K1 == !K2),
+             "null pointer");
+  hipLaunchKernelGGL((dr::ransac_init_kernel<float>), dim3(P), dim3(256), 0, (hipStream_t)stream, K1, K2, k_stride,
+                     (float)threshold, N, max_iterations, thr, best_score, best_model, best_mask, best_inliers, iters,
+                     max_iters);
+  return dr::check_launch("ransac_init_kernel");
+}
+
+int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double threshold, int P, int N,
+                       int max_iterations, double *thr, double *best_score, double *best_model, uint8_t *best_mask,
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+  DR_REQUIRE(P > 0 && N > 0 && (k_stride == 0 || k_stride == 9), "bad sizes");
+  DR_REQUIRE(thr && best_score && best_model && best_mask && best_inliers && iters && max_iters && (!K1 == !K2),
+             "null pointer");
+  hipLaunchKernelGGL((dr::ransac_init_kernel<double>), dim3(P), dim3(256), 0, (hipStream_t)stream, K1, K2, k_stride,
+                     threshold, N, max_iterations, thr, best_score, best_model, best_mask, best_inliers, iters,
+                     max_iters);
+  return dr::check_launch("ransac_init_kernel");
 }
 
 int dr_ransac_update_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,

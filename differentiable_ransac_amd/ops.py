@@ -61,14 +61,37 @@ def select_best(matches: torch.Tensor, models: torch.Tensor, scores: torch.Tenso
 class RansacState:
     """Per-pair test-mode state kept on the device (best score / model / mask / inlier count, iteration counters)."""
 
-    def __init__(self, P: int, N: int, max_iterations: int, device, dtype):
-        self.best_score = torch.zeros(P, device=device, dtype=dtype)
-        self.best_model = torch.eye(3, device=device, dtype=dtype).repeat(P, 1, 1)
-        self.best_mask = torch.zeros(P, N, device=device, dtype=torch.bool)
-        self.best_inliers = torch.zeros(P, device=device, dtype=torch.int32)
-        self.iters = torch.zeros(P, device=device, dtype=torch.int32)
-        self.max_iters = torch.full((P,), float(max_iterations), device=device, dtype=torch.float64)
+    def __init__(self, P: int, N: int, max_iterations: int, device, dtype, _init: bool = True):
+        alloc = torch.zeros if _init else torch.empty
+        self.best_score = alloc(P, device=device, dtype=dtype)
+        self.best_model = (torch.eye(3, device=device, dtype=dtype).repeat(P, 1, 1) if _init
+                           else torch.empty(P, 3, 3, device=device, dtype=dtype))
+        self.best_mask = alloc(P, N, device=device, dtype=torch.bool)
+        self.best_inliers = alloc(P, device=device, dtype=torch.int32)
+        self.iters = alloc(P, device=device, dtype=torch.int32)
+        self.max_iters = (torch.full((P,), float(max_iterations), device=device, dtype=torch.float64) if _init
+                          else torch.empty(P, device=device, dtype=torch.float64))
         self.max_iterations = max_iterations
+
+
+def ransac_init(P: int, N: int, max_iterations: int, threshold: float, K1: Optional[torch.Tensor],
+                K2: Optional[torch.Tensor], device, dtype) -> Tuple[RansacState, torch.Tensor]:
+    """dr_ransac_init: the per-pair state and the threshold normalised as ransac.py:49-53 (K1/K2 [3,3] or [P,3,3];
+    None = threshold used as is), in ONE launch.  Returns (state, thr [P])."""
+    st = RansacState(P, N, max_iterations, device, dtype, _init=False)
+    thr = torch.empty(P, device=device, dtype=dtype)
+    k_stride = 0
+    if K1 is not None:
+        K1 = K1.to(device=device, dtype=dtype).contiguous()
+        K2 = K2.to(device=device, dtype=dtype).contiguous()
+        if K1.dim() == 3 and K1.shape[0] != 1:
+            if K1.shape[0] != P or K2.shape != K1.shape:
+                raise ValueError("K1/K2 must be [3,3] or [P,3,3]")
+            k_stride = 9
+    L.call(f"dr_ransac_init_{L.suffix(dtype)}", ptr(K1), ptr(K2), c_int(k_stride), L.c_double(float(threshold)),
+           c_int(P), c_int(N), c_int(max_iterations), ptr(thr), ptr(st.best_score), ptr(st.best_model),
+           ptr(st.best_mask), ptr(st.best_inliers), ptr(st.iters), ptr(st.max_iters), stream())
+    return st, thr
 
 
 def ransac_update(state: RansacState, matches, models, valid, scores, thr, B: int, k: int, confidence: float = 0.999,

@@ -252,11 +252,6 @@ class BatchedRANSAC(object):
     def __call__(self, matches, logits, K1=None, K2=None, gt_model=None, gumbels=None):
         P, N, _ = matches.shape
         dev, dt = matches.device, matches.dtype
-        if K1 is not None and not self.fmat:
-            thr = normalized_threshold(self.threshold, K1, K2, False).to(dt).reshape(-1)
-            thr = thr.expand(P).contiguous() if thr.numel() == 1 else thr.contiguous()
-        else:
-            thr = torch.full((P,), float(self.threshold), device=dev, dtype=dt)
         rounds = max(1, math.ceil(self.max_iterations / self.B))
         if self.train:
             out = []
@@ -273,7 +268,10 @@ class BatchedRANSAC(object):
             return torch.cat([c for c, _ in out], dim=1), torch.cat([k for _, k in out], dim=1)
 
         with torch.no_grad():
-            st = ops.RansacState(P, N, self.max_iterations, dev, dt)
+            # threshold normalisation (ransac.py:49-53) + per-pair state in one launch
+            use_K = K1 is not None and not self.fmat
+            st, thr = ops.ransac_init(P, N, self.max_iterations, self.threshold, K1 if use_K else None,
+                                      K2 if use_K else None, dev, dt)
             all_masks = None
             matches = matches.contiguous()
             # The essential-matrix refit candidate (Nister on ALL points, ransac.py:157-165) depends on the matches only:
@@ -302,7 +300,7 @@ class BatchedRANSAC(object):
                 if r + 1 < rounds and not bool((st.iters.double() < st.max_iters).any()):
                     break
             best_score, best_model, best_mask, best_inl, iters = (st.best_score, st.best_model, st.best_mask,
-                                                                  st.best_inliers, st.iters.long())
+                                                                  st.best_inliers, st.iters)
             if self.refit:
                 if self.fmat:
                     F, fvalid = ops.refit_fundamental(matches, best_mask)   # LSQ on the inliers of the best mask

@@ -185,6 +185,18 @@ int dr_select_best_f64(const double *matches, const double *models, const uint8_
                        const double *thr, int P, int M, int N, int32_t *best_idx, double *best_score,
                        double *best_model, uint8_t *best_mask, int32_t *inliers, void *stream);
 
+/* K6 set-up: threshold normalisation of ransac.py:49-53 and the initial per-pair state, one launch.
+ *   K1, K2: calibration matrices, [3,3] shared by all pairs (k_stride 0) or [P,3,3] (k_stride 9), or both NULL
+ *   (fundamental-matrix mode / threshold already normalised: thr[p] = threshold).  Otherwise
+ *   thr[p] = threshold / ((K1[0,0] + K1[1,1] + K1[0,0] + K2[1,1]) / 4)  -- sic, ransac.py:52.
+ *   State: best_score = 0, best_model = eye(3), best_mask = 0, best_inliers = 0, iters = 0, max_iters = max_iterations. */
+int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,
+                       int max_iterations, float *thr, float *best_score, float *best_model, uint8_t *best_mask,
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double threshold, int P, int N,
+                       int max_iterations, double *thr, double *best_score, double *best_model, uint8_t *best_mask,
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+
 /* K6 (batched, state on the device)  RANSAC.__call__ ransac.py:109-144 + adaptive_iteration_number :202-215.
  *   For every pair p with iters[p] < max_iters[p] (the others have terminated and are left untouched):
  *     b = first arg-max of scores[p] over valid, non-NaN models;
@@ -192,7 +204,7 @@ int dr_select_best_f64(const double *matches, const double *models, const uint8_
  *         best_inliers <- model b (mask recomputed), max_iters[p] = min(max_iterations,
  *         log10(1-confidence) / log10(1 - (inliers/N)^k + eps))   (computed in f64);
  *     iters[p] += B.
- *   The caller initialises best_score = 0, iters = 0, max_iters = max_iterations. */
+ *   The caller initialises best_score = 0, iters = 0, max_iters = max_iterations (dr_ransac_init does). */
 int dr_ransac_update_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
                          const float *thr, int P, int M, int N, int B, int k, double confidence, double eps,
                          int max_iterations, float *best_score, float *best_model, uint8_t *best_mask,
