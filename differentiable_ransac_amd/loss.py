@@ -1,4 +1,6 @@
-"""MatchLoss -- the clamped symmetric-epipolar training loss of the reference (loss.py:107-153), on the fused kernel
+"""The two training losses that follow the hot path: MatchLoss and PoseLoss.
+
+MatchLoss -- the clamped symmetric-epipolar training loss of the reference (loss.py:107-153), on the fused kernel
 `dr_episym_fwd/bwd`.
 
 The reference obtains the ground-truth inlier mask from `cv2.recoverPose` (cheirality of the triangulated points);
@@ -24,3 +26,31 @@ class MatchLoss(object):
         return per_pair.mean()
 
     __call__ = forward
+
+
+class PoseLoss(object):
+    """PoseLoss (loss.py:11-68), essential-matrix branch with the Horn decomposition (`svd=False`, what train.py:82-93
+    passes): per pair the mean over the pair's models of (err_R + err_t) / 2 in degrees, then the mean over pairs.  One
+    launch (`dr_pose_error_fwd`) instead of a Python loop over models with four cv2.triangulatePoints calls each."""
+
+    def __init__(self, fmat=False):
+        if fmat:
+            raise NotImplementedError("PoseLoss: map F to E = K2^T F K1 and normalise the points by K first (loss.py:36-49)")
+        self.fmat = fmat
+
+    def forward_average(self, estimated_models, pts1, pts2, gt_R, gt_t, keep=None, svd=False):
+        """estimated_models [P,M,3,3]; pts1, pts2 [P,N,2] normalised image points; gt_R [P,3,3]; gt_t [P,3];
+        keep [P,M] bool (models to average over, e.g. the solver's validity flags; None = all) -> scalar loss."""
+        if svd:
+            raise NotImplementedError("PoseLoss: only the Horn decomposition (svd=False) is implemented")
+        matches = torch.cat((pts1, pts2), dim=-1)
+        err_R, err_t, _, _ = ops.pose_error(matches, estimated_models, gt_R, gt_t)
+        per_model = (err_R + err_t) / 2
+        if keep is not None:
+            k = keep.to(per_model.dtype)
+            per_pair = (per_model * k).sum(1) / k.sum(1).clamp(min=1.0)
+        else:
+            per_pair = per_model.mean(1)
+        return per_pair.mean()
+
+    __call__ = forward_average

@@ -533,3 +533,49 @@ def episym_sums(matches, mask, models, valid=None):
     if matches.dtype != torch.float32:
         raise L.DransacError("episym_sums is implemented for f32")
     return _EpisymSums.apply(matches, mask, models.reshape(models.shape[0], -1, 3, 3), valid)
+
+
+# ------------------------------------------------------------------------------------------ PoseLoss pose error (8(f) rank 3)
+class _PoseError(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, matches, models, gt_R, gt_t, distance_threshold, want_votes):
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        dev, dt = matches.device, matches.dtype
+        sfx = L.suffix(dt)
+        matches, models = matches.contiguous(), models.contiguous()
+        gt_R, gt_t = gt_R.to(dt).contiguous(), gt_t.to(dt).contiguous()
+        err_R = torch.empty((P, M), device=dev, dtype=dt)
+        err_t = torch.empty((P, M), device=dev, dtype=dt)
+        which = torch.empty((P, M), device=dev, dtype=torch.int32)
+        votes = torch.empty((P, M, 4), device=dev, dtype=torch.int32) if want_votes else None
+        L.call(f"dr_pose_error_fwd_{sfx}", ptr(matches), ptr(models), ptr(gt_R), ptr(gt_t), c_int(P), c_int(M), c_int(N),
+               L.c_double(float(distance_threshold)), ptr(err_R), ptr(err_t), ptr(which), ptr(votes), stream())
+        ctx.save_for_backward(models, gt_R, gt_t, which)
+        ctx.mark_non_differentiable(which)
+        if votes is not None:
+            ctx.mark_non_differentiable(votes)
+        return err_R, err_t, which, votes
+
+    @staticmethod
+    def backward(ctx, g_R, g_t, _gw, _gv):
+        models, gt_R, gt_t, which = ctx.saved_tensors
+        P, M = which.shape
+        gm = torch.empty_like(models)
+        zero = None
+        if g_R is None or g_t is None:
+            zero = torch.zeros((P, M), device=models.device, dtype=models.dtype)
+        g_R = zero if g_R is None else g_R.contiguous()
+        g_t = zero if g_t is None else g_t.contiguous()
+        L.call(f"dr_pose_error_bwd_{L.suffix(models.dtype)}", ptr(models), ptr(gt_R), ptr(gt_t), ptr(which), ptr(g_R),
+               ptr(g_t), c_int(P), c_int(M), ptr(gm), stream())
+        return None, gm, None, None, None, None
+
+
+def pose_error(matches, models, gt_R, gt_t, distance_threshold: float = 50.0, want_votes: bool = False):
+    """eval_essential_matrix(svd=False) (cv_utils.py:503-525) for all models of all pairs: matches [P,N,4] normalised,
+    models [P,M,3,3], gt_R [P,3,3], gt_t [P,3] -> err_R, err_t [P,M] in degrees (differentiable w.r.t. models), the
+    chosen candidate [P,M] (0..3 = (R1,t) (R2,t) (R1,-t) (R2,-t)) and, optionally, the four cheirality votes."""
+    P = matches.shape[0]
+    models = models.reshape(P, -1, 3, 3)
+    return _PoseError.apply(matches, models, gt_R.reshape(P, 9), gt_t.reshape(P, 3), distance_threshold, want_votes)

@@ -23,7 +23,7 @@ def two_view_pair(seed: int, n_points: int = 2000, inlier_ratio: float = 0.5, no
 
     Returns matches [N,4] (x1,y1,x2,y2; normalised camera coordinates, or pixels when
     `pixel`), logits [N], gt_E [3,3] (unit Frobenius norm; satisfies x2^T E x1 = 0),
-    gt_F [3,3], K1, K2, inlier mask [N].  The first floor(N*(1-rho)) points are outliers.
+    gt_F [3,3], K1, K2, inlier mask [N], the ground-truth pose R [3,3], t [3] (x2 ~ R x1 + t).  The first floor(N*(1-rho)) points are outliers.
     """
     g = torch.Generator().manual_seed(int(seed))
     f64 = torch.float64
@@ -57,7 +57,7 @@ def two_view_pair(seed: int, n_points: int = 2000, inlier_ratio: float = 0.5, no
         p2 = torch.cat((x2, one), 1) @ K.T
         matches = torch.cat((p1[:, :2], p2[:, :2]), dim=1)
     return dict(matches=matches.to(dtype), logits=logits.to(dtype), gt_E=E.to(dtype), gt_F=F.to(dtype),
-                K1=K.to(dtype), K2=K.clone().to(dtype), inliers=inl)
+                K1=K.to(dtype), K2=K.clone().to(dtype), inliers=inl, R=R.to(dtype), t=t.to(dtype))
 
 
 def rigid_pair(seed: int, n_points: int = 50000, inlier_ratio: float = 0.5, noise: float = 0.01,

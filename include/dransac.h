@@ -245,6 +245,31 @@ int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *mo
 int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
                       const float *grad_sums, int P, int M, int N, float *grad_models, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * pose error of essential matrices -- the body of PoseLoss.forward_average (loss.py:11-68) =
+ * eval_essential_matrix(svd=False) (cv_utils.py:503-525) for every model of every pair:
+ *   Horn decomposition (new_decompose_E, cv_utils.py:118-161) -> candidates (R1,t) (R2,t) (R1,-t) (R2,-t);
+ *   votes[c] = number of points triangulated in front of both cameras and closer than distance_threshold
+ *   (recoverPose / cheirality_check, cv_utils.py:48-80,177-189; the reference passes 50); which = first arg-max;
+ *   err_R, err_t in degrees (evaluate_R_t_tensor, cv_utils.py:361-380).
+ *   matches [P,N,4] (normalised coordinates), models [P,M,9], gt_R [P,9], gt_t [P,3];
+ *   err_R, err_t [P,M]; which [P,M] int32; votes [P,M,4] int32 or NULL.
+ * Backward: grad_models [P,M,9] from grad_err_R, grad_err_t [P,M] at the recorded candidate `which`
+ * (the skew matrix of Horn's formula is a constant, as in the reference; non-finite derivatives -> 0).
+ * ------------------------------------------------------------------------------------------ */
+int dr_pose_error_fwd_f32(const float *matches, const float *models, const float *gt_R, const float *gt_t, int P, int M,
+                          int N, double distance_threshold, float *err_R, float *err_t, int32_t *which, int32_t *votes,
+                          void *stream);
+int dr_pose_error_fwd_f64(const double *matches, const double *models, const double *gt_R, const double *gt_t, int P,
+                          int M, int N, double distance_threshold, double *err_R, double *err_t, int32_t *which,
+                          int32_t *votes, void *stream);
+int dr_pose_error_bwd_f32(const float *models, const float *gt_R, const float *gt_t, const int32_t *which,
+                          const float *grad_err_R, const float *grad_err_t, int P, int M, float *grad_models,
+                          void *stream);
+int dr_pose_error_bwd_f64(const double *models, const double *gt_R, const double *gt_t, const int32_t *which,
+                          const double *grad_err_R, const double *grad_err_t, int P, int M, double *grad_models,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,9 @@ taken as an explicit input -- of the reference functions on the hot path:
     K6   test-mode arg-max + adaptive stop    ransac.py:109-144, 202-215
     K7   final refit                          ransac.py:148-195
     L    MatchLoss residual (8(f) rank 2)     loss.py:107-153, cv_utils.py:680-695
+    Lp   PoseLoss pose error (8(f) rank 3)    loss.py:11-68, cv_utils.py:48-80,118-189,361-380,503-525
+         (Horn decomposition + R/t error pinned by golden vectors; the triangulation inside the cheirality vote is
+          cv2.triangulatePoints, absent here: restated from OpenCV's published DLT, PARITY UNPINNED for that primitive)
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
 The product package (differentiable_ransac_amd) never does: its ops fail loudly when
@@ -577,6 +580,106 @@ def match_loss(models, matches, gt_mask):
     """MatchLoss.forward for one pair given the GT-inlier mask (loss.py:137-153): mean of min(ys, 1)."""
     ys = episym(matches[gt_mask, :2], matches[gt_mask, 2:], models)
     return torch.clamp(ys, max=1.0).mean()
+
+
+# --------------------------------------------------------------------------- #
+# SURVEY 8(f) rank 3: pose error of an essential matrix (PoseLoss, loss.py:11-68)
+# --------------------------------------------------------------------------- #
+
+
+def cofactor3(E):
+    """Cofactor matrix of [...,3,3] by cross products of the rows.  The reference computes inv(E).T * det(E)
+    (matrix_cofactor_tensor, cv_utils.py:163-175), which is the same matrix for det != 0 and raises for det == 0."""
+    r0, r1, r2 = E[..., 0, :], E[..., 1, :], E[..., 2, :]
+    return torch.stack((torch.linalg.cross(r1, r2), torch.linalg.cross(r2, r0), torch.linalg.cross(r0, r1)), dim=-2)
+
+
+def _skew(b):
+    z = torch.zeros_like(b[..., 0])
+    return torch.stack((torch.stack((z, -b[..., 2], b[..., 1]), -1), torch.stack((b[..., 2], z, -b[..., 0]), -1),
+                        torch.stack((-b[..., 1], b[..., 0], z), -1)), -2)
+
+
+def horn_decompose(E):
+    """new_decompose_E, cv_utils.py:118-161 (Horn 1990), batched over [...,3,3]: returns R1, R2 [...,3,3], t [...,3].
+    b = sqrt(tr(E E^T)/2) * (largest pairwise cross product of the COLUMNS of E, normalised); R1,2 = (cof(E) -+ [b]x E)
+    / (b.b); t = b / |b|.  As in the reference the skew matrix is built from detached values (torch.tensor(...) at
+    :144-148), i.e. it is a constant for autograd."""
+    e1, e2, e3 = E[..., :, 0], E[..., :, 1], E[..., :, 2]
+    crosses = torch.stack((torch.linalg.cross(e1, e2), torch.linalg.cross(e2, e3), torch.linalg.cross(e3, e1)), dim=-2)
+    norms = torch.linalg.norm(crosses, dim=-1)
+    largest = norms.argmax(dim=-1)
+    pick = torch.gather(crosses, -2, largest[..., None, None].expand(largest.shape + (1, 3))).squeeze(-2)
+    scale = torch.sqrt(0.5 * (E * E).sum((-1, -2)))
+    b1 = scale[..., None] * pick / torch.linalg.norm(pick, dim=-1, keepdim=True)
+    B1 = _skew(b1.detach())
+    bb = (b1 * b1).sum(-1)[..., None, None]
+    cof = cofactor3(E)
+    R1 = (cof - B1 @ E) / bb
+    R2 = (cof + B1 @ E) / bb
+    return R1, R2, b1 / torch.linalg.norm(b1, dim=-1, keepdim=True)
+
+
+def triangulate_dlt(P0, P1, x1, x2):
+    """cv2.triangulatePoints (OpenCV calib3d triangulate.cpp, the call at cv_utils.py:182): per point the 4x4 system
+    [x P[2] - P[0]; y P[2] - P[1]] of both cameras, solution = right singular vector of the smallest singular value.
+    OpenCV is absent from the build container: PARITY UNPINNED for this primitive (restated from the published
+    algorithm); every test the reference applies to the result is invariant to its sign and scale.
+    P0, P1 [...,3,4]; x1, x2 [n,2] -> X [...,n,4]."""
+    def rows(P, x):
+        return torch.stack((x[:, 0, None] * P[..., None, 2, :] - P[..., None, 0, :],
+                            x[:, 1, None] * P[..., None, 2, :] - P[..., None, 1, :]), dim=-2)
+    A = torch.cat((rows(P0, x1), rows(P1, x2)), dim=-2)          # [..., n, 4, 4]
+    return torch.linalg.svd(A)[2][..., 3, :]
+
+
+def cheirality_votes(R1, R2, t, x1, x2, distance_threshold: float = 50.0):
+    """recoverPose + cheirality_check, cv_utils.py:48-80,177-189: number of points in front of both cameras (and
+    closer than the threshold) for the candidates (R1,t), (R2,t), (R1,-t), (R2,-t).  R [...,3,3], t [...,3] -> [...,4]."""
+    P0 = torch.eye(3, 4, dtype=R1.dtype).expand(R1.shape[:-2] + (3, 4))
+    votes = []
+    for R, tt in ((R1, t), (R2, t), (R1, -t), (R2, -t)):
+        P = torch.cat((R, tt[..., None]), dim=-1)
+        Q = triangulate_dlt(P0, P, x1, x2)                       # [..., n, 4]
+        Qh = Q / Q[..., 3:4]
+        d2 = (P[..., None, 2, :] * Qh).sum(-1)
+        m = (Q[..., 2] * Q[..., 3] > 0) & (Qh[..., 2] < distance_threshold) & (d2 > 0) & (d2 < distance_threshold)
+        votes.append(m.sum(-1))
+    return torch.stack(votes, dim=-1)
+
+
+def rotation_translation_error(R_gt, t_gt, R, t):
+    """evaluate_R_t_tensor, cv_utils.py:361-380, batched over the leading dims of R/t: radians."""
+    eps = 1e-8
+    c = ((R * R_gt).sum((-1, -2)) - 1.0) * 0.5                   # trace(R R_gt^T) = sum(R * R_gt)
+    err_q = torch.arccos(torch.clamp(c, -1.0, 1.0))
+    tg = t_gt / (torch.linalg.norm(t_gt) + eps)
+    loss_t = torch.clamp(1.0 - (t * tg).sum(-1) ** 2, min=eps)
+    err_t = torch.arccos(torch.sqrt(1.0 - loss_t + eps))
+    return err_q, err_t
+
+
+def pose_error(E, matches, R_gt, t_gt, distance_threshold: float = 50.0):
+    """eval_essential_matrix(svd=False), cv_utils.py:503-525, for models E [M,3,3] of one pair: (err_R, err_t) in
+    degrees [M], chosen candidate [M] (first arg-max of the votes, as torch.argmax at cv_utils.py:69)."""
+    R1, R2, t = horn_decompose(E)
+    with torch.no_grad():
+        votes = cheirality_votes(R1, R2, t, matches[:, :2], matches[:, 2:], distance_threshold)
+        which = votes.argmax(dim=-1)
+    R = torch.where((which % 2 == 0)[:, None, None], R1, R2)
+    tt = torch.where((which < 2)[:, None], t, -t)
+    eq, et = rotation_translation_error(R_gt, t_gt, R, tt)
+    return eq * (180.0 / math.pi), et * (180.0 / math.pi), which
+
+
+def pose_loss(models_per_pair, matches, R_gt, t_gt):
+    """PoseLoss.forward_average, loss.py:17-68 (essential-matrix branch): mean over pairs of the mean over the pair's
+    models of (err_R + err_t) / 2 in degrees."""
+    total = 0.0
+    for b, E in enumerate(models_per_pair):
+        eq, et, _ = pose_error(E, matches[b], R_gt[b], t_gt[b])
+        total = total + ((eq + et) / 2).sum() / E.shape[0]
+    return total / len(models_per_pair)
 
 
 # --------------------------------------------------------------------------- #

@@ -4,7 +4,7 @@ Imports the reference's own Python for the hot path (with empty `cv2` / `h5py` s
 they are imported at module level by feature_utils.py:5,7 / utils.py:1 / cv_utils.py:1 /
 loss.py:1 but never called on the path), runs every hot-path function on seeded synthetic
 inputs and stores INPUTS and OUTPUTS as small .npz fixtures next to this file.  No
-reference source is stored.  Re-run:  python tests/golden/gen_golden.py
+reference source is stored.  Re-run:  python tests/golden/gen_golden.py [fixture names]
 """
 import os
 import sys
@@ -31,13 +31,19 @@ from estimators.fundamental_matrix_estimator import FundamentalMatrixEstimatorNe
 from estimators.rigid_transformation_SVD_based_solver import RigidTransformationSVDBasedSolver  # noqa: E402
 from ransac import RANSAC, RANSAC3D  # noqa: E402
 from cv_utils import batch_episym  # noqa: E402  (8(f) rank 2: the residual inside MatchLoss, loss.py:107-153)
+import cv_utils as ref_cv  # noqa: E402  (8(f) rank 3: new_decompose_E / recoverPose / evaluate_R_t_tensor)
 
 from differentiable_ransac_amd import synth  # noqa: E402
 
 torch.set_num_threads(1)
 
 
+ONLY = set(sys.argv[1:])   # optional: names of the fixtures to (re)write; the others are computed but left untouched
+
+
 def save(name, **arrs):
+    if ONLY and name not in ONLY:
+        return
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
@@ -204,6 +210,48 @@ def main():
     for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
         out[f"ys_{tag}"] = batch_episym(x1.to(dt).repeat(24, 1, 1), x2.to(dt).repeat(24, 1, 1), Fs.to(dt))
     save("episym", matches=pair["matches"], inliers=pair["inliers"], models=Fs, **out)
+
+    # ---------------------------------------------------------------- PoseLoss pose error (8(f) rank 3)
+    # new_decompose_E / evaluate_R_t_tensor are pure torch and run as they are.  recoverPose needs
+    # cv2.triangulatePoints (cv_utils.py:182), which does not exist here: the stub module gets a numpy DLT
+    # (OpenCV's published algorithm: 4x4 system per point, smallest right singular vector) so that the reference's own
+    # control flow around it (candidate order, vote, arg-max, sign of t) is what produces the vectors.
+    def dlt(P0, P1, x1, x2):
+        out = np.zeros((4, x1.shape[1]))
+        for i in range(x1.shape[1]):
+            A = np.stack((x1[0, i] * P0[2] - P0[0], x1[1, i] * P0[2] - P0[1], x2[0, i] * P1[2] - P1[0], x2[1, i] * P1[2] - P1[1]))
+            out[:, i] = np.linalg.svd(A)[2][3]
+        return out
+    sys.modules["cv2"].triangulatePoints = dlt
+    pair = synth.two_view_pair(21, 160, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(22)
+    gtE = pair["gt_E"]
+    Es = [gtE, -gtE]
+    for sgm in (1e-3, 1e-2, 5e-2, 0.2):
+        for _ in range(4):
+            Es.append(gtE + sgm * torch.randn(3, 3, generator=gen, dtype=torch.float64))
+    smp5 = minimal_samples(pair["matches"], 6, 5, 23)
+    sol = EssentialMatrixEstimatorNister(device="cpu").estimate_model(smp5)
+    Es = torch.cat((torch.stack(Es), sol[:12].to(torch.float64)))
+    p1 = pair["matches"][:, :2].numpy()
+    p2 = pair["matches"][:, 2:].numpy()
+    R1s, R2s, ts, Rs, tsel, eq, et = [], [], [], [], [], [], []
+    for E in Es:
+        R1, R2, t = ref_cv.new_decompose_E(E)
+        R, tt = ref_cv.recoverPose(E, p1, p2, False)
+        a, b = ref_cv.eval_essential_matrix(p1, p2, E, pair["R"], pair["t"], svd=False)
+        R1s.append(R1); R2s.append(R2); ts.append(t.flatten()); Rs.append(R); tsel.append(tt.flatten())
+        eq.append(a); et.append(b)
+    # gradient of the pose loss of one pair w.r.t. the models (loss.py:58-66), the skew matrix detached as in the reference
+    Eg = Es.clone().requires_grad_(True)
+    tot = 0
+    for i in range(Eg.shape[0]):
+        a, b = ref_cv.eval_essential_matrix(p1, p2, Eg[i], pair["R"], pair["t"], svd=False)
+        tot = tot + (a + b) / 2
+    (tot / Eg.shape[0]).backward()
+    save("pose_error", matches=pair["matches"], gt_R=pair["R"], gt_t=pair["t"], models=Es, R1=torch.stack(R1s),
+         R2=torch.stack(R2s), t=torch.stack(ts), R_sel=torch.stack(Rs), t_sel=torch.stack(tsel),
+         err_R=torch.stack(eq), err_t=torch.stack(et), loss=(tot / Eg.shape[0]).detach(), grad_models=Eg.grad)
 
     rp = synth.rigid_pair(9, 256)
     smp = GumbelSoftmaxSampler(32, 3, device="cpu", data_type=torch.float32)

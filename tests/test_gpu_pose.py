@@ -1,0 +1,87 @@
+"""pose error of essential matrices (dr_pose_error_*) against the reference's golden vectors
+(Horn decomposition, candidate selection, R/t error, PoseLoss gradient) and the oracle (cheirality votes by SVD)."""
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(g, dev, dtype, want_votes=True):
+    from differentiable_ransac_amd import ops
+    E = g["models"].to(dtype).to(dev)[None].clone().requires_grad_(True)
+    out = ops.pose_error(g["matches"].to(dtype).to(dev)[None], E, g["gt_R"].to(dtype).to(dev)[None],
+                         g["gt_t"].to(dtype).to(dev)[None], want_votes=want_votes)
+    return E, out
+
+
+def test_pose_error_matches_reference_f64(dev):
+    g = load_golden("pose_error")
+    E, (eq, et, which, votes) = _run(g, dev, torch.float64)
+    assert (eq[0].cpu() - g["err_R"]).abs().max() < 1e-7
+    assert (et[0].cpu() - g["err_t"]).abs().max() < 1e-7
+    # the oracle's cheirality votes (4x4 SVD per point and candidate) are reproduced exactly by the closed-form eigenvector
+    R1, R2, t = O.horn_decompose(g["models"])
+    ov = O.cheirality_votes(R1, R2, t, g["matches"][:, :2], g["matches"][:, 2:])
+    assert torch.equal(votes[0].cpu().long(), ov)
+    assert torch.equal(which[0].cpu().long(), ov.argmax(-1))
+    # gradient of the reference's loss (mean over models of (err_R + err_t) / 2)
+    ((eq + et) / 2).mean().backward()
+    gm = E.grad[0].cpu()
+    det = torch.linalg.det(g["models"]).abs()
+    ok = (det > 1e-6) & (g["err_R"] > 1e-3)      # see tests/test_oracle_golden.py::test_pose_error_matches_reference
+    rel = (gm - g["grad_models"]).abs().amax((-1, -2)) / g["grad_models"].abs().amax((-1, -2))
+    assert rel[ok].max() < 1e-7
+    # ... and against the oracle's autograd everywhere except at the ground truth itself (arccos'(1) is singular)
+    Eo = g["models"].clone().requires_grad_(True)
+    O.pose_loss([Eo], g["matches"][None], g["gt_R"][None], g["gt_t"][None]).backward()
+    away = g["err_R"] > 1e-3
+    rel_o = (gm - Eo.grad).abs().amax((-1, -2)) / Eo.grad.abs().amax((-1, -2))
+    assert rel_o[away].max() < 1e-7
+
+
+def test_pose_error_f32_and_invariances(dev):
+    g = load_golden("pose_error")
+    _, (eq, et, which, _) = _run(g, dev, torch.float32, want_votes=False)
+    # f32 storage, f64 arithmetic: the error of an angle near 0 is limited by the f32 rounding of E itself
+    assert (eq[0].cpu().double() - g["err_R"]).abs().max() < 5e-3
+    assert (et[0].cpu().double() - g["err_t"]).abs().max() < 5e-3
+    # E, -E and 3E describe the same pose
+    from differentiable_ransac_amd import ops
+    m = g["matches"].to(dev)[None]
+    E = g["models"].to(dev)[None]
+    a = ops.pose_error(m, E, g["gt_R"].to(dev)[None], g["gt_t"].to(dev)[None])
+    b = ops.pose_error(m, -3.0 * E, g["gt_R"].to(dev)[None], g["gt_t"].to(dev)[None])
+    # (arccos near 1 turns 1e-16 of rounding into 1e-6 degrees at the ground truth)
+    assert (a[0] - b[0]).abs().max() < 1e-5 and (a[1] - b[1]).abs().max() < 1e-5
+
+
+def test_pose_loss_full_size_vs_oracle(dev):
+    """C2-sized pairs: models = Nister solutions of sampled minimal sets; PoseLoss against the oracle on a subset of
+    the models and known answers for the ground truth."""
+    from differentiable_ransac_amd import ops, synth
+    from differentiable_ransac_amd.loss import PoseLoss
+    P, N, B = 3, 2000, 128
+    data = synth.batch_two_view(P, N, seed0=40, dtype=torch.float64)
+    m = data["matches"].to(dev)
+    r = ops.gumbel_topk(data["logits"].to(dev), B, 5, 1.0, None, seed=9)
+    models, valid = ops.solve_nister5(ops.gather(m, r["idx"], r["y_sel"]))
+    models = models.reshape(P, -1, 3, 3)
+    models[:, 0] = data["gt_E"].to(dev)                      # slot 0 <- ground truth
+    valid = valid.reshape(P, -1).clone()
+    valid[:, 0] = True
+    eq, et, which, votes = ops.pose_error(m, models, data["R"].to(dev), data["t"].to(dev), want_votes=True)
+    assert eq[:, 0].max() < 1e-4 and et[:, 0].max() < 0.2     # GT E -> GT pose (t only up to the noise-free limit)
+    assert (votes[:, 0].max(-1).values > 0.45 * N).all()      # the inlier half triangulates in front of both cameras
+    sub = slice(0, 60)
+    for p in range(P):
+        oq, ot, ow = O.pose_error(models[p, sub].cpu(), data["matches"][p], data["R"][p], data["t"][p])
+        same = ow == which[p, sub].cpu().long()
+        assert same.float().mean() > 0.97                      # vote ties / borderline points may flip a candidate
+        assert (eq[p, sub].cpu() - oq)[same].abs().max() < 1e-5 and (et[p, sub].cpu() - ot)[same].abs().max() < 1e-5
+    loss = PoseLoss()(models, m[..., :2], m[..., 2:], data["R"].to(dev), data["t"].to(dev), keep=valid)
+    k = valid.double()
+    want = ((((eq + et) / 2) * k).sum(1) / k.sum(1)).mean()
+    assert abs(float(loss) - float(want)) < 1e-9

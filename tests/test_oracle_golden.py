@@ -221,3 +221,29 @@ def test_episym_matches_reference():
         ref = g[f"ys_{tag}"]
         assert ys.shape == ref.shape
         assert ((ys - ref).abs() / ref.abs().clamp(min=1e-12)).max() < tol
+
+
+def test_pose_error_matches_reference():
+    """8(f) rank 3: Horn decomposition, cheirality vote (reference control flow around a DLT stand-in for
+    cv2.triangulatePoints), rotation / translation error and the PoseLoss gradient."""
+    g = load_golden("pose_error")
+    E = g["models"]
+    R1, R2, t = O.horn_decompose(E)
+    _close(R1, g["R1"], 1e-12), _close(R2, g["R2"], 1e-12), _close(t, g["t"], 1e-12)
+    eq, et, which = O.pose_error(E, g["matches"], g["gt_R"], g["gt_t"])
+    _close(torch.where((which % 2 == 0)[:, None, None], R1, R2), g["R_sel"], 1e-12)
+    _close(torch.where((which < 2)[:, None], t, -t), g["t_sel"], 1e-12)
+    _close(eq, g["err_R"], 1e-8), _close(et, g["err_t"], 1e-8)
+    # known answers: the ground-truth E (and -E) decompose to the ground-truth pose
+    assert eq[0] < 1e-4 and eq[1] < 1e-4 and et[0] < 0.05 and et[1] < 0.05
+    Eg = E.clone().requires_grad_(True)
+    loss = O.pose_loss([Eg], g["matches"][None], g["gt_R"][None], g["gt_t"][None])
+    assert abs(float(loss) - float(g["loss"])) < 1e-9
+    loss.backward()
+    # the reference differentiates inv(E).T * det(E) (cv_utils.py:163-175), which is ill-conditioned for the exactly
+    # singular E a five-point solver returns, and arccos at the ground truth: the gradient is pinned on the rest
+    det = torch.linalg.det(E).abs()
+    ok = (det > 1e-6) & (g["err_R"] > 1e-3)
+    assert int(ok.sum()) >= 20
+    rel = (Eg.grad - g["grad_models"]).abs().amax((-1, -2)) / g["grad_models"].abs().amax((-1, -2))
+    assert rel[ok].max() < 1e-8
