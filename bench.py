@@ -157,11 +157,19 @@ def main():
         tr = BatchedRANSAC(args.solver, ransac_batch_size=B, train=True, max_iterations=B, seed=99 + rank)
         lg = logits.clone().requires_grad_(True)
 
+        from differentiable_ransac_amd.loss import MatchLoss
+        match_loss = MatchLoss()                     # the reference's default training loss (-w2 1, train.py:70-79)
+        gt_mask = data["inliers"].to(dev)
+
         def step():
             lg.grad = None
             chosen, keep = tr(matches, lg, gt_model=gt)
-            d = torch.minimum(((chosen - gt[:, None]) ** 2).sum((-1, -2)), ((chosen + gt[:, None]) ** 2).sum((-1, -2)))
-            (d * keep).sum().backward()
+            if args.solver == "f8":                  # pixel coordinates: plain distance to the ground-truth F
+                d = torch.minimum(((chosen - gt[:, None]) ** 2).sum((-1, -2)), ((chosen + gt[:, None]) ** 2).sum((-1, -2)))
+                loss = (d * keep).sum()
+            else:
+                loss = match_loss(chosen, matches, gt_mask, keep)
+            loss.backward()
             return {"inliers": torch.zeros(P, device=dev), "grad": lg.grad}
     else:
         def step():
@@ -225,7 +233,8 @@ def main():
                               "value": job_hyps_per_s, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"{args.solver} train step, {N} pts x {B} hyps per pair, {P} pairs/GPU",
+                              "config": {"workload": f"{args.solver} train step (sample, solve, best-of-10 vs GT, MatchLoss, backward), "
+                                                     f"{N} pts x {B} hyps per pair, {P} pairs/GPU",
                                          "mode": "train"},
                               "grad_finite": bool(torch.isfinite(out["grad"]).all())}))
         if dist is not None:

@@ -264,6 +264,20 @@ __global__ void select_closest_kernel(const T *__restrict__ models, const uint8_
   for (int q = 0; q < 9; ++q) chosen[e * 9 + q] = best >= 0 ? models[(e * S + best) * 9 + q] : T(q % 4 == 0 ? 1 : 0);
 }
 
+// backward of K5: the gradient of chosen[p,b] goes to slot which[p,b]; every other slot gets 0 (one launch instead of
+// zeros + clamp + compare + mul + scatter)
+template <typename T>
+__global__ void select_closest_bwd_kernel(const T *__restrict__ grad_chosen, const int32_t *__restrict__ which, size_t total,
+                                          int S, T *__restrict__ grad_models) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (p, b, s, q)
+  if (i >= total) return;
+  const int q = (int)(i % 9);
+  const size_t es = i / 9;
+  const int s = (int)(es % S);
+  const size_t e = es / S;
+  grad_models[i] = (which[e] == s) ? grad_chosen[e * 9 + q] : T(0);
+}
+
 }  // namespace dr
 
 extern "C" {
@@ -313,6 +327,25 @@ int dr_select_closest_f64(const double *models, const uint8_t *valid, const doub
   hipLaunchKernelGGL((dr::select_closest_kernel<double>), dim3((B + 255) / 256, P), dim3(256), 0,
                      (hipStream_t)stream, models, valid, gt, B, S, chosen, which);
   return dr::check_launch("select_closest_kernel");
+}
+
+int dr_select_closest_bwd_f32(const float *grad_chosen, const int32_t *which, int P, int B, int S, float *grad_models,
+                              void *stream) {
+  DR_REQUIRE(P > 0 && B > 0 && S > 0, "bad sizes");
+  DR_REQUIRE(grad_chosen && which && grad_models, "null pointer");
+  const size_t total = (size_t)P * B * S * 9;
+  hipLaunchKernelGGL((dr::select_closest_bwd_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, grad_chosen, which, total, S, grad_models);
+  return dr::check_launch("select_closest_bwd_kernel");
+}
+int dr_select_closest_bwd_f64(const double *grad_chosen, const int32_t *which, int P, int B, int S, double *grad_models,
+                              void *stream) {
+  DR_REQUIRE(P > 0 && B > 0 && S > 0, "bad sizes");
+  DR_REQUIRE(grad_chosen && which && grad_models, "null pointer");
+  const size_t total = (size_t)P * B * S * 9;
+  hipLaunchKernelGGL((dr::select_closest_bwd_kernel<double>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, grad_chosen, which, total, S, grad_models);
+  return dr::check_launch("select_closest_bwd_kernel");
 }
 
 }  // extern "C"

@@ -489,10 +489,9 @@ class _SelectClosest(torch.autograd.Function):
     def backward(ctx, g_chosen, _gw):
         (which,) = ctx.saved_tensors
         P, B, S = ctx.shape[:3]
-        g = torch.zeros(ctx.shape, device=g_chosen.device, dtype=g_chosen.dtype)
-        w = which.long().clamp(min=0)
-        live = (which >= 0).to(g_chosen.dtype)[..., None, None]
-        g.scatter_(2, w[..., None, None, None].expand(P, B, 1, 3, 3), (g_chosen * live).unsqueeze(2))
+        g = torch.empty(ctx.shape, device=g_chosen.device, dtype=g_chosen.dtype)
+        L.call(f"dr_select_closest_bwd_{L.suffix(g_chosen.dtype)}", ptr(g_chosen.contiguous()), ptr(which), c_int(P),
+               c_int(B), c_int(S), ptr(g), stream())
         return g, None, None
 
 

@@ -171,6 +171,11 @@ int dr_select_closest_f32(const float *models, const uint8_t *valid, const float
                           float *chosen, int32_t *which, void *stream);
 int dr_select_closest_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
                           double *chosen, int32_t *which, void *stream);
+/* backward: grad_models [P,B,S,9] = grad_chosen [P,B,9] at slot which[p,b], 0 elsewhere (all of it is written). */
+int dr_select_closest_bwd_f32(const float *grad_chosen, const int32_t *which, int P, int B, int S, float *grad_models,
+                              void *stream);
+int dr_select_closest_bwd_f64(const double *grad_chosen, const int32_t *which, int P, int B, int S, double *grad_models,
+                              void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K6  test-mode selection      RANSAC.__call__, ransac.py:111-120
