@@ -21,6 +21,7 @@ for name in ("cv2", "h5py"):
     sys.modules.setdefault(name, types.ModuleType(name))
 sys.path.insert(0, REF)
 sys.path.insert(1, REPO)
+sys.path.insert(2, HERE)
 
 from samplers.gumbel_sampler import GumbelSoftmaxSampler  # noqa: E402
 from samplers.uniform_sampler import UniformSampler  # noqa: E402
@@ -252,6 +253,41 @@ def main():
     save("pose_error", matches=pair["matches"], gt_R=pair["R"], gt_t=pair["t"], models=Es, R1=torch.stack(R1s),
          R2=torch.stack(R2s), t=torch.stack(ts), R_sel=torch.stack(Rs), t_sel=torch.stack(tsel),
          err_R=torch.stack(eq), err_t=torch.stack(et), loss=(tot / Eg.shape[0]).detach(), grad_models=Eg.grad)
+
+    # ---------------------------------------------------------------- data readers (8(f) rank 4, datasets.py:16-129,311-352)
+    # cv2.undistortPoints(pts, K, None) (datasets.py:85-86) does not exist here: without distortion coefficients it is the
+    # pinhole inverse, which the stub implements so that the reference's own Dataset code produces the vectors.
+    import tempfile
+    from make_pair_files import make_tree
+    import datasets as ref_ds
+
+    def undistort(p, K, dist):
+        assert dist is None
+        out = np.empty_like(p)
+        out[..., 0] = (p[..., 0] - K[0, 2]) / K[0, 0]
+        out[..., 1] = (p[..., 1] - K[1, 2]) / K[1, 1]
+        return out
+    sys.modules["cv2"].undistortPoints = undistort
+    with tempfile.TemporaryDirectory() as root:
+        ng, m3 = make_tree(root)
+        out = {}
+        for fmat in (False, True):
+            ds = ref_ds.Dataset([ng], ratiothreshold=0.8, nfeatures=200, fmat=fmat)
+            order = sorted(range(len(ds)), key=lambda i: ds.files[i])
+            for j, i in enumerate(order):
+                torch.manual_seed(100 + j)
+                it = ds[i]
+                tag = f"{'F' if fmat else 'E'}{j}"
+                for k in ("correspondences", "gt_F", "gt_E", "gt_R", "gt_t", "K1", "K2", "im_size1", "im_size2"):
+                    out[f"{tag}_{k}"] = it[k]
+        d3 = ref_ds.Dataset3D([m3], num=100)
+        order = sorted(range(len(d3)), key=lambda i: d3.files[i])
+        for j, i in enumerate(order):
+            torch.manual_seed(200 + j)
+            it = d3[i]
+            out[f"M{j}_correspondences"] = it["correspondences"]
+            out[f"M{j}_gt_pose"] = it["gt_pose"]
+        save("data_readers", **out)
 
     rp = synth.rigid_pair(9, 256)
     smp = GumbelSoftmaxSampler(32, 3, device="cpu", data_type=torch.float32)
