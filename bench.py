@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--extras", action="store_true",
                     help="after the official timed region also measure (a) two-stream overlap of consecutive batches and "
                          "(b) the step followed by the final refit; off by default so that a profiler sees only the official loop")
+    ap.add_argument("--sampler", default="gumbel", choices=["gumbel", "topdown"],
+                    help="gumbel: the reference's sampler (noise for every point of every hypothesis + top-k, in-kernel "
+                         "Philox); topdown: the same index-set distribution drawn as k soft-max draws without replacement "
+                         "(test mode only) -- reported as a variant, never the default")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the K steps are issued on round-robin (default 2: two batches in flight, the "
                          "latency-bound sampler/solver of batch i+1 runs under the VALU-bound scoring of batch i); "
@@ -133,7 +137,7 @@ def main():
     K1, K2 = data["K1"].to(dev), data["K2"].to(dev)
     thr_px = 0.75
     rn = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
-                       seed=1234 + rank, keep_masks=True, refit=False)
+                       seed=1234 + rank, keep_masks=True, refit=False, sampling=args.sampler)
 
     # HIP events bracket exactly the dr_msac_score launch (the ctypes call), on the stream it is launched on
     from differentiable_ransac_amd import _lib as L
@@ -256,6 +260,26 @@ def main():
         e3 = time.perf_counter() - t2
         with_refit = {"value": P * B * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3}
 
+    # informational (--extras): the same K steps with the top-down draw of the index sets instead of the dense Gumbel
+    # sampler (identical set distribution, tests/test_gpu_sampler.py; not the reference's sampler kernel, so not the headline)
+    topdown = None
+    if args.extras and world == 1 and args.sampler == "gumbel":
+        rn_td = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
+                              seed=77, keep_masks=True, refit=False, sampling="topdown")
+        keep = [None] * len(streams)
+        for i in range(2 * len(streams)):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                keep[i % len(streams)] = rn_td(matches, logits, K1, K2)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for i in range(args.steps):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                keep[i % len(streams)] = rn_td(matches, logits, K1, K2)
+        torch.cuda.synchronize()
+        e4 = time.perf_counter() - t3
+        topdown = {"value": P * B * args.steps / e4, "ms_per_step": e4 / args.steps * 1e3, "streams": len(streams)}
+        del keep
+
     k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     # the same launch with nothing else on the GPU (one stream, a few extra untimed steps): with two batches in flight
     # the scoring kernel shares the CUs with the next batch's sampler/solver, so its wall duration above is longer than
@@ -306,8 +330,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.solver} 5-pt E, {N} pts x {B} hyps per pair, Gumbel top-k sampler (in-kernel "
-                               f"Philox), MSAC scoring with masks, test mode, {P} pairs/GPU/step",
+        "config": {"workload": f"{args.solver} 5-pt E, {N} pts x {B} hyps per pair, "
+                               + ("Gumbel top-k sampler (in-kernel Philox)" if args.sampler == "gumbel" else
+                                  "top-down (Plackett-Luce) draw of the Gumbel top-k index sets")
+                               + f", MSAC scoring with masks, test mode, {P} pairs/GPU/step",
+                   "sampler": args.sampler,
                    "pairs_per_gpu": P, "points": N, "hypotheses_per_pair": B, "models_per_pair": M,
                    "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective",
                    "streams": len(streams),
@@ -326,6 +353,7 @@ def main():
         "check": {"mean_inlier_fraction_of_best_model": inl_frac},
         "other_issue_policy": overlap,
         "with_final_refit": with_refit,
+        "sampler_topdown": topdown,
     }
     if args.profile_kernels and rank == 0:
         result["kernel_breakdown_ms"] = kernel_breakdown(args, rn, matches, logits, K1, K2, ops)

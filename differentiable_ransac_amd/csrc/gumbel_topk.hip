@@ -371,6 +371,97 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
     if (4 * q + j < a.N) atomicAdd(grad_logits + (size_t)p * a.N + 4 * q + j, acc[j] / a.tau);
 }
 
+// ---- K1 (inference variant): top-down sampling of the Gumbel top-k index set --------------------------------------
+// The k largest of {logit_n + G_n}, G_n iid Gumbel(0,1), taken in decreasing order, are distributed as k sequential
+// draws WITHOUT replacement from softmax(logits) (Plackett-Luce; the "Gumbel-max trick" read backwards, Kool et al. 2019,
+// Maddison et al. 2014).  When only the index set is consumed -- RANSAC test mode, ransac.py:65: `samples != 0` -- the
+// N noise values of a row are never needed: k uniforms and k binary searches in the cumulative weights of the pair do.
+// O(B k log N) instead of O(B N); tau > 0 does not change the order, so it does not appear.  y_sel / lse / the dense
+// outputs (train mode, weighted mode) need the whole noise row and stay with gumbel_topk_kernel.
+// Step 1, per pair: cdf[n] = sum_{m <= n} exp(logit_m - max logit) in f64 (one block per pair).
+template <typename T>
+__global__ __launch_bounds__(1024) void softmax_cdf_kernel(const T *__restrict__ logits, int N, double *__restrict__ cdf) {
+  __shared__ double s_part[1024];
+  __shared__ double s_max;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const T *l = logits ? logits + (size_t)p * N : nullptr;
+  double *c = cdf + (size_t)p * N;
+  double mx = -INFINITY;
+  for (int n = tid; n < N; n += 1024) mx = fmax(mx, l ? (double)l[n] : 1.0);
+  s_part[tid] = mx;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) s_part[tid] = fmax(s_part[tid], s_part[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) s_max = s_part[0];
+  __syncthreads();
+  mx = s_max;
+  // contiguous chunk per thread, then an exclusive scan of the chunk sums
+  const int per = (N + 1023) / 1024, n0 = tid * per, n1 = min(N, n0 + per);
+  double acc = 0;
+  for (int n = n0; n < n1; ++n) acc += exp((l ? (double)l[n] : 1.0) - mx);
+  s_part[tid] = acc;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+    const double v = tid >= o ? s_part[tid - o] : 0.0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  double run = s_part[tid] - acc;
+  for (int n = n0; n < n1; ++n) {
+    run += exp((l ? (double)l[n] : 1.0) - mx);
+    c[n] = run;
+  }
+}
+
+// Step 2, one lane per (pair, hypothesis): k draws without replacement, ascending output.
+// Philox4x32-10(key = seed, counter = (draw pair, b, p, 2)): 64 random bits per draw.
+__global__ __launch_bounds__(256) void topdown_sample_kernel(const double *__restrict__ cdf, uint64_t seed, int B, int N, int k,
+                                                            int32_t *__restrict__ idx) {
+  const int p = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double *c = cdf + (size_t)p * N;
+  const double total = c[N - 1];
+  int sel[kMaxK];
+  double wsel[kMaxK];
+  double removed = 0;
+  uint32_t r[4];
+  for (int d = 0; d < k; ++d) {
+    if ((d & 1) == 0) Philox::gen(seed, (uint32_t)(d >> 1), (uint32_t)b, (uint32_t)p, 2u, r);
+    const uint64_t bits = ((uint64_t)r[2 * (d & 1)] << 32) | r[2 * (d & 1) + 1];
+    const double u = ((double)(bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);   // (0,1), 53 bits
+    const double target = u * (total - removed);
+    // smallest n with  cdf[n] - (weight already removed at positions <= n)  >  target
+    int lo = 0, hi = N - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      double v = c[mid];
+      for (int j = 0; j < d; ++j) v -= (sel[j] <= mid) ? wsel[j] : 0.0;
+      if (v > target) hi = mid; else lo = mid + 1;
+    }
+    // rounding can land on an already-selected point (its remaining weight is 0): move to the next free one
+    bool dup = true;
+    while (dup) {
+      dup = false;
+      for (int j = 0; j < d; ++j) dup = dup || (sel[j] == lo);
+      if (dup) lo = (lo + 1 < N) ? lo + 1 : 0;
+    }
+    sel[d] = lo;
+    wsel[d] = c[lo] - (lo > 0 ? c[lo - 1] : 0.0);
+    removed += wsel[d];
+  }
+  // insertion sort (k <= 8), ascending point index: the order `points[samples != 0]` yields (ransac.py:65)
+  for (int i = 1; i < k; ++i) {
+    const int v = sel[i];
+    int j = i - 1;
+    while (j >= 0 && sel[j] > v) { sel[j + 1] = sel[j]; --j; }
+    sel[j + 1] = v;
+  }
+  for (int d = 0; d < k; ++d) idx[((size_t)p * B + b) * k + d] = sel[d];
+}
+
 // ---- K1u: uniform indices in [0, N-2]
 __global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_t *__restrict__ idx) {
   const int p = blockIdx.y;
@@ -464,6 +555,28 @@ int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t se
   hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
                      lse, a_sel, grad_logits, rows_per_block);
   return dr::check_launch("gumbel_bwd_kernel");
+}
+
+int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
+                          void *stream) {
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && k > 0 && k <= dr::kMaxK && k <= N && P <= 65535, "bad sizes");
+  DR_REQUIRE(cdf_ws && idx, "null pointer");
+  hipLaunchKernelGGL((dr::softmax_cdf_kernel<float>), dim3(P), dim3(1024), 0, (hipStream_t)stream, logits, N, cdf_ws);
+  if (int rc = dr::check_launch("softmax_cdf_kernel")) return rc;
+  hipLaunchKernelGGL(dr::topdown_sample_kernel, dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, cdf_ws, seed, B,
+                     N, k, idx);
+  return dr::check_launch("topdown_sample_kernel");
+}
+
+int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
+                          void *stream) {
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && k > 0 && k <= dr::kMaxK && k <= N && P <= 65535, "bad sizes");
+  DR_REQUIRE(cdf_ws && idx, "null pointer");
+  hipLaunchKernelGGL((dr::softmax_cdf_kernel<double>), dim3(P), dim3(1024), 0, (hipStream_t)stream, logits, N, cdf_ws);
+  if (int rc = dr::check_launch("softmax_cdf_kernel")) return rc;
+  hipLaunchKernelGGL(dr::topdown_sample_kernel, dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, cdf_ws, seed, B,
+                     N, k, idx);
+  return dr::check_launch("topdown_sample_kernel");
 }
 
 int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream) {

@@ -154,6 +154,26 @@ def gumbel_topk_bwd(logits, gumbel, seed, tau, idx, lse, a_sel):
     return grad
 
 
+def topdown_sample(logits: Optional[torch.Tensor], B: int, k: int, seed: int = 0, N: Optional[int] = None, P: int = 1,
+                   device=None) -> torch.Tensor:
+    """K1, inference variant (dr_topdown_sample): the Gumbel top-k INDEX SET drawn top-down -- k sequential draws
+    without replacement from softmax(logits), the exact distribution of the top-k of logits + iid Gumbel(0,1) for any
+    tau > 0 -- in O(B k log N).  logits [P,N] (or None = uniform: pass N, P, device) -> idx [P,B,k] int32 ascending.
+    No y_sel / lse: train mode and weighted mode need the whole noise row (use gumbel_topk)."""
+    if logits is not None:
+        logits = logits.contiguous()
+        P, N = logits.shape
+        device = logits.device
+        sfx = L.suffix(logits.dtype)
+    else:
+        sfx = "f32"
+    ws = torch.empty((P, N), device=device, dtype=torch.float64)
+    idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
+    L.call(f"dr_topdown_sample_{sfx}", ptr(logits), c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(N), c_int(k),
+           ptr(ws), ptr(idx), stream())
+    return idx
+
+
 def uniform_sample(P: int, B: int, k: int, N: int, seed: int, device) -> torch.Tensor:
     """K1u: idx [P,B,k] int32 ~ U{0..N-2} (uniform_sampler.py:15-19 semantics)."""
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)

@@ -213,7 +213,16 @@ class BatchedRANSAC(object):
     _SOLVERS = {"nister": (5, 10), "stewenius": (5, 10), "f8": (8, 1), "f7": (7, 4)}
 
     def __init__(self, solver="nister", ransac_batch_size=1024, train=False, threshold=0.75, confidence=0.999,
-                 max_iterations=5000, tau=1.0, seed=0, weighted=0, keep_masks=False, refit=True, eps=1e-5):
+                 max_iterations=5000, tau=1.0, seed=0, weighted=0, keep_masks=False, refit=True, eps=1e-5,
+                 sampling="gumbel"):
+        # sampling: "gumbel" = the reference's sampler (noise for every point of every hypothesis, top-k);
+        # "topdown" = the same index-set distribution drawn as k sequential soft-max draws without replacement
+        # (ops.topdown_sample, O(B k log N)); test mode only, no soft weights (weighted=0), no explicit noise.
+        if sampling not in ("gumbel", "topdown"):
+            raise ValueError("sampling must be 'gumbel' or 'topdown'")
+        if sampling == "topdown" and (train or weighted):
+            raise ValueError("top-down sampling yields index sets only: train mode and weighted=1 need the Gumbel sampler")
+        self.sampling = sampling
         self.solver = solver
         self.k, self.S = self._SOLVERS[solver]
         self.B = ransac_batch_size
@@ -238,7 +247,11 @@ class BatchedRANSAC(object):
 
     def hypotheses(self, matches, logits, gumbels=None):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
-        samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, self._next_seed())
+        if self.sampling == "topdown" and gumbels is None:
+            idx = ops.topdown_sample(logits, self.B, self.k, self._next_seed())
+            samples, w = ops.gather(matches, idx), None
+        else:
+            samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, self._next_seed())
         wts = w if self.weighted else None
         if self.solver in ("nister", "stewenius"):
             models, valid = ops.solve_essential(samples, wts, self.solver)

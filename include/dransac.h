@@ -68,6 +68,17 @@ int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t se
                            int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
                            void *stream);
 
+/* K1, inference variant: the index SET of the Gumbel top-k sampler by top-down (Plackett-Luce) sampling -- k sequential
+ * draws without replacement from softmax(logits), which is the distribution of the top-k of logits + iid Gumbel noise
+ * (any tau > 0).  For callers that only consume `samples != 0` (RANSAC test mode, ransac.py:65); y_sel / lse need the
+ * whole noise row and come from dr_gumbel_topk_fwd.  logits [P,N] or NULL (uniform); cdf_ws [P,N] f64 workspace (the
+ * per-pair cumulative soft-max weights, overwritten); idx [P,B,k] ascending.
+ * Philox4x32-10(key = seed, counter = (draw / 2, b, p, 2)). */
+int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
+                          void *stream);
+int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
+                          void *stream);
+
 /* K1u  UniformSampler.batch_generate, samplers/uniform_sampler.py:15-19: idx ~ U{0..N-2}, with replacement.
  * Philox4x32-10(key = seed, counter = (j, b, p, 1)). */
 int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream);

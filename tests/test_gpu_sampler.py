@@ -147,3 +147,70 @@ def test_sampler_gather_backward(dev, explicit):
     gl, gm = lg.grad.cpu().double(), mt.grad.cpu().double()
     assert (gl - l64.grad).abs().max() <= 2e-4 * l64.grad.abs().max()
     assert (gm - m64.grad).abs().max() <= 1e-5 * m64.grad.abs().max()
+
+
+def _pl_set_probs(w, k):
+    """exact probability of every k-subset under sequential sampling without replacement (Plackett-Luce)."""
+    import itertools
+    n = len(w)
+    probs = {}
+    for perm in itertools.permutations(range(n), k):
+        p, rest = 1.0, sum(w)
+        for i in perm:
+            p *= w[i] / rest
+            rest -= w[i]
+        key = tuple(sorted(perm))
+        probs[key] = probs.get(key, 0.0) + p
+    return probs
+
+
+def test_topdown_sampler_has_the_gumbel_topk_distribution(dev):
+    """The top-down sampler draws the index SET of the Gumbel top-k sampler: exact Plackett-Luce set probabilities on a
+    small problem (chi-square), and the dense Gumbel kernel run on the same problem as a cross-check."""
+    from differentiable_ransac_amd import ops
+    logits = torch.tensor([[0.0, 1.0, -1.0, 2.0, 0.5, float("-inf"), 1.5]], device=dev)
+    N, k, B = logits.shape[1], 3, 400000
+    w = torch.exp(logits[0].double().cpu()).tolist()
+    probs = _pl_set_probs(w, k)
+    for name, idx in (("topdown", ops.topdown_sample(logits, B, k, seed=5)),
+                      ("gumbel", ops.gumbel_topk(logits, B, k, 1.0, None, seed=5)["idx"])):
+        idx = idx[0].long().cpu()
+        assert idx.shape == (B, k)
+        assert (idx[:, 1:] > idx[:, :-1]).all()                       # ascending, distinct
+        assert (idx != 5).all()                                       # a zero-probability point is never drawn
+        code = (idx * torch.tensor([N * N, N, 1])).sum(1)
+        chi2, cells = 0.0, 0
+        for key, pr in probs.items():
+            if pr <= 0:
+                continue
+            obs = int((code == key[0] * N * N + key[1] * N + key[2]).sum())
+            chi2 += (obs - B * pr) ** 2 / (B * pr)
+            cells += 1
+        # chi-square with (cells - 1) = 19 degrees of freedom: P(chi2 > 50) < 1.3e-4
+        assert cells == 20 and chi2 < 50.0, (name, chi2)
+
+
+def test_topdown_sampler_full_size_inclusion_frequencies(dev):
+    """C2 size: per-point inclusion frequencies of the top-down sampler against the dense Gumbel kernel (both ~ the
+    same Plackett-Luce law), and basic structure."""
+    from differentiable_ransac_amd import ops, synth
+    d = synth.batch_two_view(2, 2000, seed0=11)
+    lg = d["logits"].to(dev)
+    B, k = 65536, 5
+    a = ops.topdown_sample(lg, B, k, seed=1)
+    b = ops.gumbel_topk(lg, B, k, 1.0, None, seed=2)["idx"]
+    for idx in (a, b):
+        assert idx.shape == (2, B, k) and int(idx.min()) >= 0 and int(idx.max()) < 2000
+        assert (idx[..., 1:] > idx[..., :-1]).all()
+    for p in range(2):
+        fa = torch.bincount(a[p].flatten().long(), minlength=2000).double() / B
+        fb = torch.bincount(b[p].flatten().long(), minlength=2000).double() / B
+        # inclusion probability of a point is a few 1e-3; the difference of two empirical frequencies has
+        # sigma ~ sqrt(2 f / B) ~ 3e-4: 6 sigma bound on the maximum over 2000 points
+        assert (fa - fb).abs().max() < 6 * (2 * fb.max() / B) ** 0.5 + 1e-4
+        # first-order check against the soft-max itself: sum_n f_n = k
+        assert abs(float(fa.sum()) - k) < 1e-9
+    # different hypotheses and different seeds draw different sets; the same seed reproduces
+    assert not torch.equal(a[0, 0], a[0, 1]) or not torch.equal(a[0, 1], a[0, 2])
+    assert torch.equal(a, ops.topdown_sample(lg, B, k, seed=1))
+    assert not torch.equal(a, ops.topdown_sample(lg, B, k, seed=3))
