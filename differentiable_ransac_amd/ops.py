@@ -525,7 +525,7 @@ class _EpisymSums(torch.autograd.Function):
     def forward(ctx, matches, mask, models, valid):
         P, N, _ = matches.shape
         M = models.shape[1]
-        sums = torch.zeros((P, M), device=matches.device, dtype=matches.dtype)
+        sums = torch.empty((P, M), device=matches.device, dtype=matches.dtype)   # every slot is written (invalid: 0)
         mk = None if mask is None else mask.contiguous().view(torch.uint8)
         v = None if valid is None else valid.contiguous().view(torch.uint8)
         L.call("dr_episym_fwd_f32", ptr(matches.contiguous()), ptr(mk), ptr(models.contiguous()), ptr(v), c_int(P), c_int(M),
@@ -540,7 +540,7 @@ class _EpisymSums(torch.autograd.Function):
         mk, v = ctx.aux
         P, N, _ = matches.shape
         M = models.shape[1]
-        gm = torch.zeros_like(models)
+        gm = torch.empty_like(models)   # every slot is written (invalid: 0)
         L.call("dr_episym_bwd_f32", ptr(matches.contiguous()), ptr(mk), ptr(models.contiguous()), ptr(v),
                ptr(g.contiguous()), c_int(P), c_int(M), c_int(N), ptr(gm), stream())
         return None, None, gm, None

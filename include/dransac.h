@@ -254,7 +254,7 @@ int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, 
  * min(ys, 1), ys = (x2^T M x1)^2 (1/((Mx1)_0^2+(Mx1)_1^2+1e-15) + 1/((M^T x2)_0^2+(M^T x2)_1^2+1e-15)).
  * Slots with valid == 0 get 0 (NULL = all valid).  The mean over (models x masked points) and over pairs is the
  * caller's.  Backward: grad_models [P,M,9] from grad_sums [P,M] (the clamp passes no gradient at ys >= 1;
- * invalid slots are left untouched -- zero the buffer first).
+ * invalid slots get 0: every entry of grad_models is written).
  * ------------------------------------------------------------------------------------------ */
 int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid, int P, int M,
                       int N, float *sums, void *stream);
