@@ -137,18 +137,18 @@ __device__ __forceinline__ void triangulate(const double (&R)[9], const double (
                                             double y2, double (&X)[4]) {
   const double a[4] = {x2 * R[6] - R[0], x2 * R[7] - R[1], x2 * R[8] - R[2], x2 * t[2] - t[0]};
   const double c[4] = {y2 * R[6] - R[3], y2 * R[7] - R[4], y2 * R[8] - R[5], y2 * t[2] - t[1]};
-  double g0[4], g1[4], g2[4], g3[4];   // rows of G (symmetric)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    g0[j] = a[0] * a[j] + c[0] * c[j];
-    g1[j] = a[1] * a[j] + c[1] * c[j];
-    g2[j] = a[2] * a[j] + c[2] * c[j];
-    g3[j] = a[3] * a[j] + c[3] * c[j];
-  }
-  g0[0] += 1.0; g1[1] += 1.0;
-  g0[2] -= x1; g2[0] = g0[2];
-  g1[2] -= y1; g2[1] = g1[2];
-  g2[2] += x1 * x1 + y1 * y1;
+  double g0[4], g1[4], g2[4], g3[4];   // rows of G (symmetric: 10 products, mirrored)
+  g0[0] = a[0] * a[0] + c[0] * c[0] + 1.0;
+  g0[1] = a[0] * a[1] + c[0] * c[1];
+  g0[2] = a[0] * a[2] + c[0] * c[2] - x1;
+  g0[3] = a[0] * a[3] + c[0] * c[3];
+  g1[1] = a[1] * a[1] + c[1] * c[1] + 1.0;
+  g1[2] = a[1] * a[2] + c[1] * c[2] - y1;
+  g1[3] = a[1] * a[3] + c[1] * c[3];
+  g2[2] = a[2] * a[2] + c[2] * c[2] + (x1 * x1 + y1 * y1);
+  g2[3] = a[2] * a[3] + c[2] * c[3];
+  g3[3] = a[3] * a[3] + c[3] * c[3];
+  g1[0] = g0[1]; g2[0] = g0[2]; g2[1] = g1[2]; g3[0] = g0[3]; g3[1] = g1[3]; g3[2] = g2[3];
   const Minors2 p = minors2(g0, g1), q = minors2(g2, g3);
   const double c3 = g0[0] + g1[1] + g2[2] + g3[3];
   const double c2 = (g0[0] * g1[1] - g0[1] * g0[1]) + (g0[0] * g2[2] - g0[2] * g0[2]) + (g0[0] * g3[3] - g0[3] * g0[3]) +
@@ -156,12 +156,15 @@ __device__ __forceinline__ void triangulate(const double (&R)[9], const double (
   const double c1 = (g1[1] * q.m23 - g1[2] * q.m13 + g1[3] * q.m12) + (g0[0] * q.m23 - g0[2] * q.m03 + g0[3] * q.m02) +
                     (g3[0] * p.m13 - g3[1] * p.m03 + g3[3] * p.m01) + (g2[0] * p.m12 - g2[1] * p.m02 + g2[2] * p.m01);
   const double c0 = p.m01 * q.m23 - p.m02 * q.m13 + p.m03 * q.m12 + p.m12 * q.m03 - p.m13 * q.m02 + p.m23 * q.m01;
+  // Newton from below; v_rcp_f64 instead of the IEEE division sequence: an inexact step is corrected by the next one
+  // and the final accuracy is that of the last evaluation of the polynomial (10 steps: the distance to the root
+  // shrinks by >= 1/4 per step until the quadratic phase, which takes 3 steps from 1e-2 to 1e-16)
   double lam = 0.0;
 #pragma unroll 1
-  for (int it = 0; it < 12; ++it) {
+  for (int it = 0; it < 10; ++it) {
     const double pv = (((lam - c3) * lam + c2) * lam - c1) * lam + c0;
     const double dp = ((4.0 * lam - 3.0 * c3) * lam + 2.0 * c2) * lam - c1;
-    lam -= (dp != 0.0) ? pv / dp : 0.0;
+    lam -= (dp != 0.0) ? pv * __builtin_amdgcn_rcp(dp) : 0.0;
   }
   g0[0] -= lam; g1[1] -= lam; g2[2] -= lam; g3[3] -= lam;
   const Minors2 u = minors2(g0, g1), w = minors2(g2, g3);
@@ -225,11 +228,13 @@ __global__ __launch_bounds__(kPoseThreads) void pose_error_kernel(const T *__res
           double X[4];
           const double(&R)[9] = r == 0 ? R1 : R2;
           triangulate(R, t, px1[j], py1[j], px2[j], py2[j], X);
-          const double z = X[2] / X[3];
-          const double d = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2] * X[3]) / X[3];
-          // cheirality_check (cv_utils.py:186): Q[2]*Q[3] > 0 & Qh[2] < thr & (P Qh)[2] > 0 & (P Qh)[2] < thr
-          const bool pos = have[j] && z > 0 && z < dist_thr && d > 0 && d < dist_thr;       // (R,  t)
-          const bool neg = have[j] && z < 0 && -z < dist_thr && d < 0 && -d < dist_thr;     // (R, -t): X3 -> -X3
+          // cheirality_check (cv_utils.py:186): Q[2]*Q[3] > 0 & Qh[2] < thr & (P Qh)[2] > 0 & (P Qh)[2] < thr with
+          // Qh = Q / Q[3]; all four compared after multiplying by Q[3]^2 > 0 (no division)
+          const double zw = X[2] * X[3];                                                   // z  = zw / X3^2
+          const double dw = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2] * X[3]) * X[3];   // d2 = dw / X3^2
+          const double lim = dist_thr * (X[3] * X[3]);
+          const bool pos = have[j] && zw > 0 && zw < lim && dw > 0 && dw < lim;       // (R,  t)
+          const bool neg = have[j] && zw < 0 && -zw < lim && dw < 0 && -dw < lim;     // (R, -t): X3 -> -X3
           v[r] += pos ? 1 : 0;
           v[2 + r] += neg ? 1 : 0;
         }
