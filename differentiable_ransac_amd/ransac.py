@@ -223,6 +223,8 @@ class BatchedRANSAC(object):
         if sampling == "topdown" and (train or weighted):
             raise ValueError("top-down sampling yields index sets only: train mode and weighted=1 need the Gumbel sampler")
         self.sampling = sampling
+        self.pipeline = True     # test mode: issue round r+1's sampler/solver on a second stream while round r is scored
+        self._pipe = None
         self.solver = solver
         self.k, self.S = self._SOLVERS[solver]
         self.B = ransac_batch_size
@@ -297,11 +299,30 @@ class BatchedRANSAC(object):
                 with torch.cuda.stream(self._side):
                     pre = ops.refit_essential(matches)
                     matches.record_stream(self._side)
-            for r in range(rounds):
-                g = None if gumbels is None else (gumbels[r] if r < len(gumbels) else None)
-                if gumbels is not None and g is None:
-                    break
-                models, valid, _ = self.hypotheses(matches, logits, g)
+            # Rounds are pipelined: the hypotheses of round r+1 (sampler + solver, latency-bound, independent of round r's
+            # outcome) are issued on a second stream before round r is scored, so they run under K4/K6 and under the
+            # host's "does any pair continue?" read-back.  If round r ends the loop they are simply dropped.
+            main = torch.cuda.current_stream()
+
+            def noise_of(r):
+                return None if gumbels is None else (gumbels[r] if r < len(gumbels) else None)
+
+            def have_round(r):
+                return r < rounds and (gumbels is None or noise_of(r) is not None)
+
+            ahead = None
+            if have_round(0):
+                ahead = self.hypotheses(matches, logits, noise_of(0))[:2]
+            r = 0
+            while ahead is not None:
+                models, valid = ahead
+                ahead = None
+                if self.pipeline and have_round(r + 1):
+                    if self._pipe is None:
+                        self._pipe = torch.cuda.Stream(device=dev)
+                    self._pipe.wait_stream(main)          # inputs (and, for explicit noise, the caller's tensors) are ready
+                    with torch.cuda.stream(self._pipe):
+                        ahead = self.hypotheses(matches, logits, noise_of(r + 1))[:2]
                 flat = models.reshape(P, self.B * self.S, 3, 3)
                 scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks, valid=valid.reshape(P, -1))
                 if self.keep_masks:
@@ -309,9 +330,20 @@ class BatchedRANSAC(object):
                 # K6: arg-max, "better?" test, best mask / inlier count and the adaptive stop of ransac.py:135-142, on the device
                 ops.ransac_update(st, matches, flat, valid.reshape(P, -1), scores, thr, self.B, self.k, self.confidence,
                                   self.eps)
-                # one host sync per round, only when another round could follow
-                if r + 1 < rounds and not bool((st.iters.double() < st.max_iters).any()):
+                r += 1
+                if not have_round(r):
                     break
+                # one host sync per round, only when another round could follow
+                if not bool((st.iters.double() < st.max_iters).any()):
+                    break
+                if ahead is None:
+                    ahead = self.hypotheses(matches, logits, noise_of(r))[:2]
+                else:
+                    main.wait_stream(self._pipe)
+                    for t_ in ahead:
+                        t_.record_stream(main)
+            if ahead is not None and self._pipe is not None:
+                main.wait_stream(self._pipe)              # dropped speculative work: keep the allocator's stream order simple
             best_score, best_model, best_mask, best_inl, iters = (st.best_score, st.best_model, st.best_mask,
                                                                   st.best_inliers, st.iters)
             if self.refit:
