@@ -497,8 +497,8 @@ __global__ __launch_bounds__(kBT) void msac_bwd_kernel(const float *__restrict__
       }
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        const float v = wave_sum(acc[q]);
-        if (lane == 0) part[wv][ml][q] += v;
+        const float v = wave_sum_lane63(acc[q]);
+        if (lane == 63) part[wv][ml][q] += v;
       }
     }
   }
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(kBT) void rigid_residual_bwd_kernel(const float *__
       }
 #pragma unroll
       for (int q = 0; q < 12; ++q) {
-        const float v = wave_sum(acc[q]);
-        if (lane == 0) part[wv][ml][q] += v;
+        const float v = wave_sum_lane63(acc[q]);
+        if (lane == 63) part[wv][ml][q] += v;
       }
     }
   }

@@ -36,6 +36,19 @@ __device__ __forceinline__ T wave_sum(T v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 64 lanes by DPP only (six VALU instructions, no LDS-pipe traffic; __shfl_xor compiles to ds_bpermute):
+// butterfly inside each row of 16 lanes (quad_perm, row_half_mirror, row_mirror), then row_bcast:15 / row_bcast:31.
+// The total is valid in LANE 63 ONLY.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror: row sums
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
       }
 #pragma unroll
       for (int q = 0; q < kV; ++q) {
-        const float v = wave_sum(acc[q][0] + acc[q][1]);
-        if (lane == 0) part[wv][ml][q] += v;
+        const float v = wave_sum_lane63(acc[q][0] + acc[q][1]);
+        if (lane == 63) part[wv][ml][q] += v;
       }
     }
   }
