@@ -97,11 +97,13 @@ __device__ __forceinline__ void essential_residual(const double (&E)[9], double 
 // r(E) is homogeneous of degree 3, hence J u = 3 r ~ 0 and the normal matrix is singular along u; adding u u^T picks the
 // step orthogonal to u.  No chart, no scaling problem when a solution has a vanishing N3 component (|z| -> infinity), and
 // no per-root permutation of the basis (everything is statically indexed).
-__device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&u)[4], bool live) {
-  // two iterations for everybody, then only waves that still hold an unconverged sample go on (max 8)
+// `tol2`: squared residual norm at which a sample stops iterating -- 1e-28 for f64 output (rounding level of the unit-norm
+// E), 1e-20 for f32 output (E to 1e-10, far below the f32 rounding that follows; usually ONE Gauss-Newton step).
+__device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&u)[4], bool live, double tol2) {
+  // one iteration for everybody, then only waves that still hold an unconverged sample go on (max 8)
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
-    if (it >= 2 && !__any(live)) break;
+    if (it >= 1 && !__any(live)) break;
     double E[9], r[10];
 #pragma unroll
     for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
@@ -195,12 +197,12 @@ __device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&
 #pragma unroll
     for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
     const bool better = n1 <= n0 && is_finite(n1);
-    if (better && (live || it < 2)) {
+    if (better && (live || it < 1)) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) u[k] = un[k];
     }
     // |E| = 1: stop at rounding level, or when the residual no longer shrinks geometrically
-    live = live && better && (n1 > 1e-28) && (n1 < 0.25 * n0);
+    live = live && better && (n1 > tol2) && (n1 < 0.25 * n0);
   }
 }
 
@@ -214,7 +216,7 @@ __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double
   double u[4] = {x * inv, y * inv, z * inv, inv};
   bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
   if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
-  polish_homog(nb, u, good);
+  polish_homog(nb, u, good, sizeof(T) == 4 ? 1e-17 : 1e-28);
   double E[9], r[10];
 #pragma unroll
   for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];

@@ -57,12 +57,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const T *pts = samples + (size_t)sc * 20;
   const T *wts = weights ? weights + (size_t)sc * 5 : nullptr;
   double nb[4][9];
+  DR_STAGE_BEGIN();
   fivepoint_basis_minimal<T>(pts, wts, nb);
+  DR_STAGE(0);
   double e[3][3][4];
   basis_to_entries(nb, e);
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
+  DR_STAGE(2);
   nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, half);
+  DR_STAGE(5);
 }
 
 // ---- Stewenius ---------------------------------------------------------------------------------------------

@@ -130,8 +130,12 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
       neg_a[i] = fprev < 0;
       fprev = fhi;
     }
-    const int kBis = (d == D) ? kBisLast : 6;
-    const int kNewt = (d == D) ? kNewtLast : 4;
+#ifndef DR_ROOT_BIS_LOW
+#define DR_ROOT_BIS_LOW 6
+#define DR_ROOT_NEWT_LOW 4
+#endif
+    const int kBis = (d == D) ? kBisLast : DR_ROOT_BIS_LOW;
+    const int kNewt = (d == D) ? kNewtLast : DR_ROOT_NEWT_LOW;
 #pragma unroll 1
     for (int it = 0; it < kBis; ++it) {
 #pragma unroll
@@ -206,7 +210,11 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
 
 // One half of the search (two lanes per sample: the even lane takes |z| <= 1, the odd lane |z| > 1 through the reversed
 // polynomial).  roots[0..count-1] dense.
-template <int D, int kBisLast = 10, int kNewtLast = 6>
+#ifndef DR_ROOT_BIS_LAST
+#define DR_ROOT_BIS_LAST 10
+#define DR_ROOT_NEWT_LAST 6
+#endif
+template <int D, int kBisLast = DR_ROOT_BIS_LAST, int kNewtLast = DR_ROOT_NEWT_LAST>
 __device__ __forceinline__ void real_roots_half(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count) {
   double cmax = 0;
 #pragma unroll
