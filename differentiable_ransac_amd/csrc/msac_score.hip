@@ -399,6 +399,9 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 // Same algorithm with a lane owning 16 consecutive points (64 VGPRs), 128-thread blocks (two waves cover 2048 points):
 // every mask row segment is one 16-byte store per lane (1 KiB per wave instruction) -- the mask stream is store-ISSUE
 // bound with 8-byte stores.  Requires N % 16 == 0 (otherwise the 8-point kernel above is used).
+#ifndef DR_K4_TILE16
+#define DR_K4_TILE16 64   // model slots per block (multiple of 32)
+#endif
 constexpr int kT16 = 128, kP16 = 16, kChunk16 = kT16 * kP16;
 
 __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
                                                                      float *__restrict__ scores,
                                                                      uint8_t *__restrict__ masks, int write_masks,
                                                                      int chunks_per_block, int use_atomic) {
-  constexpr int kTile = 64;
+  constexpr int kTile = DR_K4_TILE16;
   __shared__ float part[kT16 / kWave][kTile];
   const int p = blockIdx.z;
   const int m0 = blockIdx.x * kTile;
@@ -680,7 +683,7 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
                       T *scores, uint8_t *masks, hipStream_t st) {
   constexpr bool kFast = sizeof(T) == 4;
   const bool fast16 = kFast && DR_K4_FAST16 && (N % 16 == 0);
-  const int tile = fast16 ? 64 : (kFast ? kFastTile : kModelsPerBlock);
+  const int tile = fast16 ? DR_K4_TILE16 : (kFast ? kFastTile : kModelsPerBlock);
   const int tiles = (M + tile - 1) / tile;
   const int chunks = (N + kChunk - 1) / kChunk;   // kChunk16 == kChunk
   // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip

@@ -8,7 +8,7 @@ variants = [int(a) for a in args] or [0]
 if '--build' in sys.argv:
     for v in variants:
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-                               '-ffp-contract=fast', f'-DDR_K4_VARIANT={v % 100}', *(['-DDR_K4_NOREDUCE'] if v // 100 == 7 else []), *(['-DDR_K4_BPERMUTE_SUM'] if v // 100 == 8 else []), *(['-fno-slp-vectorize'] if v == 9 else []), '-o', f'scratch/libk4_v{v}.so',
+                               '-ffp-contract=fast', f'-DDR_K4_VARIANT={v % 100}', *(['-DDR_K4_NOREDUCE'] if v // 100 == 7 else []), *(['-DDR_K4_BPERMUTE_SUM'] if v // 100 == 8 else []), *([f'-DDR_K4_TILE16={32 * (v // 1000)}'] if v >= 1000 else []), *(['-fno-slp-vectorize'] if v == 9 else []), '-o', f'scratch/libk4_v{v}.so',
                                'differentiable_ransac_amd/csrc/msac_score.hip', 'differentiable_ransac_amd/csrc/dr_core.hip'])
     sys.exit(0)
 import torch
