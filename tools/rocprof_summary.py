@@ -2,7 +2,10 @@
 """Turns a rocprofv3 (rocpd sqlite) capture into the per-kernel summary kept under profiles/.
 
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py ...
-    python tools/rocprof_summary.py gpurun_out/prof/bench_results.db profiles/rNN_bench_kernel_stats.md "command line"
+    python tools/rocprof_summary.py gpurun_out/prof/bench_results.db profiles/rNN_bench_kernel_stats.md "command line" [first N | skip N]
+
+`first N` / `skip N`: statistics over the first N dispatches of every kernel only (or over everything after them) --
+bench.py runs its warm-up + timed region first and an informational two-streams region afterwards.
 """
 import sqlite3
 import sys
@@ -11,23 +14,31 @@ import sys
 def main():
     db, out = sys.argv[1], sys.argv[2]
     cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+    mode, n = (sys.argv[4], int(sys.argv[5])) if len(sys.argv) > 5 else ("all", 0)
     c = sqlite3.connect(db)
-    rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    extra = {}
-    for name, vg, sg, lds, gx, gy, gz, wx in c.execute(
-            "select name, max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(grid_y), max(grid_z), "
-            "max(workgroup_x) from kernels group by name"):
-        extra[name] = (vg, sg, lds, gx, gy, gz, wx)
-    mn = {n: (a, b) for n, a, b in c.execute("select name, min(duration), max(duration) from kernels group by name")}
+    per = {}
+    for name, dur, vg, sg, lds, gx, gy, gz, wx in c.execute(
+            "select name, duration, vgpr_count, sgpr_count, lds_size, grid_x, grid_y, grid_z, workgroup_x from kernels "
+            "order by start"):
+        per.setdefault(name, []).append((dur, vg, sg, lds, gx, gy, gz, wx))
+    rows = []
+    for name, lst in per.items():
+        sel = lst[:n] if mode == "first" else (lst[n:] if mode == "skip" else lst)
+        if not sel:
+            continue
+        durs = [x[0] for x in sel]
+        rows.append((name, len(durs), sum(durs) / 1e3, sum(durs) / len(durs) / 1e3, min(durs) / 1e3, max(durs) / 1e3, sel[0][1:]))
+    total = sum(r[2] for r in rows) or 1.0
+    rows.sort(key=lambda r: -r[2])
     with open(out, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
+        if mode != "all":
+            f.write(f"dispatches: {'the first' if mode == 'first' else 'all after the first'} {n} of every kernel\n\n")
         f.write("| kernel | calls | total (us) | avg (us) | min (us) | max (us) | % | VGPR | SGPR | LDS (B) | grid | block |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
-        for name, calls, tot, avg, pct in rows:
+        for name, calls, tot, avg, lo, hi, (vg, sg, lds, gx, gy, gz, wx) in rows:
             short = name if len(name) < 110 else name[:107] + "..."
-            vg, sg, lds, gx, gy, gz, wx = extra.get(name, (0,) * 7)
-            lo, hi = mn.get(name, (0, 0))
-            f.write(f"| `{short}` | {calls} | {tot:.1f} | {avg:.2f} | {lo / 1e3:.2f} | {hi / 1e3:.2f} | {pct:.2f} | {vg} | {sg} | "
+            f.write(f"| `{short}` | {calls} | {tot:.1f} | {avg:.2f} | {lo:.2f} | {hi:.2f} | {100 * tot / total:.2f} | {vg} | {sg} | "
                     f"{lds} | {gx}x{gy}x{gz} | {wx} |\n")
     print("wrote", out)
 
