@@ -34,7 +34,8 @@
 // LDS and flushed as one line-aligned contiguous range: 5.4 TB/s as a pure store pattern) runs at 2 waves/SIMD and loses:
 // 278 us.  Mask rows padded to a 2048-byte stride (every row store a whole number of lines): 226 us, no gain -- the row
 // alignment is not what the stream costs.  Decomposition at 224 us: arithmetic alone 165 us, + packing/storing the valid
-// rows 26 us, + zero rows of the invalid slots 33 us.
+// rows 26 us, + zero rows of the invalid slots 33 us.  Zero rows written by separate store-only blocks interleaved in the
+// grid (blockIdx.x & 1): 341 us -- the role branch wrecks the code generated for the evaluating path.
 #include "dr_common.hpp"
 
 namespace dr {
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;
         if (write_masks && have) *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + cur) * N + n0) = q;
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
-        if (lane == 63) part[wv][cur] += finite ? a : NAN;
+        if (lane == 63) atomicAdd(&part[wv][cur], finite ? a : NAN);   // ds_add_f32, no return: nothing to wait for (-2 %)
         if (!more) break;
       }
     }
