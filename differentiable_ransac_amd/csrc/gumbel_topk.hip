@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
                                                          const T *__restrict__ lse, const T *__restrict__ a_sel,
                                                          T *__restrict__ grad_logits, int rows_per_block) {
   // one thread per 4-point group of pair p (one Philox call regenerates its noise); blockIdx.z owns a chunk of
-  // `rows_per_block` hypothesis rows (their k winners / a values / <y,a> are staged in LDS) and adds its partial sums
+  // `rows_per_block` hypothesis rows (their lse and <y,a> are staged in LDS) and adds its partial sums
   // into grad_logits with one atomicAdd per point: (groups/256) x P x (B/rows_per_block) blocks fill the chip, where a
   // single block per point group would leave 3/4 of the CUs idle at C2.
   const int p = blockIdx.y;
@@ -299,9 +299,8 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *s_dot = reinterpret_cast<T *>(smem_raw);               // [256]   sum_m y_m a_m per row
   T *s_lse = s_dot + 256;
-  T *s_a = s_lse + 256;                                     // [256][kMaxK]
-  int *s_i = reinterpret_cast<int *>(s_a + 256 * kMaxK);    // [256][kMaxK]
   const int groups = (a.N + 3) >> 2;
+  const bool unit_tau = a.tau == T(1);   // wave-uniform: x / 1 == x exactly, skip the IEEE division sequence
   T l[4], acc[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -317,11 +316,9 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
       const T ls = lse[row];
       T dot = T(0);
       for (int j = 0; j < kMaxK; ++j) {
-        T av = T(0);
-        int i = -1;
         if (j < a.k) {
-          i = idx[row * a.k + j];
-          av = a_sel[row * a.k + j];
+          const int i = idx[row * a.k + j];
+          const T av = a_sel[row * a.k + j];
           // y at the selected index is recomputed from (logit, noise): y = exp(g - lse)
           T nz;
           if (a.gumbel) nz = a.gumbel[row * a.N + i];
@@ -331,10 +328,12 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
             nz = gumbel_from_bits_t<T>(r[i & 3]);
           }
           const T li = a.logits ? a.logits[(size_t)p * a.N + i] : T(1);
-          dot += exp_t<T>((li + nz) / a.tau - ls) * av;
+          const T yi = exp_t<T>((unit_tau ? (li + nz) : (li + nz) / a.tau) - ls);
+          dot += yi * av;
+          // the "+ y a" term exists only at the k selected points of a row: added here, once (by the first point-group
+          // block), instead of comparing every point of the row against the k winners in the main loop
+          if (blockIdx.x == 0) atomicAdd(grad_logits + (size_t)p * a.N + i, unit_tau ? yi * av : yi * av / a.tau);
         }
-        s_a[threadIdx.x * kMaxK + j] = av;
-        s_i[threadIdx.x * kMaxK + j] = i;
       }
       s_dot[threadIdx.x] = dot;
       s_lse[threadIdx.x] = ls;
@@ -356,12 +355,8 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
         const T ls = s_lse[r], dot = s_dot[r];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int n = 4 * q + j;
-          const T y = exp_t<T>((l[j] + nz[j]) / a.tau - ls);
-          T an = T(0);
-#pragma unroll
-          for (int t = 0; t < kMaxK; ++t) an += (s_i[r * kMaxK + t] == n) ? s_a[r * kMaxK + t] : T(0);
-          acc[j] += y * (an - dot);
+          const T y = exp_t<T>((unit_tau ? (l[j] + nz[j]) : (l[j] + nz[j]) / a.tau) - ls);
+          acc[j] -= y * dot;
         }
       }
     }
@@ -544,7 +539,7 @@ int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t se
   DR_REQUIRE(idx && lse && a_sel && grad_logits, "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
   dr::GumbelArgs<float> a{logits, gumbel, seed, tau, P, B, N, k};
-  const size_t smem = sizeof(float) * (256 * 2 + 256 * dr::kMaxK) + sizeof(int) * 256 * dr::kMaxK;
+  const size_t smem = sizeof(float) * 256 * 2;
   const int gx = ((N + 3) / 4 + 255) / 256;
   // enough row chunks to put >= ~2048 blocks on the chip, at least 32 rows each
   int chunks = (int)std::min<long>((B + 31) / 32, std::max<long>(1, 2048 / std::max<long>(1, (long)gx * P)));
