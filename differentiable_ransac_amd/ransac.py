@@ -314,6 +314,8 @@ class BatchedRANSAC(object):
                     chosen, which = ops.select_closest_autograd(models, valid, gt_model)
                     keep = which >= 0
                 out.append((chosen, keep))
+            if len(out) == 1:            # one batch (train.py's max_iters = 100 with -rbs >= 100): nothing to concatenate
+                return out[0]
             return torch.cat([c for c, _ in out], dim=1), torch.cat([k for _, k in out], dim=1)
 
         with torch.no_grad():
