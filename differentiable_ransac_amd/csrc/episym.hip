@@ -8,14 +8,17 @@
 
 namespace dr {
 
-constexpr int kET = 256, kEP = 8, kEChunk = kET * kEP, kEM = 16;
+constexpr int kET = 256, kEP = 8, kEChunk = kET * kEP, kEM = 8;   // 8 models per block = 2 per wave
+constexpr int kEPw = 16, kEPass = 64 * kEPw;                          // a wave holds 16 points per lane per pass
 typedef float ev2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ev2 esplat(float a) { return (ev2){a, a}; }
 
-// v2: (1) the points selected by the mask (the GT inliers: half of the points at C2) are compacted per block, so no
-// lane evaluates a point whose weight is 0; compact position j*256 + tid, i.e. the unrolled point loop ends at a
-// block-uniform j; (2) packed f32 arithmetic on point pairs and v_rcp_f32 (1 ulp) instead of the IEEE division
-// sequence.  At C5 size (32 x 1024 models x 1000 masked points) the train step went from 0.83 to 0.66 ms (one stream).
+// v3 (v2 = mask compaction + packed f32 + v_rcp_f32).  The points selected by the mask (the GT inliers: half of the points
+// at C2) are compacted per block, so no lane evaluates a point whose weight is 0.  Each WAVE then takes its own two models
+// of the block's tile over ALL compacted points (16 per lane per pass of 1024): the nine gradient accumulators of a
+// model are reduced once per wave (DPP) instead of once per 256-lane slice of the points -- with ~1000 selected points a
+// lane used to hold 4 of them per model and the reductions were 37 % of the instructions.  No LDS partials, no
+// cross-wave reduction.
 template <bool kBackward>
 __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ matches, const uint8_t *__restrict__ mask,
                                                      const float *__restrict__ models, const uint8_t *__restrict__ valid,
@@ -23,15 +26,28 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
                                                      float *__restrict__ out) {
   // forward: out = sums [P,M]; backward: out = grad_models [P,M,9]
   constexpr int kV = kBackward ? 9 : 1;
-  __shared__ float part[kET / 64][kEM][kV];
+  constexpr int kMW = kEM / (kET / 64);   // models per wave
   __shared__ int s_list[kEChunk];
   __shared__ int s_wave[kET / 64];
   const int p = blockIdx.z, m0 = blockIdx.x * kEM;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int mcount = min(kEM, M - m0);
-  for (int i = tid; i < (kET / 64) * kEM * kV; i += kET) (&part[0][0][0])[i] = 0.f;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the model coefficients below live in SGPRs
   const float *mt = matches + (size_t)p * N * 4;
   const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
+  ev2 acc[kMW][kV];
+#pragma unroll
+  for (int mi = 0; mi < kMW; ++mi)
+#pragma unroll
+    for (int q = 0; q < kV; ++q) acc[mi][q] = esplat(0.f);
+  float mcoef[kMW][9];
+  bool mlive[kMW];
+#pragma unroll
+  for (int mi = 0; mi < kMW; ++mi) {
+    const int m = m0 + wv * kMW + mi;
+    mlive[mi] = m < M && (!valid || valid[(size_t)p * M + m] != 0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mcoef[mi][q] = mlive[mi] ? models[((size_t)p * M + m) * 9 + q] : 0.f;
+  }
   for (int c0 = 0; c0 < N; c0 += kEChunk) {
     // ---- compact the selected points of this chunk: s_list[0..T) = their indices, ascending
     int T = min(kEChunk, N - c0);
@@ -63,75 +79,72 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
         if ((bits >> j) & 1u) s_list[pos++] = c0 + tid * kEP + j;
       __syncthreads();
     }
-    ev2 x1[kEP / 2], y1[kEP / 2], x2[kEP / 2], y2[kEP / 2], w[kEP / 2];
+    for (int p0 = 0; p0 < T; p0 += kEPass) {
+      ev2 x1[kEPw / 2], y1[kEPw / 2], x2[kEPw / 2], y2[kEPw / 2], w[kEPw / 2];
 #pragma unroll
-    for (int j = 0; j < kEP; ++j) {
-      const int pos = j * kET + tid;
-      const bool have = pos < T;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (have) v = reinterpret_cast<const float4 *>(mt)[mk ? s_list[pos] : c0 + pos];
-      x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
-      w[j / 2][j & 1] = have ? 1.f : 0.f;
-    }
-    for (int ml = 0; ml < mcount; ++ml) {
-      if (valid && !valid[(size_t)p * M + m0 + ml]) continue;
-      float m[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) m[q] = models[((size_t)p * M + m0 + ml) * 9 + q];
-      ev2 acc[kV];
-#pragma unroll
-      for (int q = 0; q < kV; ++q) acc[q] = esplat(0.f);
-#pragma unroll
-      for (int j = 0; j < kEP / 2; ++j) {
-        if (2 * j * kET >= T) break;   // block-uniform: the compact positions of this and all later pairs are empty
-        const ev2 a0 = x2[j] * esplat(m[0]) + (y2[j] * esplat(m[3]) + esplat(m[6]));
-        const ev2 a1 = x2[j] * esplat(m[1]) + (y2[j] * esplat(m[4]) + esplat(m[7]));
-        const ev2 a2 = x2[j] * esplat(m[2]) + (y2[j] * esplat(m[5]) + esplat(m[8]));
-        const ev2 b0 = x1[j] * esplat(m[0]) + (y1[j] * esplat(m[1]) + esplat(m[2]));
-        const ev2 b1 = x1[j] * esplat(m[3]) + (y1[j] * esplat(m[4]) + esplat(m[5]));
-        const ev2 r = x1[j] * a0 + (y1[j] * a1 + a2);
-        const ev2 db = b0 * b0 + (b1 * b1 + esplat(1e-15f)), da = a0 * a0 + (a1 * a1 + esplat(1e-15f));
-        ev2 ib, ia;
-        ib[0] = __builtin_amdgcn_rcpf(db[0]); ib[1] = __builtin_amdgcn_rcpf(db[1]);
-        ia[0] = __builtin_amdgcn_rcpf(da[0]); ia[1] = __builtin_amdgcn_rcpf(da[1]);
-        const ev2 rr = r * r, s = ib + ia;
-        const ev2 ys = rr * s;
-        if (!kBackward) {
-          ev2 cl;
-          cl[0] = fminf(ys[0], 1.0f); cl[1] = fminf(ys[1], 1.0f);
-          acc[0] = cl * w[j] + acc[0];
-        } else {
-          ev2 live;   // the clamp passes no gradient at or above 1
-          live[0] = ys[0] < 1.0f ? w[j][0] : 0.f;
-          live[1] = ys[1] < 1.0f ? w[j][1] : 0.f;
-          // d ys = c1 dr - cb (b0 db0 + b1 db1) - ca (a0 da0 + a1 da1), dr = x2^T dM x1, db = (dM x1)_{0,1}, da = (dM^T x2)_{0,1}
-          const ev2 r2l = (r + r) * live;
-          const ev2 c1 = r2l * s, cb = r2l * r * (ib * ib), ca = r2l * r * (ia * ia);
-          const ev2 u0 = c1 * x2[j] - cb * b0, u1 = c1 * y2[j] - cb * b1, v0 = ca * a0, v1 = ca * a1;
-          acc[0] = acc[0] + (x1[j] * u0 - v0 * x2[j]);
-          acc[1] = acc[1] + (y1[j] * u0 - v1 * x2[j]);
-          acc[2] = acc[2] + u0;
-          acc[3] = acc[3] + (x1[j] * u1 - v0 * y2[j]);
-          acc[4] = acc[4] + (y1[j] * u1 - v1 * y2[j]);
-          acc[5] = acc[5] + u1;
-          acc[6] = acc[6] + (x1[j] * c1 - v0);
-          acc[7] = acc[7] + (y1[j] * c1 - v1);
-          acc[8] = acc[8] + c1;
-        }
+      for (int j = 0; j < kEPw; ++j) {
+        const int pos = p0 + j * 64 + lane;
+        const bool have = pos < T;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) v = reinterpret_cast<const float4 *>(mt)[mk ? s_list[pos] : c0 + pos];
+        x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+        w[j / 2][j & 1] = have ? 1.f : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < kV; ++q) {
-        const float v = wave_sum_lane63(acc[q][0] + acc[q][1]);
-        if (lane == 63) part[wv][ml][q] += v;
+      for (int mi = 0; mi < kMW; ++mi) {
+        if (!mlive[mi]) continue;   // wave-uniform
+        const float(&m)[9] = mcoef[mi];
+#pragma unroll
+        for (int j = 0; j < kEPw / 2; ++j) {
+          if (p0 + 2 * j * 64 >= T) break;   // wave-uniform: the positions of this and all later pairs are empty
+          const ev2 a0 = x2[j] * esplat(m[0]) + (y2[j] * esplat(m[3]) + esplat(m[6]));
+          const ev2 a1 = x2[j] * esplat(m[1]) + (y2[j] * esplat(m[4]) + esplat(m[7]));
+          const ev2 a2 = x2[j] * esplat(m[2]) + (y2[j] * esplat(m[5]) + esplat(m[8]));
+          const ev2 b0 = x1[j] * esplat(m[0]) + (y1[j] * esplat(m[1]) + esplat(m[2]));
+          const ev2 b1 = x1[j] * esplat(m[3]) + (y1[j] * esplat(m[4]) + esplat(m[5]));
+          const ev2 r = x1[j] * a0 + (y1[j] * a1 + a2);
+          const ev2 db = b0 * b0 + (b1 * b1 + esplat(1e-15f)), da = a0 * a0 + (a1 * a1 + esplat(1e-15f));
+          ev2 ib, ia;
+          ib[0] = __builtin_amdgcn_rcpf(db[0]); ib[1] = __builtin_amdgcn_rcpf(db[1]);
+          ia[0] = __builtin_amdgcn_rcpf(da[0]); ia[1] = __builtin_amdgcn_rcpf(da[1]);
+          const ev2 rr = r * r, s = ib + ia;
+          const ev2 ys = rr * s;
+          if (!kBackward) {
+            ev2 cl;
+            cl[0] = fminf(ys[0], 1.0f); cl[1] = fminf(ys[1], 1.0f);
+            acc[mi][0] = cl * w[j] + acc[mi][0];
+          } else {
+            ev2 live;   // the clamp passes no gradient at or above 1
+            live[0] = ys[0] < 1.0f ? w[j][0] : 0.f;
+            live[1] = ys[1] < 1.0f ? w[j][1] : 0.f;
+            // d ys = c1 dr - cb (b0 db0 + b1 db1) - ca (a0 da0 + a1 da1), dr = x2^T dM x1, db = (dM x1)_{0,1}, da = (dM^T x2)_{0,1}
+            const ev2 r2l = (r + r) * live;
+            const ev2 c1 = r2l * s, cb = r2l * r * (ib * ib), ca = r2l * r * (ia * ia);
+            const ev2 u0 = c1 * x2[j] - cb * b0, u1 = c1 * y2[j] - cb * b1, v0 = ca * a0, v1 = ca * a1;
+            acc[mi][0] = acc[mi][0] + (x1[j] * u0 - v0 * x2[j]);
+            acc[mi][1] = acc[mi][1] + (y1[j] * u0 - v1 * x2[j]);
+            acc[mi][2] = acc[mi][2] + u0;
+            acc[mi][3] = acc[mi][3] + (x1[j] * u1 - v0 * y2[j]);
+            acc[mi][4] = acc[mi][4] + (y1[j] * u1 - v1 * y2[j]);
+            acc[mi][5] = acc[mi][5] + u1;
+            acc[mi][6] = acc[mi][6] + (x1[j] * c1 - v0);
+            acc[mi][7] = acc[mi][7] + (y1[j] * c1 - v1);
+            acc[mi][8] = acc[mi][8] + c1;
+          }
+        }
       }
     }
   }
-  __syncthreads();
-  for (int i = tid; i < mcount * kV; i += kET) {
-    const int ml = i / kV, q = i % kV;
-    float v = part[0][ml][q] + part[1][ml][q] + part[2][ml][q] + part[3][ml][q];
-    if (kBackward) v *= grad_sums[(size_t)p * M + m0 + ml];
-    out[((size_t)p * M + m0 + ml) * kV + q] = v;
+#pragma unroll
+  for (int mi = 0; mi < kMW; ++mi) {
+    const int m = m0 + wv * kMW + mi;
+    if (m >= M) continue;
+    const float gs = kBackward ? grad_sums[(size_t)p * M + m] : 1.f;
+#pragma unroll
+    for (int q = 0; q < kV; ++q) {
+      const float v = wave_sum_lane63(acc[mi][q][0] + acc[mi][q][1]);
+      if (lane == 63) out[((size_t)p * M + m) * kV + q] = v * gs;
+    }
   }
 }
 
