@@ -70,17 +70,27 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
 #pragma unroll
     for (int d = 0; d < 4; ++d) gacc[k][d] = 0;
   }
-  for (int slot = 0; slot < 10; ++slot) {
-    if (!valid[(size_t)s * 10 + slot]) continue;
+  // Each lane walks ITS OWN list of slots that carry a gradient (valid and non-zero): round r of the loop serves the r-th
+  // such slot of every lane at once.  In the training path exactly one slot per sample has a gradient (the model picked
+  // by K5), so the body runs once per wave with all lanes busy instead of once per slot index with 1 lane in 4.
+  int next = 0;
+  while (true) {
+    int slot = -1;
+    for (; next < 10 && slot < 0; ++next) {
+      if (!valid[(size_t)s * 10 + next]) continue;
+      float gn = 0.f;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) gn += fabsf(grad_models[((size_t)s * 10 + next) * 9 + q]);
+      if (gn > 0.f) slot = next;
+    }
+    if (!__any(slot >= 0)) break;
+    if (slot < 0) continue;
     double E[3][3], g[3][3];
-    double gn = 0;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       E[q / 3][q % 3] = models[((size_t)s * 10 + slot) * 9 + q];
       g[q / 3][q % 3] = grad_models[((size_t)s * 10 + slot) * 9 + q];
-      gn += fabs(g[q / 3][q % 3]);
     }
-    if (!(gn > 0)) continue;
     // tangent directions J_c (3x3 each): c<3: [e_c]x E ; c>=3: E [e_{c-3}]x
     double J[6][3][3];
 #pragma unroll
