@@ -211,6 +211,7 @@ class SampleGather(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, matches, logits, B, k, tau, gumbel, seed):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         r = gumbel_topk(logits, B, k, tau, gumbel, seed)
         samples = gather(matches, r["idx"], r["y_sel"])
         ctx.save_for_backward(matches, logits, r["idx"], r["y_sel"], r["lse"], gumbel if gumbel is not None else
@@ -221,7 +222,11 @@ class SampleGather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_samples, g_w, _g_idx):
+        if g_samples is None and g_w is None:
+            return (None,) * 7
         matches, logits, idx, y_sel, lse, gumbel = ctx.saved_tensors
+        if g_samples is None:
+            g_samples = torch.zeros(idx.shape + (matches.shape[-1],), device=matches.device, dtype=matches.dtype)
         tau, seed, has_noise = ctx.cfg
         if logits.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
@@ -350,6 +355,7 @@ class _SolveEssential(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, samples, weights, which):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         fn = (lambda s_, w_: solve_nister5(s_, w_)) if which == "nister" else (lambda s_, w_: solve_stewenius5(s_))
         need_grad = samples.requires_grad and samples.dtype == torch.float32
         if need_grad:
@@ -367,6 +373,8 @@ class _SolveEssential(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_models, _g_valid):
+        if g_models is None:
+            return None, None, None
         samples, models, m64, valid = ctx.saved_tensors
         if not ctx.minimal:
             raise L.DransacError("backward of the non-minimal five-point fallback is not defined (refit is test-mode only)")
@@ -387,6 +395,7 @@ def solve_essential(samples, weights=None, which="nister"):
 class _SolveF8(torch.autograd.Function):
     @staticmethod
     def forward(ctx, samples, weights):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         F, valid = solve_f8(samples, weights)
         ctx.save_for_backward(samples, weights if weights is not None else torch.empty(0, device=samples.device), F)
         ctx.has_w = weights is not None
@@ -395,6 +404,8 @@ class _SolveF8(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gF, _gv):
+        if gF is None:
+            return None, None
         samples, weights, F = ctx.saved_tensors
         if samples.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
@@ -414,6 +425,7 @@ def solve_fundamental8(samples, weights=None):
 class _SolveRigid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, samples, weights, flag):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         out = solve_rigid(samples, weights, flag)
         ctx.save_for_backward(samples, out[0])
         ctx.flag = flag
@@ -423,6 +435,8 @@ class _SolveRigid(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_model, g_R, g_t, g_scale, _gv):
+        if g_model is None and g_R is None and g_t is None:
+            return None, None, None
         samples, model = ctx.saved_tensors
         if samples.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
@@ -447,6 +461,7 @@ def solve_rigid_autograd(samples, weights=None, flag=True):
 class _MsacScore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, matches, models, thr, want_masks):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         scores, masks = msac_score(matches, models, thr, want_masks)
         ctx.save_for_backward(matches, models, thr)
         if masks is not None:
@@ -455,6 +470,8 @@ class _MsacScore(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_scores, _gm):
+        if g_scores is None:
+            return None, None, None, None
         matches, models, thr = ctx.saved_tensors
         if matches.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
@@ -474,6 +491,7 @@ def msac_score_autograd(matches, models, threshold, want_masks=True):
 class _RigidResidual(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, models, threshold):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         res, masks = rigid_residual(pts, models, threshold, True)
         ctx.save_for_backward(pts, models)
         ctx.mark_non_differentiable(masks)
@@ -481,6 +499,8 @@ class _RigidResidual(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_res, _gm):
+        if g_res is None:
+            return None, None, None
         pts, models = ctx.saved_tensors
         if pts.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
@@ -499,6 +519,7 @@ def rigid_residual_autograd(pts, models, threshold=0.03):
 class _SelectClosest(torch.autograd.Function):
     @staticmethod
     def forward(ctx, models, valid, gt):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         chosen, which = select_closest(models, valid, gt)
         ctx.save_for_backward(which)
         ctx.shape = models.shape
@@ -507,6 +528,8 @@ class _SelectClosest(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_chosen, _gw):
+        if g_chosen is None:
+            return None, None, None
         (which,) = ctx.saved_tensors
         P, B, S = ctx.shape[:3]
         g = torch.empty(ctx.shape, device=g_chosen.device, dtype=g_chosen.dtype)
@@ -523,6 +546,7 @@ def select_closest_autograd(models, valid, gt):
 class _EpisymSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, matches, mask, models, valid):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         P, N, _ = matches.shape
         M = models.shape[1]
         sums = torch.empty((P, M), device=matches.device, dtype=matches.dtype)   # every slot is written (invalid: 0)
@@ -536,6 +560,8 @@ class _EpisymSums(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
         matches, models = ctx.saved_tensors
         mk, v = ctx.aux
         P, N, _ = matches.shape
@@ -558,6 +584,7 @@ def episym_sums(matches, mask, models, valid=None):
 class _PoseError(torch.autograd.Function):
     @staticmethod
     def forward(ctx, matches, models, gt_R, gt_t, distance_threshold, want_votes):
+        ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         P, N, _ = matches.shape
         M = models.shape[1]
         dev, dt = matches.device, matches.dtype
@@ -578,6 +605,8 @@ class _PoseError(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_R, g_t, _gw, _gv):
+        if g_R is None and g_t is None:
+            return (None,) * 6
         models, gt_R, gt_t, which = ctx.saved_tensors
         P, M = which.shape
         gm = torch.empty_like(models)
