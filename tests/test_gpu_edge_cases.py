@@ -91,3 +91,50 @@ def test_f64_end_to_end(dev):
         assert abs(float(out["score"][p]) - score) <= 1e-6 * max(1.0, score)
         assert torch.equal(out["mask"][p].cpu(), mask)
         assert (O.canonical(out["model"][p].cpu()) - O.canonical(m)).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("P,N,M,masked", [(1, 7, 1, True), (2, 33, 5, False), (3, 1030, 19, True), (1, 2500, 9, True)])
+def test_match_loss_kernel_odd_sizes(dev, P, N, M, masked):
+    """MatchLoss kernels on ragged sizes (N not a multiple of the lane tile, more than one 2048-point chunk, model count
+    not a multiple of the block tile, no mask, empty mask) against the oracle, forward and backward."""
+    from differentiable_ransac_amd import ops
+    g = torch.Generator().manual_seed(P * 1000 + N)
+    m = (torch.rand(P, N, 4, generator=g) - 0.5)
+    E = torch.randn(P, M, 3, 3, generator=g)
+    mask = (torch.rand(P, N, generator=g) < 0.5) if masked else None
+    if masked:
+        mask[0] = False                      # a pair without a single selected point
+    valid = torch.rand(P, M, generator=g) < 0.8
+    Ed = E.clone().to(dev).requires_grad_(True)
+    sums = ops.episym_sums(m.to(dev), None if mask is None else mask.to(dev), Ed, valid.to(dev))
+    wts = torch.rand(P, M, generator=g)
+    (sums * wts.to(dev)).sum().backward()
+    Eo = E.double().clone().requires_grad_(True)
+    tot = 0
+    for p in range(P):
+        sel = mask[p] if mask is not None else torch.ones(N, dtype=torch.bool)
+        ys = O.episym(m[p, sel, :2].double(), m[p, sel, 2:].double(), Eo[p])
+        want = torch.clamp(ys, max=1.0).sum(1) * valid[p]
+        assert torch.allclose(sums[p].detach().cpu().double(), want.detach(), rtol=2e-4, atol=1e-5)
+        tot = tot + (want * wts[p].double()).sum()
+    if tot.requires_grad:
+        tot.backward()
+        ref = Eo.grad
+        got = Ed.grad.cpu().double()
+        assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6
+
+
+def test_pose_error_and_topdown_tiny_sizes(dev):
+    from differentiable_ransac_amd import ops, synth
+    d = synth.two_view_pair(3, 9, dtype=torch.float64)
+    E = torch.stack((d["gt_E"], d["gt_E"] + 0.01 * torch.eye(3, dtype=torch.float64)))[None].to(dev)
+    eq, et, which, votes = ops.pose_error(d["matches"][None].to(dev), E, d["R"][None].to(dev), d["t"][None].to(dev), want_votes=True)
+    oq, ot, ow = O.pose_error(E[0].cpu(), d["matches"], d["R"], d["t"])
+    assert torch.equal(which[0].cpu().long(), ow) and (eq[0].cpu() - oq).abs().max() < 1e-5 and int(votes.sum(-1).max()) <= 9
+    # top-down draw: k == N takes every point; one point with all the mass is always drawn
+    idx = ops.topdown_sample(torch.zeros(2, 5, device=dev), 64, 5, seed=1)
+    assert (idx == torch.arange(5, device=dev, dtype=torch.int32)).all()
+    lg = torch.full((1, 40), -30.0, device=dev)
+    lg[0, 17] = 30.0
+    idx = ops.topdown_sample(lg, 256, 3, seed=2)
+    assert (idx == 17).any(-1).all() and (idx[..., 1:] > idx[..., :-1]).all()
