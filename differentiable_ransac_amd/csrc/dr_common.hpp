@@ -49,6 +49,25 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Maximum over the 64 lanes by DPP, broadcast to every lane through an SGPR (v_readlane of lane 63).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_max_step(float x) {
+  const int xi = __float_as_int(x);
+  return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, kCtrl, kRowMask, 0xF, false)));
+}
+__device__ __forceinline__ float wave_max_bcast(float v) {
+  v = dpp_max_step<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_max_step<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_max_step<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_max_step<0x140, 0xF>(v);   // row_mirror: row maxima
+  v = dpp_max_step<0x142, 0xA>(v);   // row_bcast:15 -> rows 1, 3
+  v = dpp_max_step<0x143, 0xC>(v);   // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll

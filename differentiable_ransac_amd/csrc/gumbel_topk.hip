@@ -91,6 +91,11 @@ template <typename T> __device__ __forceinline__ T log_t(T x);
 template <> __device__ __forceinline__ float log_t<float>(float x) { return logf(x); }
 template <> __device__ __forceinline__ double log_t<double>(double x) { return log(x); }
 
+__device__ __forceinline__ float row_max(float v) { return wave_max_bcast(v); }
+__device__ __forceinline__ double row_max(double v) { return wave_max(v); }
+__device__ __forceinline__ float row_sum(float v) { return wave_sum_bcast(v); }
+__device__ __forceinline__ double row_sum(double v) { return wave_sum(v); }
+
 template <typename T, bool kCache>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelArgs<T> a, int32_t *__restrict__ idx,
                                                                         T *__restrict__ y_sel, T *__restrict__ lse_out,
@@ -130,16 +135,16 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
     for (int j = 0; j < 4; ++j) sm += exp_t<T>(g[j] - mx);
   }
   // wave-wide soft-max statistics
-  T wmx = wave_max(mx);
+  T wmx = row_max(mx);
   sm *= (mx == -INFINITY) ? T(0) : exp_t<T>(mx - wmx);
-  sm = wave_sum(sm);
+  sm = row_sum(sm);
   const T lse = wmx + log_t<T>(sm);
   const T inv_sm = T(1) / sm;   // y = exp(g - max) / sum: exact to rounding even when |g| is huge (lse alone is not)
 
   // ---------------- threshold: k-th largest lane maximum
   T v = lmax, thr = -INFINITY;
   for (int r = 0; r < a.k; ++r) {
-    thr = wave_max(v);
+    thr = row_max(v);
     unsigned long long who = __ballot(v == thr);
     if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
   }
@@ -158,6 +163,8 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
         load_group<T>(a, p, b, q, g, nz);
       }
     }
+    // most iterations hold no candidate at all: one ballot on the group maximum instead of four on the elements
+    if (!__ballot(fmax(fmax(g[0], g[1]), fmax(g[2], g[3])) >= thr)) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool c = g[j] >= thr;

@@ -1,0 +1,23 @@
+import ctypes, os, subprocess, sys
+sys.path.insert(0, '.')
+variants = {'new': []}
+if '--build' in sys.argv:
+    for name, flags in variants.items():
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast', *flags,
+                               '-o', f'scratch/libk1_{name}.so', 'differentiable_ransac_amd/csrc/gumbel_topk.hip', 'differentiable_ransac_amd/csrc/dr_core.hip'])
+    sys.exit(0)
+import torch
+from differentiable_ransac_amd import synth
+dev = 'cuda'; P, N, B, k = 32, 2000, 1024, 5
+lg = synth.batch_two_view(P, N)['logits'].to(dev)
+idx = torch.empty(P, B, k, device=dev, dtype=torch.int32); ys = torch.empty(P, B, k, device=dev); lse = torch.empty(P, B, device=dev)
+for name in variants:
+    lib = ctypes.CDLL(os.path.abspath(f'scratch/libk1_{name}.so'))
+    cp = lambda t: ctypes.c_void_p(t.data_ptr())
+    f = lambda: lib.dr_gumbel_topk_fwd_f32(cp(lg), None, ctypes.c_uint64(7), ctypes.c_float(1.0), P, B, N, k, cp(idx), cp(ys), cp(lse), None, None, None, None)
+    assert f() == 0; torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20): f()
+    b.record(); torch.cuda.synchronize()
+    print(name, '%.1f us' % (a.elapsed_time(b) / 20 * 1e3))
