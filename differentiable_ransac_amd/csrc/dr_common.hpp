@@ -50,6 +50,25 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 
 // Maximum over the 64 lanes by DPP, broadcast to every lane through an SGPR (v_readlane of lane 63).
+// f64 variant: the two halves travel through DPP separately; total valid in lane 63 only.
+template <int kCtrl, int kRowMask, bool kBound>
+__device__ __forceinline__ double dpp_add_step(double x) {
+  const long long xi = __double_as_longlong(x);
+  const int lo = (int)xi, hi = (int)(xi >> 32);
+  const int tlo = kBound ? __builtin_amdgcn_mov_dpp(lo, kCtrl, kRowMask, 0xF, true) : __builtin_amdgcn_update_dpp(0, lo, kCtrl, kRowMask, 0xF, false);
+  const int thi = kBound ? __builtin_amdgcn_mov_dpp(hi, kCtrl, kRowMask, 0xF, true) : __builtin_amdgcn_update_dpp(0, hi, kCtrl, kRowMask, 0xF, false);
+  return x + __longlong_as_double(((long long)thi << 32) | (unsigned int)tlo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v = dpp_add_step<0xB1, 0xF, true>(v);
+  v = dpp_add_step<0x4E, 0xF, true>(v);
+  v = dpp_add_step<0x141, 0xF, true>(v);
+  v = dpp_add_step<0x140, 0xF, true>(v);
+  v = dpp_add_step<0x142, 0xA, false>(v);
+  v = dpp_add_step<0x143, 0xC, false>(v);
+  return v;
+}
+
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ float dpp_max_step(float x) {
   const int xi = __float_as_int(x);

@@ -564,6 +564,55 @@ __global__ __launch_bounds__(kThreads) void select_best_kernel(const T *__restri
   if (tid == 0 && inliers) inliers[p] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// ---- K7 acceptance: score the (few) refit candidates of every pair and keep the best of them if it beats the RANSAC
+// result (ransac.py:173-185: `scores = score(points, models); if scores.max() > best_score: best_model, best_score =
+// ...`; the mask is left as it is, like there).  One block per pair, a wave per candidate in turn: replaces an MSAC launch,
+// select_best and four torch kernels (50 us of device time per call) by one launch.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void refit_accept_kernel(const T *__restrict__ matches, const T *__restrict__ cand,
+                                                               const uint8_t *__restrict__ cvalid, const T *__restrict__ thr,
+                                                               int S, int N, T *__restrict__ best_score,
+                                                               T *__restrict__ best_model) {
+  __shared__ T s_part[kThreads / kWave];
+  __shared__ T s_best;
+  __shared__ int s_which;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const T t = T(1.5) * thr[p];
+  const T inv_thr2 = T(1) / (t * t);
+  if (tid == 0) { s_best = best_score[p]; s_which = -1; }
+  __syncthreads();
+  for (int c = 0; c < S; ++c) {
+    if (cvalid && !cvalid[(size_t)p * S + c]) continue;   // block-uniform
+    T m[9];
+    bool finite = true;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      m[q] = cand[((size_t)p * S + c) * 9 + q];
+      finite = finite && is_finite(m[q]);
+    }
+    T acc = T(0);
+    for (int n = tid; n < N; n += kThreads) {
+      const T *q = matches + ((size_t)p * N + n) * 4;
+      const T sv = sampson_s<T>(m, q[0], q[1], q[2], q[3], inv_thr2);
+      acc += (sv < T(0)) ? -sv : T(0);      // a 0/0 point (NaN) contributes 0, as in the scoring kernel
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s_part[wv] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      T sc = T(0);
+      for (int w = 0; w < kThreads / kWave; ++w) sc += s_part[w];
+      if (finite && sc > s_best) { s_best = sc; s_which = c; }   // strict: the first maximum wins, like torch.argmax
+    }
+    __syncthreads();
+  }
+  const int w = s_which;
+  if (w >= 0) {
+    if (tid < 9) best_model[(size_t)p * 9 + tid] = cand[((size_t)p * S + w) * 9 + tid];
+    if (tid == 0) best_score[p] = s_best;
+  }
+}
+
 // ---- K6 fused: arg-max + "is it better" + best mask + adaptive stop, all per-pair state on the device ----------
 // (ransac.py:109-144 and adaptive_iteration_number :202-215).  One 1024-thread block per pair.
 constexpr int kUpdThreads = 1024;
@@ -745,6 +794,24 @@ int dr_select_best_f32(const float *matches, const float *models, const uint8_t 
   hipLaunchKernelGGL((dr::select_best_kernel<float>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches,
                      models, valid, scores, thr, M, N, best_idx, best_score, best_model, best_mask, inliers);
   return dr::check_launch("select_best_kernel");
+}
+
+int dr_refit_accept_f32(const float *matches, const float *cand, const uint8_t *cand_valid, const float *thr, int P, int S,
+                        int N, float *best_score, float *best_model, void *stream) {
+  DR_REQUIRE(P > 0 && S > 0 && N > 0, "bad sizes");
+  DR_REQUIRE(matches && cand && thr && best_score && best_model, "null pointer");
+  hipLaunchKernelGGL((dr::refit_accept_kernel<float>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches, cand,
+                     cand_valid, thr, S, N, best_score, best_model);
+  return dr::check_launch("refit_accept_kernel");
+}
+
+int dr_refit_accept_f64(const double *matches, const double *cand, const uint8_t *cand_valid, const double *thr, int P,
+                        int S, int N, double *best_score, double *best_model, void *stream) {
+  DR_REQUIRE(P > 0 && S > 0 && N > 0, "bad sizes");
+  DR_REQUIRE(matches && cand && thr && best_score && best_model, "null pointer");
+  hipLaunchKernelGGL((dr::refit_accept_kernel<double>), dim3(P), dim3(dr::kThreads), 0, (hipStream_t)stream, matches, cand,
+                     cand_valid, thr, S, N, best_score, best_model);
+  return dr::check_launch("refit_accept_kernel");
 }
 
 int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,

@@ -42,49 +42,70 @@ __device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const 
 #pragma unroll
       for (int j = i; j < 9; ++j) acc[q++] += row[i] * row[j];
   }
-  int q = 0;
+  // 45 partial sums per thread: reduced inside each wave by DPP (no LDS traffic), one LDS slot per (wave, entry), ONE
+  // barrier, then 45 threads add the four wave partials (was: 45 x (wave butterfly over ds_bpermute + two barriers))
+  double *part = gram + 96;   // [4][45] behind gram[81] + red[4] (+ padding); see the LDS sizes at the launch sites
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int j = i; j < 9; ++j) {
-      const double s = block_sum(acc[q++], red);
-      if (threadIdx.x == 0) { gram[i * 9 + j] = s; gram[j * 9 + i] = s; }
-    }
+  for (int q = 0; q < 45; ++q) {
+    const double s = wave_sum_lane63(acc[q]);
+    if ((threadIdx.x & 63) == 63) part[(threadIdx.x >> 6) * 45 + q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 45) {
+    const double s = part[threadIdx.x] + part[45 + threadIdx.x] + part[90 + threadIdx.x] + part[135 + threadIdx.x];
+    int i = 0, rem = threadIdx.x;     // entry q of the upper triangle -> (i, j)
+    while (rem >= 9 - i) { rem -= 9 - i; ++i; }
+    const int j = i + rem;
+    gram[i * 9 + j] = s;
+    gram[j * 9 + i] = s;
+  }
   __syncthreads();
 }
 
+// Register budget: 256 per lane (waves_per_eu(2, 2)) although one wave per pair does the work -- the kernel runs on a side
+// stream next to the minimal solver of the same call, whose 1024 waves hold 184 registers each and need every SIMD of
+// the chip; with 346 registers this kernel took a SIMD away from 32 of them (solver 106 -> 168 us).
 template <typename T>
-__global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) void refit_essential_kernel(const T *__restrict__ matches,
+__global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(2, 2))) void refit_essential_kernel(const T *__restrict__ matches,
                                                                 const uint8_t *__restrict__ mask, int N,
                                                                 T *__restrict__ models, uint8_t *__restrict__ valid) {
-  extern __shared__ __align__(16) double lds[];   // [162 * 64] per-lane workspace of wave 0, then gram[81], red[4]
-  double *gram = lds + 162 * 64;
+  extern __shared__ __align__(16) double lds[];   // [192] five-point workspace, then gram[81] + red[4], wave partials, Jacobi
+  double *gram = lds + 192;   // [0,162): the one five-point workspace slot all lanes share (identical values)
   double *red = gram + 81;
   const int p = blockIdx.x;
   const T *mt = matches + (size_t)p * N * 4;
   const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
   const double mu[4] = {0, 0, 0, 0};
   gram_accumulate<false, T>(mt, mk, N, mu, 1.0, 1.0, gram, red);
+#if defined(DR_REFIT_STOP) && DR_REFIT_STOP == 1
+  return;
+#endif
   if (threadIdx.x >= 64) return;
+  // the rest is one latency-bound wave per pair, usually running next to the scoring kernel of the same call (8 VALU-bound
+  // waves per SIMD): raise its issue priority so that it proceeds at its own pace and the scoring waves fill the gaps
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   double nb[4][9];
   {
-    double A[9][9], V[9][9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-      for (int j = 0; j < 9; ++j) A[i][j] = gram[i * 9 + j];
-    jacobi_eig9_reg(A, V);
-    unsigned used = 0;
+    // 9x9 eigen-decomposition by the whole wave in LDS (was: every lane ran the full cyclic Jacobi redundantly in
+    // registers: 324 live doubles, 512 registers + 1.5 KB of scratch per lane and ~120 us of the kernel)
+    double *Vl = gram + 96 + 4 * 45, *cs = Vl + 81;
+    jacobi_eig9_wave(gram, Vl, cs, lane);
+    double ev[4][9];
+    smallest_eigvecs9_lds<4>(gram, Vl, ev);
     // nb[3] <-> smallest eigenvalue ... nb[0] <-> fourth smallest (the order of torch.linalg.svd's Vh[-4:])
-    smallest_eigvec9(A, V, used, nb[3]);
-    smallest_eigvec9(A, V, used, nb[2]);
-    smallest_eigvec9(A, V, used, nb[1]);
-    smallest_eigvec9(A, V, used, nb[0]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 9; ++r) nb[3 - t][r] = ev[t][r];
   }
+#if defined(DR_REFIT_STOP) && DR_REFIT_STOP == 2
+  if (lane == 0) models[(size_t)p * 90] = (T)nb[0][0];
+  return;
+#endif
   double e[3][3][4];
   basis_to_entries(nb, e);
-  LaneWs w{lds + lane};
+  LaneWs w{lds, 1};   // every lane solves the same system: one shared slot, same-address writes of equal values
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
   nister_finish<T, false>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane == 0);
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
                                                                   const uint8_t *__restrict__ mask, int N,
                                                                   T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
-  double *gram = lds + 162 * 64;
+  double *gram = lds + 192;   // [0,162): the one five-point workspace slot all lanes share (identical values)
   double *red = gram + 81;
   const int p = blockIdx.x;
   const T *mt = matches + (size_t)p * N * 4;
@@ -128,14 +149,12 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   const int lane = threadIdx.x;
   double f[9];
   {
-    double A[9][9], V[9][9];
+    double A[9][9];
 #pragma unroll
     for (int i = 0; i < 9; ++i)
 #pragma unroll
       for (int j = 0; j < 9; ++j) A[i][j] = gram[i * 9 + j];
-    jacobi_eig9_reg(A, V);
-    unsigned used = 0;
-    smallest_eigvec9(A, V, used, f);
+    smallest_eigvec9_invit(A, f);   // only the last right singular vector is needed (fundamental_matrix_estimator.py:249-254)
   }
   double G[3][3];
 #pragma unroll
@@ -164,7 +183,9 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 template <typename T>
 int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, int P, int N, T *models, uint8_t *valid,
                  hipStream_t st) {
-  const size_t smem = sizeof(double) * (162 * 64 + 81 + 4);
+  // five-point workspace (one slot), gram[81] + red[4] (padded to 96), wave partials [4][45], Jacobi V[81] + (c, s, p, q)[4]:
+  // 4.6 KB -- with a 162-double slot PER LANE (83 KB) a block left room for only two of the four solver blocks a CU hosts
+  const size_t smem = sizeof(double) * (192 + 96 + 4 * 45 + 81 + 16);
   static bool attr_e = false, attr_f = false;
   if (fundamental) {
     if (!attr_f) {

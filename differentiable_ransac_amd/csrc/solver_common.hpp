@@ -294,13 +294,17 @@ template <int N>
 __device__ __forceinline__ void jacobi_eig_lds(const LaneWs &A, const LaneWs &V) {
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+  double prev_off = INFINITY;
   for (int sweep = 0; sweep < 30; ++sweep) {
     double off = 0, dg = 0;
     for (int i = 0; i < N; ++i) {
       dg += A[i * N + i] * A[i * N + i];
       for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j];
     }
-    const bool done = !(off > 1e-34 * dg) ;
+    // converged, or stagnating at the rounding floor of a badly scaled matrix (1e-34 was never reached by Gram matrices
+    // with a 1e6 eigenvalue spread: all 30 sweeps ran)
+    const bool done = !(off > 1e-30 * dg) || (sweep >= 4 && off > 0.25 * prev_off);
+    prev_off = off;
     if (__all(done)) break;
     for (int p = 0; p < N - 1; ++p) {
       for (int q = p + 1; q < N; ++q) {
@@ -341,6 +345,7 @@ __device__ __forceinline__ void jacobi_eig9_reg(double (&A)[9][9], double (&V)[9
   for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  double prev_off = INFINITY;
 #pragma unroll 1
   for (int sweep = 0; sweep < 30; ++sweep) {
     double off = 0, dg = 0;
@@ -350,7 +355,8 @@ __device__ __forceinline__ void jacobi_eig9_reg(double (&A)[9][9], double (&V)[9
 #pragma unroll
       for (int j = i + 1; j < 9; ++j) off += A[i][j] * A[i][j];
     }
-    const bool done = !(off > 1e-34 * dg);
+    const bool done = !(off > 1e-30 * dg) || (sweep >= 4 && off > 0.25 * prev_off);
+    prev_off = off;
     if (__all(done)) break;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -406,6 +412,149 @@ __device__ __forceinline__ int smallest_eigvec9(const double (&A)[9][9], const d
     out[r] = v;
   }
   return best;
+}
+
+// Parallel cyclic Jacobi for ONE symmetric 9x9 matrix held in LDS (A, V: 81 doubles each, row-major), executed by one
+// whole wave: round-robin ordering -- 9 rounds per sweep, 4 disjoint rotations per round (player r sits out in round r)
+// -- lanes 0-3 compute the four (c, s), then 36 lanes apply the column updates of A, 36 those of V, 36 the row updates.
+// ~700 cycles per round instead of ~27 k cycles per sweep of the serial register version above; on return the diagonal
+// of A holds the eigenvalues and the columns of V the eigenvectors.  `cs` = 16 doubles of LDS scratch.
+__device__ __forceinline__ void jacobi_eig9_wave(double *A, double *V, double *cs, int lane) {
+  for (int i = lane; i < 81; i += 64) V[i] = (i % 10 == 0) ? 1.0 : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  double prev_off = INFINITY;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0, dg = 0;
+    for (int i = lane; i < 81; i += 64) {
+      const double v = A[i] * A[i];
+      if (i % 10 == 0) dg += v; else off += v;
+    }
+    off = wave_sum(off);
+    dg = wave_sum(dg);
+    // converged (off-diagonal mass at rounding level), or stagnating at the rounding floor of a badly scaled matrix
+    if (!(off > 2e-30 * dg) || (sweep >= 4 && off > 0.25 * prev_off)) break;
+    prev_off = off;
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      if (lane < 4) {
+        const int a = (r + lane + 1) % 9, b = (r + 9 - (lane + 1)) % 9;
+        const int p = min(a, b), q = max(a, b);
+        const double apq = A[p * 9 + q];
+        double c = 1.0, sn = 0.0;
+        if (fabs(apq) > 1e-300) {
+          const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
+          const double t = dsign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          sn = t * c;
+        }
+        cs[4 * lane] = c; cs[4 * lane + 1] = sn;
+        cs[4 * lane + 2] = (double)p; cs[4 * lane + 3] = (double)q;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 36) {            // columns p, q of A and of V: element row k of rotation pr
+        const int pr = lane / 9, k = lane % 9;
+        const double c = cs[4 * pr], sn = cs[4 * pr + 1];
+        const int p = (int)cs[4 * pr + 2], q = (int)cs[4 * pr + 3];
+        const double akp = A[k * 9 + p], akq = A[k * 9 + q];
+        A[k * 9 + p] = c * akp - sn * akq;
+        A[k * 9 + q] = sn * akp + c * akq;
+        const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
+        V[k * 9 + p] = c * vkp - sn * vkq;
+        V[k * 9 + q] = sn * vkp + c * vkq;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 36) {            // rows p, q of A
+        const int pr = lane / 9, k = lane % 9;
+        const double c = cs[4 * pr], sn = cs[4 * pr + 1];
+        const int p = (int)cs[4 * pr + 2], q = (int)cs[4 * pr + 3];
+        const double apk = A[p * 9 + k], aqk = A[q * 9 + k];
+        A[p * 9 + k] = c * apk - sn * aqk;
+        A[q * 9 + k] = sn * apk + c * aqk;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// the `count` smallest eigenpairs after jacobi_eig9_wave: out[t] = eigenvector of the (t+1)-th smallest eigenvalue
+template <int kCount>
+__device__ __forceinline__ void smallest_eigvecs9_lds(const double *A, const double *V, double (&out)[kCount][9]) {
+  double d[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d[i] = A[i * 10];
+  unsigned used = 0;
+#pragma unroll
+  for (int t = 0; t < kCount; ++t) {
+    int best = 0;
+    double bv = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const bool free_ = !((used >> i) & 1u);
+      if (free_ && d[i] < bv) { bv = d[i]; best = i; }
+    }
+    used |= 1u << best;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) out[t][r] = V[r * 9 + best];
+  }
+}
+
+// Eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite 9x9 matrix by inverse iteration on a
+// Cholesky factor (A + 1e-14 tr(A) I, so that an exactly singular A -- noise-free data -- still factors): ~200 flops
+// for the factor + 162 per iteration, against ~29 k for the cyclic Jacobi above, which it replaces where only this one
+// vector is needed (LSQ fundamental matrix).  Error after m iterations ~ (lambda_9 / lambda_8)^m; 24 iterations.
+__device__ __forceinline__ void smallest_eigvec9_invit(const double (&A)[9][9], double (&x)[9]) {
+  double L[9][9];
+  double tr = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) tr += A[i][i];
+  const double shift = 1e-14 * tr;
+  double inv[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double d = A[j][j] + shift;
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    d = fmax(d, 1e-300);
+    const double r = 1.0 / sqrt(d);
+    inv[j] = r;
+#pragma unroll
+    for (int i = j + 1; i < 9; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v * r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x[i] = 1.0 / 3.0 + 0.01 * i;   // fixed start, not orthogonal to anything in particular
+#pragma unroll 1
+  for (int it = 0; it < 24; ++it) {
+    double y[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {        // L y = x
+      double v = x[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+      y[i] = v * inv[i];
+    }
+    double nn = 0;
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {       // L^T z = y
+      double v = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 9; ++k) v -= L[k][i] * x[k];
+      x[i] = v * inv[i];
+      nn += x[i] * x[i];
+    }
+    const double sc = 1.0 / sqrt(nn);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) x[i] *= sc;
+  }
 }
 
 // symmetric 3x3 Jacobi in registers; eigenvalues in d[], eigenvectors = columns of V

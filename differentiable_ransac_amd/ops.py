@@ -337,6 +337,17 @@ def refit_essential(matches: torch.Tensor, mask: Optional[torch.Tensor] = None):
     return models, valid
 
 
+def refit_accept(matches: torch.Tensor, cand: torch.Tensor, cand_valid: Optional[torch.Tensor], thr: torch.Tensor,
+                 best_score: torch.Tensor, best_model: torch.Tensor) -> None:
+    """K7 acceptance in one launch (dr_refit_accept): scores cand [P,S,3,3] and replaces best_score [P] / best_model
+    [P,3,3] IN PLACE where a candidate scores strictly higher (ransac.py:173-185)."""
+    P, N, _ = matches.shape
+    S = cand.shape[1]
+    cv = None if cand_valid is None else cand_valid.contiguous().view(torch.uint8)
+    L.call(f"dr_refit_accept_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(cand.contiguous()), ptr(cv), ptr(thr),
+           c_int(P), c_int(S), c_int(N), ptr(best_score), ptr(best_model), stream())
+
+
 def refit_fundamental(matches: torch.Tensor, mask: Optional[torch.Tensor] = None):
     """K7 (F): Hartley-normalised LSQ 8-point on the masked points of every pair.  -> F [P,3,3], valid [P]."""
     P, N, _ = matches.shape

@@ -326,15 +326,18 @@ class BatchedRANSAC(object):
             all_masks = None
             matches = matches.contiguous()
             # The essential-matrix refit candidate (Nister on ALL points, ransac.py:157-165) depends on the matches only:
-            # it is issued up front on a side stream (32 latency-bound blocks) and joins before the final scoring.
+            # it is issued up front on a side stream (32 latency-bound blocks, register budget chosen so that the minimal
+            # solver's waves still find room on the same SIMDs) and joins before the final scoring.
             pre = None
-            if self.refit and not self.fmat:
+
+            def issue_refit():
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=dev)
                 self._side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._side):
-                    pre = ops.refit_essential(matches)
+                    out_ = ops.refit_essential(matches)
                     matches.record_stream(self._side)
+                return out_
             # Rounds are pipelined: the hypotheses of round r+1 (sampler + solver, latency-bound, independent of round r's
             # outcome) are issued on a second stream before round r is scored, so they run under K4/K6 and under the
             # host's "does any pair continue?" read-back.  If round r ends the loop they are simply dropped.
@@ -346,6 +349,8 @@ class BatchedRANSAC(object):
             def have_round(r):
                 return r < rounds and (gumbels is None or noise_of(r) is not None)
 
+            if self.refit and not self.fmat:
+                pre = issue_refit()
             ahead = None
             if have_round(0):
                 ahead = self.hypotheses(matches, logits, noise_of(0))[:2]
@@ -393,10 +398,7 @@ class BatchedRANSAC(object):
                     cand, cvalid = pre
                     cand.record_stream(torch.cuda.current_stream())
                     cvalid.record_stream(torch.cuda.current_stream())
-                cs, _ = ops.msac_score(matches, cand, thr, want_masks=False)
-                ci, cbs, cbm, cmask, cinl = ops.select_best(matches, cand, cs, thr, cvalid)
-                better = (cbs > best_score) & (ci >= 0)
-                best_model = torch.where(better[:, None, None], cbm, best_model)
-                best_score = torch.where(better, cbs, best_score)
+                # score the candidates and keep the best one where it beats the RANSAC result: one launch, in place
+                ops.refit_accept(matches, cand, cvalid, thr, best_score, best_model)
             return dict(model=best_model, mask=best_mask, score=best_score, iterations=iters, inliers=best_inl,
                         masks=all_masks)

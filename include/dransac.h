@@ -248,6 +248,14 @@ int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, i
 int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
                              void *stream);
 
+/* K7 acceptance (ransac.py:173-185): MSAC scores of the S refit candidates of every pair (cand [P,S,9], cand_valid [P,S]
+ * or NULL); where the best candidate scores strictly higher than best_score[p], best_score[p] and best_model[p] ([P,9])
+ * are replaced in place (the best mask is not touched, as in the reference). */
+int dr_refit_accept_f32(const float *matches, const float *cand, const uint8_t *cand_valid, const float *thr, int P, int S,
+                        int N, float *best_score, float *best_model, void *stream);
+int dr_refit_accept_f64(const double *matches, const double *cand, const uint8_t *cand_valid, const double *thr, int P,
+                        int S, int N, double *best_score, double *best_model, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * the training loss right after the path -- MatchLoss (loss.py:107-153) on batch_episym
  * (cv_utils.py:680-695).  sums [P,M] = sum over the points with mask[p,n] != 0 (NULL = all points) of
