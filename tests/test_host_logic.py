@@ -1,0 +1,65 @@
+"""Host-side logic that needs no GPU: driver configuration, plugin detection, sharding arithmetic."""
+import pytest
+import torch
+
+
+def _plugins(fmat=False, k=5, uniform=False):
+    from differentiable_ransac_amd.estimators import (EssentialMatrixEstimator, EssentialMatrixEstimatorNister,
+                                                      FundamentalMatrixEstimatorNew)
+    from differentiable_ransac_amd.samplers import GumbelSoftmaxSampler, UniformSampler
+    from differentiable_ransac_amd.scorings import MSACScore
+    est = FundamentalMatrixEstimatorNew("cuda") if fmat else EssentialMatrixEstimatorNister("cuda")
+    smp = UniformSampler(64, k) if uniform else GumbelSoftmaxSampler(64, k, device="cuda")
+    return est, smp, MSACScore("cuda"), EssentialMatrixEstimator
+
+
+def test_dropin_ransac_picks_the_fused_driver_only_for_its_own_plugins():
+    from differentiable_ransac_amd.ransac import RANSAC
+    est, smp, sc, Stew = _plugins()
+    assert RANSAC(est, smp, sc, sampler_id=2)._fused_solver() == "nister"
+    assert RANSAC(est, smp, sc, sampler_id=2, train=True)._fused_solver() is None          # train mode: plugin path
+    assert RANSAC(Stew("cuda"), smp, sc, sampler_id=2)._fused_solver() == "stewenius"
+    estF, smp8, scF, _ = _plugins(fmat=True, k=8)
+    assert RANSAC(estF, smp8, scF, fmat=True, sampler_id=3)._fused_solver() == "f8"
+    assert RANSAC(estF, smp8, scF, fmat=False, sampler_id=3)._fused_solver() is None       # inconsistent flags
+    _, smpu, _, _ = _plugins(uniform=True)
+    assert RANSAC(est, smpu, sc, sampler_id=0)._fused_solver() is None                      # uniform sampler
+
+    class MyScore(type(sc)):                                                                # a user's subclass is custom
+        pass
+    assert RANSAC(est, smp, MyScore("cuda"), sampler_id=2)._fused_solver() is None
+    with pytest.raises(NotImplementedError):
+        RANSAC(est, smp, sc, lo=3)
+
+
+def test_batched_ransac_configuration_errors():
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    with pytest.raises(ValueError):
+        BatchedRANSAC("nister", sampling="sobol")
+    with pytest.raises(ValueError):
+        BatchedRANSAC("nister", train=True, sampling="topdown")
+    with pytest.raises(ValueError):
+        BatchedRANSAC("nister", weighted=1, sampling="topdown")
+    with pytest.raises(KeyError):
+        BatchedRANSAC("dlt")
+    rn = BatchedRANSAC("f8", ransac_batch_size=64)
+    assert (rn.k, rn.S, rn.fmat, rn.sync_every) == (8, 1, True, 4)
+    assert BatchedRANSAC("nister", ransac_batch_size=1024).sync_every == 1
+
+
+def test_ops_refuse_cpu_tensors_without_touching_the_gpu():
+    from differentiable_ransac_amd import ops
+    from differentiable_ransac_amd._lib import DransacError
+    with pytest.raises(DransacError):
+        ops.msac_score(torch.rand(1, 16, 4), torch.rand(1, 3, 3, 3), 1e-3)
+    with pytest.raises(DransacError):
+        ops.topdown_sample(torch.rand(1, 16), 4, 3)
+
+
+def test_pose_loss_rejects_unimplemented_branches():
+    from differentiable_ransac_amd.loss import PoseLoss
+    with pytest.raises(NotImplementedError):
+        PoseLoss(fmat=True)
+    with pytest.raises(NotImplementedError):
+        PoseLoss().forward_average(torch.zeros(1, 1, 3, 3), torch.zeros(1, 4, 2), torch.zeros(1, 4, 2), torch.eye(3)[None],
+                                   torch.ones(1, 3), svd=True)
