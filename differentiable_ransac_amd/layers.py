@@ -1,0 +1,127 @@
+"""The RANSAC layers of the reference (the callers of the hot path), without the CLNet that feeds them:
+
+  RANSACLayer      model_cl.py:160-256   plugin wiring from the option namespace + forward for one image pair
+  RANSACLayer3D    model_cl.py:516-595   the same for 3-D point registration
+  batched_forward  model_cl.py:488-511   the per-pair Python loop of DeepRansac_CLNet.forward as ONE BatchedRANSAC call
+
+`opt` is the reference's argparse namespace (utils.py:30-77); only the fields the reference reads here are used:
+fmat, sampler, ransac_batch_size, tr, weighted, threshold, precision, device.  Returns are the reference's:
+(models with NaN rows dropped, wall time of the RANSAC call in seconds).
+"""
+import time
+
+import torch
+
+from .estimators import EssentialMatrixEstimatorNister, FundamentalMatrixEstimatorNew, RigidTransformationSVDBasedSolver
+from .ransac import RANSAC, RANSAC3D, BatchedRANSAC
+from .samplers import GumbelSoftmaxSampler, UniformSampler
+from .scorings import MSACScore
+
+
+def denormalize_pts(pts: torch.Tensor, im_size: torch.Tensor) -> torch.Tensor:
+    """cv_utils.denormalize_pts (:35-45): undo the image-size normalisation of the F branch; im_size = (height, width)."""
+    return pts * max(im_size) + torch.stack((im_size[1] / 2, im_size[0] / 2)).to(pts)
+
+
+def _data_type(opt):
+    if opt.precision == 0:
+        raise NotImplementedError("half precision is not supported (it never worked upstream either: SURVEY Q15)")
+    return torch.float64 if opt.precision == 2 else torch.float32
+
+
+def _sampler(opt, sample_size, data_type):
+    # model_cl.py:178-207: 0 uniform; 1, 2 Gumbel with the solver's sample size; anything else Gumbel with 8 points
+    if opt.sampler == 0:
+        return UniformSampler(opt.ransac_batch_size, sample_size)
+    k = sample_size if opt.sampler in (1, 2) else 8
+    return GumbelSoftmaxSampler(opt.ransac_batch_size, k, device=opt.device, data_type=data_type)
+
+
+def _drop_nan(models: torch.Tensor) -> torch.Tensor:
+    if models.dim() == 2:                      # test mode returns one [3,3] model
+        return models
+    keep = ~torch.isnan(models).flatten(1).any(1)
+    return models[keep]
+
+
+class RANSACLayer(torch.nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        dt = _data_type(opt)
+        solver = (FundamentalMatrixEstimatorNew(opt.device, opt.weighted) if opt.fmat
+                  else EssentialMatrixEstimatorNister(opt.device))
+        sampler = _sampler(opt, solver.sample_size, dt)
+        max_iters = (1000 if opt.tr else 5000) if opt.fmat else (100 if opt.tr else 5000)      # model_cl.py:213-219
+        self.estimator = RANSAC(solver, sampler, MSACScore(opt.device), max_iterations=max_iters, fmat=opt.fmat,
+                                train=opt.tr, ransac_batch_size=opt.ransac_batch_size, sampler_id=opt.sampler,
+                                weighted=opt.weighted, threshold=opt.threshold)
+
+    def forward(self, points, weights, K1, K2, im_size1, im_size2, ground_truth=None, gumbels=None):
+        """points [N,4], weights (logits) [N] -> (Es, seconds).  Train: Es [n_batches * B', 3, 3] with autograd to
+        `weights`; test: Es [3,3]."""
+        points_ = points.clone()
+        if self.opt.fmat:
+            points_[:, 0:2] = denormalize_pts(points[:, 0:2], im_size1)
+            points_[:, 2:4] = denormalize_pts(points[:, 2:4], im_size2)
+        t0 = time.time()
+        models, _, _, _ = self.estimator(points_, weights, K1, K2, ground_truth, gumbels=gumbels)
+        dt = time.time() - t0
+        Es = torch.cat(list(models.values())) if self.opt.tr else models
+        return _drop_nan(Es), dt
+
+
+class RANSACLayer3D(torch.nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        dt = _data_type(opt)
+        solver = RigidTransformationSVDBasedSolver()
+        sampler = _sampler(opt, solver.sample_size, dt)
+        self.estimator = RANSAC3D(solver, sampler, MSACScore(opt.device), max_iterations=1000, fmat=opt.fmat, train=opt.tr,
+                                  ransac_batch_size=opt.ransac_batch_size, sampler_id=opt.sampler, weighted=opt.weighted,
+                                  threshold=opt.threshold)
+
+    def forward(self, points, weights, ground_truth=None, gumbels=None):
+        """points [N,6], weights [N] -> (T [n,4,4], mean residual sum, mean of the mean residuals, seconds) in train mode
+        (model_cl.py:579-595; the reference's test branch reads undefined variables, SURVEY Q4: here (T [4,4], time))."""
+        t0 = time.time()
+        models, residuals, avg_residuals, _, _ = self.estimator(points, weights, ground_truth, gumbels=gumbels)
+        dt = time.time() - t0
+        if not self.opt.tr:
+            return models, dt
+        Ts = torch.cat(list(models.values()))
+        loss = torch.cat(list(residuals.values()))
+        avg_loss = sum(avg_residuals.values()) / len(avg_residuals)
+        keep = ~torch.isnan(Ts).flatten(1).any(1)
+        return Ts[keep], loss.mean(), avg_loss, dt
+
+
+def batched_forward(opt, points, weights, K1, K2, im_size1=None, im_size2=None, gt=None, driver=None):
+    """DeepRansac_CLNet.forward's loop over the pairs of a batch (model_cl.py:488-511) as one BatchedRANSAC call.
+    points [P,N,4], weights [P,N], K1/K2 [P,3,3], im sizes [P,2] (F branch), gt [P,3,3] (train) ->
+    (list of per-pair model tensors like the reference's `ret`, seconds per pair).  Pass `driver` to reuse one
+    BatchedRANSAC across calls."""
+    P = points.shape[0]
+    if opt.sampler == 0:
+        raise NotImplementedError("the batched driver samples with the Gumbel sampler (sampler ids 1-3); "
+                                  "use RANSACLayer for the uniform sampler")
+    if driver is None:
+        solver = ("f8" if opt.sampler not in (1, 2) else "f7") if opt.fmat else "nister"
+        max_iters = (1000 if opt.tr else 5000) if opt.fmat else (100 if opt.tr else 5000)
+        driver = BatchedRANSAC(solver, ransac_batch_size=opt.ransac_batch_size, train=bool(opt.tr), threshold=opt.threshold,
+                               max_iterations=max_iters, weighted=opt.weighted)
+    pts = points
+    if opt.fmat:
+        pts = points.clone()
+        for p in range(P):
+            pts[p, :, 0:2] = denormalize_pts(points[p, :, 0:2], im_size1[p])
+            pts[p, :, 2:4] = denormalize_pts(points[p, :, 2:4], im_size2[p])
+    t0 = time.time()
+    if opt.tr:
+        chosen, keep = driver(pts, weights, K1, K2, gt_model=gt)
+        ret = [chosen[p][keep[p]] for p in range(P)]
+    else:
+        out = driver(pts, weights, K1, K2)
+        ret = [out["model"][p] for p in range(P)]
+    return ret, (time.time() - t0) / P

@@ -304,3 +304,48 @@ def test_batched_topdown_sampling_recovers_the_pose(dev):
     assert abs(res["gumbel"][1] - res["topdown"][1]) < 0.05 * res["gumbel"][1]
     with pytest.raises(ValueError):
         BatchedRANSAC("nister", train=True, sampling="topdown")
+
+
+def test_ransac_layers_forward(dev):
+    """Row H: RANSACLayer / RANSACLayer3D forward = the driver call + the reference's post-processing (concatenate the
+    per-batch models, drop NaN rows, wall time), and the batched counterpart of the per-pair loop."""
+    import types
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.layers import RANSACLayer, RANSACLayer3D, batched_forward
+    g = load_golden("ransac_train_nister")
+    opt = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=32, tr=True, weighted=0, threshold=0.75, precision=1,
+                                device="cuda")
+    layer = RANSACLayer(opt)
+    logits = g["logits"].to(dev).requires_grad_(True)
+    Es, secs = layer(g["matches"].to(dev), logits, g["K1"].to(dev), g["K2"].to(dev), None, None, g["gt"].to(dev),
+                     gumbels=[x.to(dev) for x in g["gumbels"]])
+    direct = _make("nister", 32, True, 100)
+    models, _, _, _ = direct(g["matches"].to(dev), g["logits"].to(dev), g["K1"].to(dev), g["K2"].to(dev), g["gt"].to(dev),
+                             gumbels=[x.to(dev) for x in g["gumbels"]])
+    want = torch.cat([models[k] for k in sorted(models.keys())])
+    assert Es.shape == want.shape and torch.allclose(Es, want, atol=1e-6) and secs > 0
+    Es.sum().backward()
+    assert torch.isfinite(logits.grad).all() and logits.grad.abs().sum() > 0
+    # test mode: one model per pair; the batched counterpart recovers the same geometry for every pair of a batch
+    opt.tr, opt.ransac_batch_size = False, 512
+    P, N = 4, 1000
+    data = synth.batch_two_view(P, N, seed0=90)
+    ret, per_pair = batched_forward(opt, data["matches"].to(dev), data["logits"].to(dev), data["K1"].to(dev), data["K2"].to(dev))
+    single = RANSACLayer(opt)
+    for p in range(P):
+        E1, _ = single(data["matches"][p].to(dev), data["logits"][p].to(dev), data["K1"][p].to(dev), data["K2"][p].to(dev),
+                       None, None)
+        for E in (E1, ret[p]):
+            assert E.shape == (3, 3)
+            assert (O.canonical(E.cpu().double()) - O.canonical(data["gt_E"][p].double())).abs().max() < 0.05
+    # 3-D layer, train mode, against the reference run
+    g3 = load_golden("ransac3d_train")
+    opt3 = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=32, tr=True, weighted=0, threshold=0.75, precision=1,
+                                 device="cuda")
+    l3 = RANSACLayer3D(opt3)
+    l3.estimator.max_iterations = 64
+    Ts, loss, avg_loss, secs = l3(g3["matches"].to(dev), g3["logits"].to(dev), None, gumbels=[x.to(dev) for x in g3["gumbels"]])
+    err = (Ts.cpu() - g3["models"]).abs().amax((-1, -2))
+    assert (err < 1e-4).float().mean() > 0.85 and err.max() < 5e-3      # flag=True: R = I up to the reference's f32 noise (Q9)
+    assert abs(float(loss) - float(g3["residuals"].mean())) < 5e-3 * float(g3["residuals"].mean())
+    assert abs(float(avg_loss) - float(g3["mean_residuals"].mean())) < 5e-3 * float(g3["mean_residuals"].abs().max())

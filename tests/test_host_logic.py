@@ -63,3 +63,34 @@ def test_pose_loss_rejects_unimplemented_branches():
     with pytest.raises(NotImplementedError):
         PoseLoss().forward_average(torch.zeros(1, 1, 3, 3), torch.zeros(1, 4, 2), torch.zeros(1, 4, 2), torch.eye(3)[None],
                                    torch.ones(1, 3), svd=True)
+
+
+def test_ransac_layers_wire_the_plugins_like_the_reference():
+    """model_cl.py:160-232, 516-575: solver / sampler / iteration budget chosen from the option namespace."""
+    import types
+    from differentiable_ransac_amd.layers import RANSACLayer, RANSACLayer3D, batched_forward, denormalize_pts
+    from differentiable_ransac_amd.estimators import EssentialMatrixEstimatorNister, FundamentalMatrixEstimatorNew
+    from differentiable_ransac_amd.samplers import GumbelSoftmaxSampler, UniformSampler
+    opt = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=64, tr=True, weighted=0, threshold=0.75, precision=1,
+                                device="cuda")
+    l = RANSACLayer(opt)
+    assert isinstance(l.estimator.estimator, EssentialMatrixEstimatorNister) and l.estimator.max_iterations == 100
+    assert isinstance(l.estimator.sampler, GumbelSoftmaxSampler) and l.estimator.sampler.num_samples == 5
+    opt.tr = False
+    assert RANSACLayer(opt).estimator.max_iterations == 5000
+    opt.fmat, opt.sampler, opt.tr = True, 3, True
+    l = RANSACLayer(opt)
+    assert isinstance(l.estimator.estimator, FundamentalMatrixEstimatorNew) and l.estimator.max_iterations == 1000
+    assert l.estimator.sampler.num_samples == 8
+    opt.sampler = 0
+    assert isinstance(RANSACLayer(opt).estimator.sampler, UniformSampler)
+    with pytest.raises(NotImplementedError):
+        batched_forward(opt, torch.zeros(1, 8, 4), torch.zeros(1, 8), None, None)
+    opt.sampler = 2
+    assert RANSACLayer3D(opt).estimator.max_iterations == 1000
+    opt.precision = 0
+    with pytest.raises(NotImplementedError):
+        RANSACLayer(opt)
+    # cv_utils.denormalize_pts: pts * max(im_size) + (w/2, h/2), im_size = (h, w)
+    out = denormalize_pts(torch.tensor([[0.0, 0.0], [0.5, -0.25]]), torch.tensor([480.0, 640.0]))
+    assert torch.equal(out, torch.tensor([[320.0, 240.0], [640.0, 80.0]]))
