@@ -315,6 +315,63 @@ __global__ __launch_bounds__(64) void pose_error_bwd_kernel(const T *__restrict_
   }
 }
 
+// ---- the inlier mask cv2.recoverPose returns (loss.py:99: `_, R, t, gt_inliers = cv2.recoverPose(gt_E, pts1, pts2)`;
+// the reference's MatchLoss / ClassificationLoss use it as the ground-truth inlier mask): the points that pass the
+// cheirality test of the winning candidate.  One block per (pair, model) -- meant for the ground-truth model of each pair
+// (M = 1): pass 1 votes for the four candidates like pose_error_kernel, pass 2 re-triangulates with the winner only.
+template <typename T>
+__global__ __launch_bounds__(kPoseThreads) void recover_pose_mask_kernel(const T *__restrict__ matches, const T *__restrict__ models,
+                                                                        int M, int N, double dist_thr, int32_t *__restrict__ which,
+                                                                        uint8_t *__restrict__ mask) {
+  __shared__ int s_votes[4];
+  __shared__ int s_best;
+  const int p = blockIdx.y, m = blockIdx.x, tid = threadIdx.x;
+  if (tid < 4) s_votes[tid] = 0;
+  __syncthreads();
+  const T *mt = matches + (size_t)p * N * 4;
+  double E[9], R1[9], R2[9], t[3];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) E[q] = (double)models[((size_t)p * M + m) * 9 + q];
+  horn_decompose<double>(E, R1, R2, t);
+  auto test = [&](const double(&R)[9], int n, bool &pos, bool &neg) {
+    double X[4];
+    triangulate(R, t, (double)mt[n * 4], (double)mt[n * 4 + 1], (double)mt[n * 4 + 2], (double)mt[n * 4 + 3], X);
+    const double zw = X[2] * X[3];
+    const double dw = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2] * X[3]) * X[3];
+    const double lim = dist_thr * (X[3] * X[3]);
+    pos = zw > 0 && zw < lim && dw > 0 && dw < lim;
+    neg = zw < 0 && -zw < lim && dw < 0 && -dw < lim;
+  };
+  int v[4] = {0, 0, 0, 0};
+  for (int n = tid; n < N; n += kPoseThreads) {
+    bool a, b;
+    test(R1, n, a, b);
+    v[0] += a; v[2] += b;
+    test(R2, n, a, b);
+    v[1] += a; v[3] += b;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int sum = wave_sum(v[c]);
+    if ((tid & 63) == 0 && sum) atomicAdd(&s_votes[c], sum);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = 0, bv = s_votes[0];
+    for (int c = 1; c < 4; ++c)
+      if (s_votes[c] > bv) { bv = s_votes[c]; best = c; }
+    s_best = best;
+    if (which) which[(size_t)p * M + m] = best;
+  }
+  __syncthreads();
+  const int best = s_best;
+  for (int n = tid; n < N; n += kPoseThreads) {
+    bool a, b;
+    if (best & 1) test(R2, n, a, b); else test(R1, n, a, b);
+    mask[((size_t)p * M + m) * N + n] = (best >= 2) ? b : a;
+  }
+}
+
 template <typename T>
 int pose_error_launch(const T *matches, const T *models, const T *gt_R, const T *gt_t, int P, int M, int N,
                       double dist_thr, T *err_R, T *err_t, int32_t *which, int32_t *votes, hipStream_t st) {
@@ -371,6 +428,24 @@ int dr_pose_error_bwd_f64(const double *models, const double *gt_R, const double
   DR_REQUIRE(models && gt_R && gt_t && which && grad_err_R && grad_err_t && grad_models, "null pointer");
   return dr::pose_error_bwd_launch<double>(models, gt_R, gt_t, which, grad_err_R, grad_err_t, P, M, grad_models,
                                            (hipStream_t)stream);
+}
+
+int dr_recover_pose_mask_f32(const float *matches, const float *models, int P, int M, int N, double distance_threshold,
+                             int32_t *which, uint8_t *mask, void *stream) {
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && mask, "null pointer");
+  hipLaunchKernelGGL((dr::recover_pose_mask_kernel<float>), dim3(M, P), dim3(dr::kPoseThreads), 0, (hipStream_t)stream, matches,
+                     models, M, N, distance_threshold, which, mask);
+  return dr::check_launch("recover_pose_mask_kernel");
+}
+
+int dr_recover_pose_mask_f64(const double *matches, const double *models, int P, int M, int N, double distance_threshold,
+                             int32_t *which, uint8_t *mask, void *stream) {
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && mask, "null pointer");
+  hipLaunchKernelGGL((dr::recover_pose_mask_kernel<double>), dim3(M, P), dim3(dr::kPoseThreads), 0, (hipStream_t)stream, matches,
+                     models, M, N, distance_threshold, which, mask);
+  return dr::check_launch("recover_pose_mask_kernel");
 }
 
 }  // extern "C"

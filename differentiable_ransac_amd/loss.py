@@ -3,9 +3,11 @@
 MatchLoss -- the clamped symmetric-epipolar training loss of the reference (loss.py:107-153), on the fused kernel
 `dr_episym_fwd/bwd`.
 
-The reference obtains the ground-truth inlier mask from `cv2.recoverPose` (cheirality of the triangulated points);
-OpenCV is outside this package, so the mask is an INPUT here (`gt_mask [P,N] bool`; None = all points).  Everything
-else follows the reference: per pair, mean over (models x masked points) of min(error, 1); then the mean over pairs."""
+The reference obtains the ground-truth inlier mask from `cv2.recoverPose(gt_E, pts1, pts2)` (cheirality of the
+triangulated points, loss.py:99,134).  Pass either the mask (`gt_mask [P,N] bool`) or the ground-truth essential matrices
+(`gt_E [P,3,3]`: the mask is then computed by `ops.recover_pose_mask`, the same Horn decomposition + cheirality vote as
+the pose-error kernel); neither = all points.  Everything else follows the reference: per pair, mean over (models x
+masked points) of min(error, 1); then the mean over pairs."""
 import torch
 
 from . import ops
@@ -15,9 +17,12 @@ class MatchLoss(object):
     def __init__(self, fmat=False):
         self.fmat = fmat
 
-    def forward(self, models, matches, gt_mask=None, keep=None):
-        """models [P,M,3,3] (E, or F already mapped to normalised coordinates), matches [P,N,4] normalised, gt_mask [P,N],
-        keep [P,M] bool (models to average over; None = all) -> scalar loss."""
+    def forward(self, models, matches, gt_mask=None, keep=None, gt_E=None):
+        """models [P,M,3,3] (E, or F already mapped to normalised coordinates), matches [P,N,4] normalised, gt_mask [P,N]
+        or gt_E [P,3,3], keep [P,M] bool (models to average over; None = all) -> scalar loss."""
+        if gt_mask is None and gt_E is not None:
+            with torch.no_grad():
+                gt_mask = ops.recover_pose_mask(matches, gt_E)[0][:, 0]
         sums = ops.episym_sums(matches, gt_mask, models, keep)
         P, N, _ = matches.shape
         n_in = gt_mask.sum(1).to(sums.dtype) if gt_mask is not None else torch.full((P,), float(N), device=sums.device)
@@ -54,3 +59,21 @@ class PoseLoss(object):
         return per_pair.mean()
 
     __call__ = forward_average
+
+
+class ClassificationLoss(object):
+    """ClassificationLoss (loss.py:71-104), essential-matrix branch: binary cross-entropy between the per-correspondence
+    inlier probabilities and the inlier mask of `cv2.recoverPose(gt_E, pts1, pts2)` (here `ops.recover_pose_mask`)."""
+
+    def __init__(self, fmat=False):
+        if fmat:
+            raise NotImplementedError("ClassificationLoss: normalise the points by K first (loss.py:81-92)")
+        self.fmat = fmat
+
+    def forward(self, gt_E, matches, probs):
+        """gt_E [P,3,3], matches [P,N,4] normalised, probs [P,N] in (0,1) -> scalar loss."""
+        with torch.no_grad():
+            gt_mask = ops.recover_pose_mask(matches, gt_E)[0][:, 0]
+        return torch.nn.functional.binary_cross_entropy(probs, gt_mask.to(probs.dtype))
+
+    __call__ = forward

@@ -638,3 +638,16 @@ def pose_error(matches, models, gt_R, gt_t, distance_threshold: float = 50.0, wa
     P = matches.shape[0]
     models = models.reshape(P, -1, 3, 3)
     return _PoseError.apply(matches, models, gt_R.reshape(P, 9), gt_t.reshape(P, 3), distance_threshold, want_votes)
+
+
+def recover_pose_mask(matches, models, distance_threshold: float = 50.0):
+    """The inlier mask of cv2.recoverPose(E, pts1, pts2) (what loss.py:99,134 uses as ground-truth inliers): matches
+    [P,N,4] normalised, models [P,M,3,3] or [P,3,3] -> (mask [P,M,N] bool, which [P,M] int32 = winning candidate)."""
+    P, N, _ = matches.shape
+    models = models.reshape(P, -1, 3, 3).to(matches.dtype).contiguous()
+    M = models.shape[1]
+    mask = torch.empty((P, M, N), device=matches.device, dtype=torch.bool)
+    which = torch.empty((P, M), device=matches.device, dtype=torch.int32)
+    L.call(f"dr_recover_pose_mask_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(models), c_int(P), c_int(M),
+           c_int(N), L.c_double(float(distance_threshold)), ptr(which), ptr(mask), stream())
+    return mask, which

@@ -294,6 +294,14 @@ int dr_pose_error_bwd_f64(const double *models, const double *gt_R, const double
                           const double *grad_err_R, const double *grad_err_t, int P, int M, double *grad_models,
                           void *stream);
 
+/* The inlier mask of cv2.recoverPose (loss.py:99,134: the ground-truth inlier mask of ClassificationLoss / MatchLoss):
+ * per (pair, model) the points that pass the cheirality test of the winning one of the four candidate poses.
+ * models [P,M,9] (normally the ground-truth E, M = 1); which [P,M] int32 or NULL; mask [P,M,N] uint8. */
+int dr_recover_pose_mask_f32(const float *matches, const float *models, int P, int M, int N, double distance_threshold,
+                             int32_t *which, uint8_t *mask, void *stream);
+int dr_recover_pose_mask_f64(const double *matches, const double *models, int P, int M, int N, double distance_threshold,
+                             int32_t *which, uint8_t *mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -648,6 +648,25 @@ def cheirality_votes(R1, R2, t, x1, x2, distance_threshold: float = 50.0):
     return torch.stack(votes, dim=-1)
 
 
+def recover_pose_mask(E, matches, distance_threshold: float = 50.0):
+    """The inlier mask cv2.recoverPose returns (loss.py:99,134 use it as the ground-truth inlier mask): the points that
+    pass cheirality_check (cv_utils.py:177-189) for the winning candidate of recoverPose (cv_utils.py:48-80).
+    E [3,3] -> (mask [n] bool, winning candidate)."""
+    R1, R2, t = horn_decompose(E[None])
+    x1, x2 = matches[:, :2], matches[:, 2:]
+    P0 = torch.eye(3, 4, dtype=E.dtype)
+    masks = []
+    for R, tt in ((R1[0], t[0]), (R2[0], t[0]), (R1[0], -t[0]), (R2[0], -t[0])):
+        P = torch.cat((R, tt[:, None]), dim=-1)
+        Q = triangulate_dlt(P0, P, x1, x2)
+        Qh = Q / Q[:, 3:4]
+        d2 = (P[2] * Qh).sum(-1)
+        masks.append((Q[:, 2] * Q[:, 3] > 0) & (Qh[:, 2] < distance_threshold) & (d2 > 0) & (d2 < distance_threshold))
+    votes = torch.stack([m.sum() for m in masks])
+    best = int(votes.argmax())
+    return masks[best], best
+
+
 def rotation_translation_error(R_gt, t_gt, R, t):
     """evaluate_R_t_tensor, cv_utils.py:361-380, batched over the leading dims of R/t: radians."""
     eps = 1e-8

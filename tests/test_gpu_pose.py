@@ -85,3 +85,30 @@ def test_pose_loss_full_size_vs_oracle(dev):
     k = valid.double()
     want = ((((eq + et) / 2) * k).sum(1) / k.sum(1)).mean()
     assert abs(float(loss) - float(want)) < 1e-9
+
+
+def test_recover_pose_mask_and_losses(dev):
+    """cv2.recoverPose's inlier mask (ground truth of MatchLoss / ClassificationLoss) against the oracle's restatement."""
+    from differentiable_ransac_amd import ops, synth
+    from differentiable_ransac_amd.loss import ClassificationLoss, MatchLoss
+    P, N = 3, 600
+    data = synth.batch_two_view(P, N, seed0=120, dtype=torch.float64)
+    m = data["matches"].to(dev)
+    mask, which = ops.recover_pose_mask(m, data["gt_E"].to(dev))
+    assert mask.shape == (P, 1, N) and which.shape == (P, 1)
+    for p in range(P):
+        om, ow = O.recover_pose_mask(data["gt_E"][p], data["matches"][p])
+        assert int(which[p, 0]) == ow
+        assert (mask[p, 0].cpu() != om).sum() == 0
+        # the synthetic inliers are in front of both cameras: nearly all of them pass, and the outliers mostly do not matter
+        assert mask[p, 0].cpu()[data["inliers"][p]].float().mean() > 0.99
+    # MatchLoss with gt_E = MatchLoss with the mask; ClassificationLoss = BCE against the same mask
+    E = (data["gt_E"][:, None] + 0.02 * torch.randn(P, 6, 3, 3, dtype=torch.float64)).float().to(dev)
+    mf = m.float()
+    a = MatchLoss()(E, mf, gt_E=data["gt_E"].float().to(dev))
+    b = MatchLoss()(E, mf, gt_mask=ops.recover_pose_mask(mf, data["gt_E"].float().to(dev))[0][:, 0])
+    assert abs(float(a) - float(b)) < 1e-7
+    probs = torch.rand(P, N, device=dev).clamp(0.01, 0.99)
+    c = ClassificationLoss()(data["gt_E"].float().to(dev), mf, probs)
+    want = torch.nn.functional.binary_cross_entropy(probs, ops.recover_pose_mask(mf, data["gt_E"].float().to(dev))[0][:, 0].float())
+    assert abs(float(c) - float(want)) < 1e-7
