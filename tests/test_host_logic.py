@@ -56,13 +56,25 @@ def test_ops_refuse_cpu_tensors_without_touching_the_gpu():
         ops.topdown_sample(torch.rand(1, 16), 4, 3)
 
 
-def test_pose_loss_rejects_unimplemented_branches():
-    from differentiable_ransac_amd.loss import PoseLoss
-    with pytest.raises(NotImplementedError):
-        PoseLoss(fmat=True)
+def test_pose_loss_rejects_the_svd_branch_and_calibrate_matches_the_reference_formulas():
+    from differentiable_ransac_amd.loss import PoseLoss, calibrate
     with pytest.raises(NotImplementedError):
         PoseLoss().forward_average(torch.zeros(1, 1, 3, 3), torch.zeros(1, 4, 2), torch.zeros(1, 4, 2), torch.eye(3)[None],
                                    torch.ones(1, 3), svd=True)
+    # E = K2^T F K1 ; points: pts * max(im_size) + (w/2, h/2), then (p - c) / f
+    g = torch.Generator().manual_seed(0)
+    F = torch.randn(2, 3, 3, 3, generator=g)
+    K1 = torch.tensor([[[500.0, 0, 320], [0, 510, 240], [0, 0, 1]]]).repeat(2, 1, 1)
+    K2 = torch.tensor([[[700.0, 0, 400], [0, 690, 300], [0, 0, 1]]]).repeat(2, 1, 1)
+    im1, im2 = torch.tensor([[480.0, 640.0]] * 2), torch.tensor([[600.0, 800.0]] * 2)
+    p1, p2 = torch.rand(2, 5, 2, generator=g) - 0.5, torch.rand(2, 5, 2, generator=g) - 0.5
+    Es, q1, q2 = calibrate(F, p1, p2, K1, K2, im1, im2)
+    for b in range(2):
+        assert torch.allclose(Es[b], K2[b].T @ F[b] @ K1[b], atol=1e-3)
+        px = p1[b] * 640.0 + torch.tensor([320.0, 240.0])
+        assert torch.allclose(q1[b], (px - torch.tensor([320.0, 240.0])) / torch.tensor([500.0, 510.0]), atol=1e-6)
+        px2 = p2[b] * 800.0 + torch.tensor([400.0, 300.0])
+        assert torch.allclose(q2[b], (px2 - torch.tensor([400.0, 300.0])) / torch.tensor([700.0, 690.0]), atol=1e-6)
 
 
 def test_ransac_layers_wire_the_plugins_like_the_reference():
