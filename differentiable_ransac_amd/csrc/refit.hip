@@ -108,7 +108,9 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   LaneWs w{lds, 1};   // every lane solves the same system: one shared slot, same-address writes of equal values
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
-  nister_finish<T, false>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane == 0);
+  // like the minimal solver, two lanes share the sample: even lanes search |z| <= 1 and fill the slots from 0 upwards,
+  // odd lanes |z| > 1 from 9 downwards (all 32 lane pairs do the same work; lanes 0 and 1 store)
+  nister_finish<T, true>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane < 2, lane & 1);
 }
 
 template <typename T>
