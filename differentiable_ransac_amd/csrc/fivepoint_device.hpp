@@ -210,14 +210,16 @@ __device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&
 // Final stage shared by both solvers: homogeneous polish of the coefficient vector (x, y, z, 1)/|.|, then a
 // VERIFICATION of the ten constraints on the (unit-norm) matrix.  `valid` therefore means "checked essential matrix
 // through the five points", not "the root finder said so".
+// `dst64` (optional): the same model in f64 as a second output (train mode keeps it for the backward); it also selects the
+// f64 stopping tolerance.
 template <typename T>
 __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double x, double y, double z, bool candidate,
-                                                T *__restrict__ dst, bool store) {
+                                                T *__restrict__ dst, bool store, double *__restrict__ dst64 = nullptr) {
   const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
   double u[4] = {x * inv, y * inv, z * inv, inv};
   bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
   if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
-  polish_homog(nb, u, good, sizeof(T) == 4 ? 1e-17 : 1e-28);
+  polish_homog(nb, u, good, (sizeof(T) == 4 && !dst64) ? 1e-17 : 1e-28);
   double E[9], r[10];
 #pragma unroll
   for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
@@ -230,7 +232,10 @@ __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int jx = 0; jx < 3; ++jx) dst[3 * i + jx] = (T)E[3 * jx + i];   // stored transposed (nister.py:407)
+      for (int jx = 0; jx < 3; ++jx) {
+        dst[3 * i + jx] = (T)E[3 * jx + i];   // stored transposed (nister.py:407)
+        if (dst64) dst64[3 * i + jx] = E[3 * jx + i];
+      }
   }
   return good;
 }
@@ -240,7 +245,8 @@ __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double
 // |z| > 1 and fills downwards from 9; the slots in between become eye(3).
 template <typename T, bool kPair>
 __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const double (&X)[6][10], bool ok, T *__restrict__ models,
-                              uint8_t *__restrict__ valid, bool active, int half = 0) {
+                              uint8_t *__restrict__ valid, bool active, int half = 0,
+                              double *__restrict__ models64 = nullptr) {
   // reduced rows e..j = rows 4..9, right block columns 10..19 hold (x z^2, x z, x | y z^2, y z, y | z^3, z^2, z, 1)
   // k = e - z f, l = g - z h, m = i - z j  ->  B(z) columns (x: deg 3, y: deg 3, 1: deg 4), ascending coefficients
   double bx[3][4], by[3][4], b1[3][5];
@@ -315,7 +321,7 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
     const double x = vx / vw, y = vy / vw;
     const int dst_slot = (kPair && half) ? 9 - slot : slot;
     const bool good = finish_solution<T>(nb, x, y, z, has_root && is_finite(x) && is_finite(y) && slot < 10,
-                                         models + 9 * dst_slot, active);
+                                         models + 9 * dst_slot, active, models64 ? models64 + 9 * dst_slot : nullptr);
     if (good && active) valid[dst_slot] = 1;
     slot += good ? 1 : 0;
   }
@@ -326,12 +332,14 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
     if (active && half == 0) {
       for (int s = min(lo, 10 - hi); s < 10 - hi; ++s) {
         write_identity<T>(models + 9 * s);
+        if (models64) write_identity<double>(models64 + 9 * s);
         valid[s] = 0;
       }
     }
   } else if (active) {
     for (int s = slot; s < 10; ++s) {
       write_identity<T>(models + 9 * s);
+      if (models64) write_identity<double>(models64 + 9 * s);
       valid[s] = 0;
     }
   }

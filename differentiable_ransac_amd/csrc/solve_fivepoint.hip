@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_pair_kernel(
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models,
-    uint8_t *__restrict__ valid) {
+    uint8_t *__restrict__ valid, double *__restrict__ models64) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   const int half = lane & 1;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
   DR_STAGE(2);
-  nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, half);
+  nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, half,
+                         models64 ? models64 + (size_t)sc * 90 : nullptr);
   DR_STAGE(5);
 }
 
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 }
 
 template <typename T>
-int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st) {
+int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st,
+                  double *models64 = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nister5_kernel<T>),
@@ -270,7 +272,7 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
     // minimal samples: two lanes per sample, 100 doubles of LDS per SAMPLE (25 KiB per block => six blocks per CU)
     const size_t smem = sizeof(double) * 100 * 32;
     hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, weights, Bt, models,
-                       valid);
+                       valid, models64);
     return check_launch("nister5_pair_kernel");
   }
   // n > 5 fallback (refit): one lane per sample, A^T A + eigenvectors in LDS (162 doubles)
@@ -304,6 +306,12 @@ int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, i
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(Bt > 0 && n >= 5, "need Bt > 0 and n >= 5 points per sample");
   return dr::nister_launch<double>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
+}
+int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
+                            uint8_t *valid, void *stream) {
+  DR_REQUIRE(samples && models && models_f64 && valid, "null pointer");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, models_f64);
 }
 int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");

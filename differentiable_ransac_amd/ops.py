@@ -253,6 +253,20 @@ def solve_nister5(samples: torch.Tensor, weights: Optional[torch.Tensor] = None)
     return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 
+def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = None):
+    """Minimal f32 samples [..., 5, 4] -> (models f32, models f64, valid): the train-mode entry, one launch."""
+    s, Bt, n = _flat_samples(samples, 4)
+    if n != 5 or s.dtype != torch.float32:
+        raise L.DransacError("solve_nister5_hp takes f32 minimal samples (5 correspondences)")
+    lead = samples.shape[:-2]
+    models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=torch.float32)
+    m64 = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=torch.float64)
+    valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
+    w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
+    L.call("dr_solve_nister5_f32_hp", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), stream())
+    return models.reshape(*lead, 10, 3, 3), m64.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
+
+
 def solve_stewenius5(samples: torch.Tensor):
     s, Bt, n = _flat_samples(samples, 4)
     if n != 5:
@@ -369,9 +383,11 @@ class _SolveEssential(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
         fn = (lambda s_, w_: solve_nister5(s_, w_)) if which == "nister" else (lambda s_, w_: solve_stewenius5(s_))
         need_grad = samples.requires_grad and samples.dtype == torch.float32
-        if need_grad:
-            # train mode: run the f64 entry point on the (exactly representable) f32 samples and keep the f64 models
-            # for the backward -- its tangent-space system is conditioned ~1e5, which f32-rounded models cannot afford
+        if need_grad and which == "nister" and samples.shape[-2] == 5:
+            # train mode: the kernel computes in f64 anyway; it writes the f64 models next to the f32 ones and the backward
+            # keeps them -- its tangent-space system is conditioned ~1e5, which f32-rounded models cannot afford
+            models, m64, valid = solve_nister5_hp(samples, weights)
+        elif need_grad:
             m64, valid = fn(samples.double(), None if weights is None else weights.double())
             models = m64.float()
         else:

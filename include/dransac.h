@@ -120,6 +120,11 @@ int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int
                          void *stream);
 int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, int n, double *models,
                          uint8_t *valid, void *stream);
+/* Train-mode variant of the minimal (n = 5) solve: f32 samples, the models written BOTH as f32 (what the scoring reads)
+ * and as f64 polished to the f64 tolerance (what dr_solve_nister5_bwd_f32 wants as models_f64).  Same models as
+ * dr_solve_nister5_f64 on the widened samples, without the two conversion passes. */
+int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
+                            uint8_t *valid, void *stream);
 int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
 int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
 int dr_solve_f8_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,

@@ -65,6 +65,23 @@ def test_fivepoint_golden(dev, solver, dtype):
     assert d.max() < tol
 
 
+def test_nister_mixed_precision_entry(dev):
+    """dr_solve_nister5_f32_hp (train mode): f64 models equal to the f64 entry on the widened samples up to the f64
+    polish tolerance (the two instantiations are compiled separately, so not bit-for-bit), f32 models the exact
+    rounding of the f64 ones, same valid flags."""
+    from differentiable_ransac_amd import ops
+    g = load_golden("fivepoint")
+    smp = g["samples"].float().to(dev)
+    m32, m64, valid = ops.solve_nister5_hp(smp)
+    r64, rvalid = ops.solve_nister5(smp.double())
+    assert m64.dtype == torch.float64 and m32.dtype == torch.float32
+    assert torch.equal(valid, rvalid)
+    assert (m64 - r64).abs().max() < 1e-12
+    assert torch.equal(m32, m64.float())
+    with pytest.raises(Exception):
+        ops.solve_nister5_hp(smp.double())
+
+
 def test_nister_weighted_and_nonminimal(dev):
     from differentiable_ransac_amd import ops
     g = load_golden("fivepoint")
