@@ -627,7 +627,6 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
   __shared__ T s_val[kUpdThreads / kWave];
   __shared__ int s_idx[kUpdThreads / kWave];
   __shared__ int s_cnt[kUpdThreads / kWave];
-  __shared__ int s_flag;
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int it0 = iters[p];
   if ((double)it0 >= max_iters[p]) return;  // this pair has terminated (uniform across the block)

@@ -1,7 +1,8 @@
 """Multi-GPU sharding of the hot path: image pairs are independent RANSAC problems, so rank r of G
 owns a contiguous block of pairs and runs the full (local pairs x hypotheses) grid with NO data-path collective.
 The only exchanges are (a) the throughput reduction of the benchmark (MAX of elapsed time, SUM of hypotheses) and
-(b) optional result gathering / the gradient all-reduce of the training step (which belongs to the caller's model).
+(b) optional result gathering / the gradient all-reduce of the training step (which belongs to the caller's model),
+and (c) when there are fewer pairs than GPUs, the hypothesis-split merge below (one tiny exchange per pair).
 Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 from __future__ import annotations
@@ -62,3 +63,34 @@ def allreduce_mean_(grads, dist=None) -> None:
     for g in grads:
         g.copy_(flat[off: off + g.numel()].view_as(g))
         off += g.numel()
+
+
+def hypothesis_seed(seed: int, rank: int) -> int:
+    """Sampler seed of `rank` when the HYPOTHESES of one pair are split over ranks (P < G): every rank must draw a
+    different stream.  The in-kernel Philox is keyed by the seed, so distinct seeds are independent streams."""
+    return (int(seed) + 0x9E3779B97F4A7C15 * (int(rank) + 1)) & (2 ** 64 - 1) if rank else int(seed)
+
+
+def merge_best(best_score: torch.Tensor, best_model: torch.Tensor, extras=(), dist=None):
+    """Hypothesis split (SURVEY 8(e), P < G): every rank ran B/G hypotheses on the SAME pairs and holds a local best
+    (score [P], model [P,3,3]); the job's answer per pair is the best over ranks (ties -> lowest rank, the analogue of
+    the first arg-max of ransac.py:109).  One all_gather of the scores and one of the 9-float models (+ any per-pair
+    `extras`, e.g. the inlier count); no collective touches the [P,M,N] data path.
+    Returns (score [P], model [P,3,3], winner_rank [P] int64, extras...)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return (best_score, best_model, torch.zeros(best_score.shape[0], dtype=torch.int64, device=best_score.device),
+                *extras)
+    world = dist.get_world_size()
+
+    def gathered(t):
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t.contiguous())
+        return torch.stack(out, 0)
+
+    sc = gathered(best_score)                                  # [G,P]
+    key = torch.where(torch.isnan(sc), torch.full_like(sc, float("-inf")), sc)
+    top = key.max(0).values
+    ranks = torch.arange(world, device=sc.device)[:, None].expand_as(key)
+    win = torch.where(key == top[None], ranks, torch.full_like(ranks, world)).min(0).values   # first rank at the max
+    pick = lambda t: gathered(t)[win, torch.arange(t.shape[0], device=t.device)]
+    return (pick(best_score), pick(best_model), win, *[pick(e) for e in extras])

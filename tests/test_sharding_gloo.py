@@ -1,5 +1,5 @@
 """N > 1 path on CPU: world-size-2 gloo processes exercise the pair partition, the throughput reduction, the
-result gather and the gradient all-reduce helpers (no GPU compute: the hot path itself has no CPU fallback)."""
+result gather, the gradient all-reduce and the hypothesis-split merge helpers (no GPU compute: the hot path itself has no CPU fallback)."""
 import os
 import socket
 
@@ -49,6 +49,16 @@ def _worker(rank, world, port, q):
         g = [torch.full((3, 2), float(rank + 1)), torch.full((5,), 10.0 * (rank + 1))]
         sharding.allreduce_mean_(g, dist)
         assert torch.allclose(g[0], torch.full((3, 2), 1.5)) and torch.allclose(g[1], torch.full((5,), 15.0))
+        # hypothesis split (P < G): both ranks hold a local best for the SAME pairs; the merge keeps the better one,
+        # ties go to the lowest rank, NaN scores never win
+        sc = torch.tensor([[3.0, 1.0, 5.0, float("nan")], [2.0, 4.0, 5.0, 0.5]])[rank]
+        md = torch.full((4, 3, 3), float(rank))
+        inl = torch.tensor([[30, 10, 50, 0], [20, 40, 51, 5]], dtype=torch.int32)[rank]
+        s, m, w, i = sharding.merge_best(sc, md, (inl,), dist)
+        assert w.tolist() == [0, 1, 0, 1]
+        assert s.tolist() == [3.0, 4.0, 5.0, 0.5] and i.tolist() == [30, 40, 50, 5]
+        assert torch.equal(m[:, 0, 0], w.float())
+        assert sharding.hypothesis_seed(7, 0) == 7 and sharding.hypothesis_seed(7, 1) != sharding.hypothesis_seed(7, 2)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
