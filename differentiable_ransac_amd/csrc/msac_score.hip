@@ -36,6 +36,9 @@
 // alignment is not what the stream costs.  Decomposition at 224 us: arithmetic alone 165 us, + packing/storing the valid
 // rows 26 us, + zero rows of the invalid slots 33 us.  Zero rows written by separate store-only blocks interleaved in the
 // grid (blockIdx.x & 1): 341 us -- the role branch wrecks the code generated for the evaluating path.
+// s = d2 - thr2 by ONE packed fma (score scaled by 1/thr2 once per model) instead of the mul + fma of d2/thr2 - 1: eight
+// instructions fewer per 16 points, identical masks, and 206.6 vs 198.1 us on the same box (scratch/ab_k4_pair.py; 208 us
+// with the addend in an SGPR): slower -- dropped.  Instruction count is not what bounds this loop any more.
 #include "dr_common.hpp"
 
 namespace dr {
