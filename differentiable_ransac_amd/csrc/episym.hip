@@ -22,8 +22,8 @@ __device__ __forceinline__ ev2 esplat(float a) { return (ev2){a, a}; }
 template <bool kBackward>
 __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ matches, const uint8_t *__restrict__ mask,
                                                      const float *__restrict__ models, const uint8_t *__restrict__ valid,
-                                                     const float *__restrict__ grad_sums, int M, int N,
-                                                     float *__restrict__ out) {
+                                                     const float *__restrict__ grad_sums, int grad_per_pair, int M,
+                                                     int N, float *__restrict__ out) {
   // forward: out = sums [P,M]; backward: out = grad_models [P,M,9]
   constexpr int kV = kBackward ? 9 : 1;
   constexpr int kMW = kEM / (kET / 64);   // models per wave
@@ -139,12 +139,46 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
   for (int mi = 0; mi < kMW; ++mi) {
     const int m = m0 + wv * kMW + mi;
     if (m >= M) continue;
-    const float gs = kBackward ? grad_sums[(size_t)p * M + m] : 1.f;
+    const float gs = kBackward ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] : 1.f;
 #pragma unroll
     for (int q = 0; q < kV; ++q) {
       const float v = wave_sum_lane63(acc[mi][q][0] + acc[mi][q][1]);
       if (lane == 63) out[((size_t)p * M + m) * kV + q] = v * gs;
     }
+  }
+}
+
+// MatchLoss's reduction over the models of a pair (loss.py:146-153 with the per-pair means written out):
+//     per_pair[p] = sum_m sums[p,m] / max(n_in[p] * n_models[p], 1),   coef[p] = 1 / max(n_in[p] * n_models[p], 1)
+// n_in = number of selected points (mask; NULL = N), n_models = number of kept models (keep; NULL = M).  One block per
+// pair; every reduction is in a fixed order (lane partials, DPP wave sum, waves in order), so the loss is reproducible.
+__global__ __launch_bounds__(kET) void match_loss_pair_kernel(const float *__restrict__ sums, const uint8_t *__restrict__ mask,
+                                                              const uint8_t *__restrict__ keep, int M, int N,
+                                                              float *__restrict__ per_pair, float *__restrict__ coef) {
+  __shared__ float s_sum[kET / 64];
+  __shared__ int s_in[kET / 64], s_kept[kET / 64];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float acc = 0.f;
+  int n_in = 0, n_kept = 0;
+  for (int m = tid; m < M; m += kET) {
+    acc += sums[(size_t)p * M + m];
+    if (keep) n_kept += keep[(size_t)p * M + m] != 0;
+  }
+  if (mask)
+    for (int n = tid; n < N; n += kET) n_in += mask[(size_t)p * N + n] != 0;
+  acc = wave_sum_lane63(acc);
+  n_in = wave_sum(n_in);
+  n_kept = wave_sum(n_kept);
+  if (lane == 63) s_sum[wv] = acc;
+  if (lane == 0) { s_in[wv] = n_in; s_kept[wv] = n_kept; }
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.f;
+    int in = 0, kept = 0;
+    for (int w = 0; w < kET / 64; ++w) { total += s_sum[w]; in += s_in[w]; kept += s_kept[w]; }
+    const float den = fmaxf((float)(mask ? in : N) * (float)(keep ? kept : M), 1.0f);
+    per_pair[p] = total / den;
+    coef[p] = 1.0f / den;
   }
 }
 
@@ -157,7 +191,7 @@ int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *mo
   DR_REQUIRE(matches && models && sums, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::episym_kernel<false>), dim3((M + dr::kEM - 1) / dr::kEM, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, M, N, sums);
+                     (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, 0, M, N, sums);
   return dr::check_launch("episym_kernel");
 }
 
@@ -166,8 +200,26 @@ int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *mo
   DR_REQUIRE(matches && models && grad_sums && grad_models, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + dr::kEM - 1) / dr::kEM, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, grad_sums, M, N, grad_models);
+                     (hipStream_t)stream, matches, mask, models, valid, grad_sums, 0, M, N, grad_models);
   return dr::check_launch("episym_kernel");
+}
+
+int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
+                           const float *grad_pair, int P, int M, int N, float *grad_models, void *stream) {
+  DR_REQUIRE(matches && models && grad_pair && grad_models, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + dr::kEM - 1) / dr::kEM, 1, P), dim3(dr::kET), 0,
+                     (hipStream_t)stream, matches, mask, models, valid, grad_pair, 1, M, N, grad_models);
+  return dr::check_launch("episym_kernel");
+}
+
+int dr_match_loss_pair_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,
+                           float *per_pair, float *coef, void *stream) {
+  DR_REQUIRE(sums && per_pair && coef, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0, "bad sizes");
+  hipLaunchKernelGGL(dr::match_loss_pair_kernel, dim3(P), dim3(dr::kET), 0, (hipStream_t)stream, sums, mask, keep, M, N,
+                     per_pair, coef);
+  return dr::check_launch("match_loss_pair_kernel");
 }
 
 }  // extern "C"

@@ -56,12 +56,8 @@ class MatchLoss(object):
         if gt_mask is None and gt_E is not None:
             with torch.no_grad():
                 gt_mask = ops.recover_pose_mask(matches, gt_E)[0][:, 0]
-        sums = ops.episym_sums(matches, gt_mask, models, keep)
-        P, N, _ = matches.shape
-        n_in = gt_mask.sum(1).to(sums.dtype) if gt_mask is not None else torch.full((P,), float(N), device=sums.device)
-        n_models = keep.sum(1).to(sums.dtype) if keep is not None else torch.full((P,), float(sums.shape[1]), device=sums.device)
-        per_pair = sums.sum(1) / (n_in * n_models).clamp(min=1.0)
-        return per_pair.mean()
+        # per pair: sum of the clamped errors / max(#masked points * #kept models, 1) -- two launches, see ops._MatchLossPair
+        return ops.match_loss_per_pair(matches, gt_mask, models, keep).mean()
 
     __call__ = forward
 

@@ -607,6 +607,52 @@ def episym_sums(matches, mask, models, valid=None):
     return _EpisymSums.apply(matches, mask, models.reshape(models.shape[0], -1, 3, 3), valid)
 
 
+class _MatchLossPair(torch.autograd.Function):
+    """episym forward + the per-pair reduction of MatchLoss in two launches; backward in one tiny torch op + one launch
+    (the per-pair gradient goes straight into the episym backward: no [P,M] gradient tensor)."""
+
+    @staticmethod
+    def forward(ctx, matches, mask, models, keep):
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        matches, models = matches.contiguous(), models.contiguous()
+        mk = None if mask is None else mask.contiguous().view(torch.uint8)
+        v = None if keep is None else keep.contiguous().view(torch.uint8)
+        sums = torch.empty((P, M), device=matches.device, dtype=matches.dtype)
+        L.call("dr_episym_fwd_f32", ptr(matches), ptr(mk), ptr(models), ptr(v), c_int(P), c_int(M), c_int(N), ptr(sums),
+               stream())
+        per_pair = torch.empty((P,), device=matches.device, dtype=matches.dtype)
+        coef = torch.empty((P,), device=matches.device, dtype=matches.dtype)
+        L.call("dr_match_loss_pair_f32", ptr(sums), ptr(mk), ptr(v), c_int(P), c_int(M), c_int(N), ptr(per_pair), ptr(coef),
+               stream())
+        ctx.save_for_backward(matches, models, coef)
+        ctx.aux = (mk, v)
+        return per_pair
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        matches, models, coef = ctx.saved_tensors
+        mk, v = ctx.aux
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        gp = (g * coef).contiguous()
+        gm = torch.empty_like(models)   # every slot is written (invalid: 0)
+        L.call("dr_episym_bwd_pair_f32", ptr(matches), ptr(mk), ptr(models), ptr(v), ptr(gp), c_int(P), c_int(M), c_int(N),
+               ptr(gm), stream())
+        return None, None, gm, None
+
+
+def match_loss_per_pair(matches, mask, models, keep=None):
+    """MatchLoss per pair: mean over the kept models and the masked points of min(symmetric epipolar error, 1).
+    matches [P,N,4] f32, mask [P,N] bool | None, models [P,M,3,3], keep [P,M] bool | None -> [P] (differentiable w.r.t.
+    models)."""
+    if matches.dtype != torch.float32:
+        raise L.DransacError("match_loss_per_pair is implemented for f32")
+    return _MatchLossPair.apply(matches, mask, models.reshape(models.shape[0], -1, 3, 3), keep)
+
+
 # ------------------------------------------------------------------------------------------ PoseLoss pose error (8(f) rank 3)
 class _PoseError(torch.autograd.Function):
     @staticmethod

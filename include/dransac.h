@@ -273,6 +273,15 @@ int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *mo
                       int N, float *sums, void *stream);
 int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
                       const float *grad_sums, int P, int M, int N, float *grad_models, void *stream);
+/* The rest of MatchLoss.forward (loss.py:146-153: mean over the GT-inlier points, mean over the models, per pair):
+ *   per_pair[p] = sum_m sums[p,m] / max(n_in[p] * n_models[p], 1),  coef[p] = 1 / max(n_in[p] * n_models[p], 1)
+ * with n_in = number of points with mask != 0 (NULL = N) and n_models = number of slots with keep != 0 (NULL = M); the
+ * mean over pairs stays with the caller.  dr_episym_bwd_pair is dr_episym_bwd with ONE gradient per pair
+ * (grad_pair[p] = d loss / d sums[p, m] for every m, i.e. upstream gradient x coef[p]). */
+int dr_match_loss_pair_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,
+                           float *per_pair, float *coef, void *stream);
+int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
+                           const float *grad_pair, int P, int M, int N, float *grad_models, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * pose error of essential matrices -- the body of PoseLoss.forward_average (loss.py:11-68) =

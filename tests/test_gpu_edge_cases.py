@@ -93,6 +93,39 @@ def test_f64_end_to_end(dev):
         assert (O.canonical(out["model"][p].cpu()) - O.canonical(m)).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("P,N,M,masked,kept", [(1, 7, 1, True, True), (2, 33, 5, False, False), (3, 1030, 19, True, True),
+                                               (2, 2500, 300, True, False), (2, 64, 1024, False, True)])
+def test_match_loss_per_pair_reduction(dev, P, N, M, masked, kept):
+    """The fused per-pair reduction (dr_match_loss_pair + dr_episym_bwd_pair) against the composition it replaces
+    (episym sums, then the means in torch): with / without mask and keep flags, a pair without any selected point, a pair
+    without any kept model (denominator clamped to 1), forward and backward."""
+    from differentiable_ransac_amd import ops
+    g = torch.Generator().manual_seed(P * 77 + N + M)
+    m = (torch.rand(P, N, 4, generator=g) - 0.5).to(dev)
+    E = torch.randn(P, M, 3, 3, generator=g)
+    mask = (torch.rand(P, N, generator=g) < 0.5).to(dev) if masked else None
+    keep = (torch.rand(P, M, generator=g) < 0.6).to(dev) if kept else None
+    if masked and P > 1:
+        mask[0] = False
+    if kept and P > 1:
+        keep[-1] = False
+    wts = torch.rand(P, generator=g).to(dev)
+    Ea = E.clone().to(dev).requires_grad_(True)
+    got = ops.match_loss_per_pair(m, mask, Ea, keep)
+    (got * wts).sum().backward()
+    Eb = E.clone().to(dev).requires_grad_(True)
+    sums = ops.episym_sums(m, mask, Eb, keep)
+    n_in = mask.sum(1).float() if masked else torch.full((P,), float(N), device=dev)
+    n_models = keep.sum(1).float() if kept else torch.full((P,), float(M), device=dev)
+    want = sums.sum(1) / (n_in * n_models).clamp(min=1.0)
+    (want * wts).sum().backward()
+    assert got.shape == (P,)
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-9)
+    assert torch.allclose(Ea.grad, Eb.grad, rtol=1e-5, atol=1e-9 + 1e-6 * float(Eb.grad.abs().max()))
+    if kept:
+        assert (Ea.grad[~keep] == 0).all()
+
+
 @pytest.mark.parametrize("P,N,M,masked", [(1, 7, 1, True), (2, 33, 5, False), (3, 1030, 19, True), (1, 2500, 9, True)])
 def test_match_loss_kernel_odd_sizes(dev, P, N, M, masked):
     """MatchLoss kernels on ragged sizes (N not a multiple of the lane tile, more than one 2048-point chunk, model count
