@@ -96,7 +96,9 @@ __device__ __forceinline__ double row_max(double v) { return wave_max(v); }
 __device__ __forceinline__ float row_sum(float v) { return wave_sum_bcast(v); }
 __device__ __forceinline__ double row_sum(double v) { return wave_sum(v); }
 
-template <typename T, bool kCache>
+// kSoft = false: index sets only (y_sel, lse and the dense outputs are all NULL) -- RANSAC test mode consumes nothing
+// but `samples != 0` (ransac.py:65), so the soft-max statistics of the row (one exp per element) are skipped.
+template <typename T, bool kCache, bool kSoft>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelArgs<T> a, int32_t *__restrict__ idx,
                                                                         T *__restrict__ y_sel, T *__restrict__ lse_out,
                                                                         T *__restrict__ y_soft, T *__restrict__ ret,
@@ -130,16 +132,21 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
     }
     T gm = fmax(fmax(g[0], g[1]), fmax(g[2], g[3]));
     lmax = fmax(lmax, gm);
-    if (gm > mx) { sm *= exp_t<T>(mx - gm); mx = gm; }
+    if (kSoft) {
+      if (gm > mx) { sm *= exp_t<T>(mx - gm); mx = gm; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm += exp_t<T>(g[j] - mx);
+      for (int j = 0; j < 4; ++j) sm += exp_t<T>(g[j] - mx);
+    }
   }
   // wave-wide soft-max statistics
-  T wmx = row_max(mx);
-  sm *= (mx == -INFINITY) ? T(0) : exp_t<T>(mx - wmx);
-  sm = row_sum(sm);
-  const T lse = wmx + log_t<T>(sm);
-  const T inv_sm = T(1) / sm;   // y = exp(g - max) / sum: exact to rounding even when |g| is huge (lse alone is not)
+  T wmx = T(0), lse = T(0), inv_sm = T(0);
+  if (kSoft) {
+    wmx = row_max(mx);
+    sm *= (mx == -INFINITY) ? T(0) : exp_t<T>(mx - wmx);
+    sm = row_sum(sm);
+    lse = wmx + log_t<T>(sm);
+    inv_sm = T(1) / sm;   // y = exp(g - max) / sum: exact to rounding even when |g| is huge (lse alone is not)
+  }
 
   // ---------------- threshold: k-th largest lane maximum
   T v = lmax, thr = -INFINITY;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
     }
     if (win) {
       idx[row * a.k + pos] = ci;
-      y_sel[row * a.k + pos] = exp_t<T>(cv - wmx) * inv_sm;
+      if (kSoft) y_sel[row * a.k + pos] = exp_t<T>(cv - wmx) * inv_sm;
       s_win[wv][pos] = ci;
     }
   } else {
@@ -238,14 +245,14 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
       int pos = 0;
       for (int r = 0; r < a.k; ++r) pos += won[r] < me;
       idx[row * a.k + pos] = me;
-      y_sel[row * a.k + pos] = exp_t<T>(mg - wmx) * inv_sm;
+      if (kSoft) y_sel[row * a.k + pos] = exp_t<T>(mg - wmx) * inv_sm;
       s_win[wv][pos] = me;
     }
   }
-  if (lane == 0) lse_out[row] = lse;
+  if (kSoft && lane == 0) lse_out[row] = lse;
 
   // ---------------- optional dense outputs (API-faithful mode)
-  if (y_soft || ret) {
+  if (kSoft && (y_soft || ret)) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     int mine[kMaxK];
@@ -283,12 +290,22 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
   const size_t cache = (size_t)kRowsPerBlock * groups * 4 * sizeof(T);
   dim3 grid((B + kRowsPerBlock - 1) / kRowsPerBlock, P);
   dim3 block(kRowsPerBlock * 64);
-  if (base + cache <= 64 * 1024)
-    hipLaunchKernelGGL((gumbel_topk_kernel<T, true>), grid, block, base + cache, st, a, idx, y_sel, lse, y_soft, ret,
-                       gumbel_out);
-  else
-    hipLaunchKernelGGL((gumbel_topk_kernel<T, false>), grid, block, base, st, a, idx, y_sel, lse, y_soft, ret,
-                       gumbel_out);
+  const bool soft = y_sel != nullptr;   // the entry points have checked: y_sel and lse both given, or neither (then no dense outputs)
+  if (base + cache <= 64 * 1024) {
+    if (soft)
+      hipLaunchKernelGGL((gumbel_topk_kernel<T, true, true>), grid, block, base + cache, st, a, idx, y_sel, lse, y_soft, ret,
+                         gumbel_out);
+    else
+      hipLaunchKernelGGL((gumbel_topk_kernel<T, true, false>), grid, block, base + cache, st, a, idx, y_sel, lse, y_soft,
+                         ret, gumbel_out);
+  } else {
+    if (soft)
+      hipLaunchKernelGGL((gumbel_topk_kernel<T, false, true>), grid, block, base, st, a, idx, y_sel, lse, y_soft, ret,
+                         gumbel_out);
+    else
+      hipLaunchKernelGGL((gumbel_topk_kernel<T, false, false>), grid, block, base, st, a, idx, y_sel, lse, y_soft, ret,
+                         gumbel_out);
+  }
   return check_launch("gumbel_topk_kernel");
 }
 
@@ -519,7 +536,9 @@ __global__ void gather_bwd_kernel(const T *__restrict__ matches, const int32_t *
 extern "C" {
 
 #define DR_GUMBEL_CHECK()                                                          \
-  DR_REQUIRE(idx && y_sel && lse, "null output pointer");                          \
+  DR_REQUIRE(idx, "null output pointer");                                          \
+  DR_REQUIRE((y_sel != nullptr) == (lse != nullptr), "y_sel and lse: pass both or neither (index sets only)"); \
+  DR_REQUIRE(y_sel || (!y_soft && !ret), "the dense outputs need y_sel and lse");    \
   DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535, "bad sizes");                  \
   DR_REQUIRE(k >= 1 && k <= dr::kMaxK && k <= N, "k must be in [1, 8] and <= N");  \
   DR_REQUIRE(tau > 0, "tau must be positive")

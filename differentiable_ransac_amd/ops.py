@@ -110,12 +110,15 @@ def ransac_update(state: RansacState, matches, models, valid, scores, thr, B: in
 # ------------------------------------------------------------------------------------------ K1 / K1u / K2
 def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0,
                 gumbel: Optional[torch.Tensor] = None, seed: int = 0, N: Optional[int] = None,
-                dense: bool = False, want_noise: bool = False, device=None, dtype=torch.float32):
+                dense: bool = False, want_noise: bool = False, device=None, dtype=torch.float32, soft: bool = True):
     """K1 forward.  logits [P,N] (or None = all-ones, then pass N/device/dtype); gumbel [P,B,N] explicit
     noise or None (in-kernel Philox keyed by `seed`).
 
     Returns dict(idx [P,B,k] int32 ascending, y_sel [P,B,k], lse [P,B]) plus, when `dense`,
-    y_soft / ret [P,B,N], and when `want_noise`, gumbel [P,B,N] (the noise the kernel used)."""
+    y_soft / ret [P,B,N], and when `want_noise`, gumbel [P,B,N] (the noise the kernel used).
+    soft=False: index sets only (y_sel = lse = None) -- what test mode consumes; the same idx, a cheaper kernel."""
+    if not soft and dense:
+        raise ValueError("the dense outputs need the soft-max statistics (soft=True)")
     if logits is not None:
         logits = logits.contiguous()
         P, N = logits.shape
@@ -127,8 +130,8 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
         gumbel = gumbel.contiguous()
         assert gumbel.shape == (P, B, N) and gumbel.dtype == dtype
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
-    y_sel = torch.empty((P, B, k), device=device, dtype=dtype)
-    lse = torch.empty((P, B), device=device, dtype=dtype)
+    y_sel = torch.empty((P, B, k), device=device, dtype=dtype) if soft else None
+    lse = torch.empty((P, B), device=device, dtype=dtype) if soft else None
     y_soft = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
     ret = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
     noise = torch.empty((P, B, N), device=device, dtype=dtype) if want_noise else None

@@ -71,9 +71,14 @@ class RANSAC(object):
         if _is_gumbel(self.sampler_id):
             seed = self.sampler._next_seed()
             g = None if gumbels is None else gumbels.unsqueeze(0)
-            samples, w, _ = ops.SampleGather.apply(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), B, k,
-                                                   self.sampler.tau, g, seed)
-            samples, w = samples[0], w[0]
+            lg = logits.unsqueeze(0).to(matches.dtype)
+            if not self.train and not self.weighted:
+                # test mode: `points[samples != 0]` (ransac.py:65) -- the index sets and the points themselves
+                idx = ops.gumbel_topk(lg, B, k, self.sampler.tau, g, seed, soft=False)["idx"]
+                samples, w = ops.gather(matches.unsqueeze(0), idx)[0], None
+            else:
+                samples, w, _ = ops.SampleGather.apply(matches.unsqueeze(0), lg, B, k, self.sampler.tau, g, seed)
+                samples, w = samples[0], w[0]
         else:
             idx = self.sampler.sample(matches.shape[0])
             samples, w = matches[idx], None
@@ -285,6 +290,11 @@ class BatchedRANSAC(object):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
         if self.sampling == "topdown" and gumbels is None:
             idx = ops.topdown_sample(logits, self.B, self.k, self._next_seed())
+            samples, w = ops.gather(matches, idx), None
+        elif not self.train and not self.weighted:
+            # test mode consumes the index sets only (`points[samples != 0]`, ransac.py:65): no soft-max statistics, and
+            # the samples are the points themselves (not points x a straight-through value of 1 +- 1 ulp)
+            idx = ops.gumbel_topk(logits, self.B, self.k, self.tau, gumbels, self._next_seed(), soft=False)["idx"]
             samples, w = ops.gather(matches, idx), None
         else:
             samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, self._next_seed())

@@ -52,6 +52,8 @@ const char *dr_last_error(void);
  *   optional dense outputs (API-faithful mode) y_soft [P,B,N], ret [P,B,N] = y_hard - y + y
  *   (gumbel_sampler.py:38) and gumbel_out [P,B,N] (the noise that was used); NULL to skip.
  *   logits == NULL  -> all-ones logits (gumbel_sampler.py:27-28).
+ *   y_sel == NULL and lse == NULL (both, and then no dense outputs) -> index sets only: what test mode consumes
+ *   (`points[samples != 0]`, ransac.py:65); the same idx, without the soft-max statistics of the rows.
  * ------------------------------------------------------------------------------------------ */
 int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
                            int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,

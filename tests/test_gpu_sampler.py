@@ -45,6 +45,32 @@ def test_gumbel_vs_oracle_explicit_noise(dev, N, B, k):
             assert (r["y_soft"][p].cpu() - y_soft).abs().max() < 2e-6
 
 
+@pytest.mark.parametrize("N,B,k,dtype", [(2000, 1024, 5, torch.float32), (131, 7, 3, torch.float32), (5, 3, 5, torch.float32),
+                                          (50000, 16, 3, torch.float32), (2000, 64, 8, torch.float64)])
+def test_gumbel_index_only_mode(dev, N, B, k, dtype):
+    """soft=False (y_sel = lse = NULL: what test mode consumes) returns exactly the index sets of the full kernel, with
+    explicit noise and with the in-kernel generator, with ties (slow path) too; half-specified outputs are refused."""
+    from differentiable_ransac_amd import ops, synth, _lib as L
+    P = 2
+    logits = torch.stack([synth.two_view_pair(20 + p, N)["logits"] for p in range(P)]).to(dtype).to(dev)
+    noise = synth.gumbel_noise((P, B, N), seed=N + k).to(dtype).to(dev)
+    for g, seed in ((noise, 0), (None, 77)):
+        full = ops.gumbel_topk(logits, B, k, 0.7, g, seed=seed)
+        only = ops.gumbel_topk(logits, B, k, 0.7, g, seed=seed, soft=False)
+        assert only["y_sel"] is None and only["lse"] is None
+        assert torch.equal(full["idx"], only["idx"])
+    flat = torch.zeros(P, N, dtype=dtype, device=dev)
+    assert torch.equal(ops.gumbel_topk(flat, B, k, 1.0, torch.zeros_like(noise), soft=False)["idx"].cpu(),
+                       torch.arange(k, dtype=torch.int32).expand(P, B, k))
+    with pytest.raises(ValueError):
+        ops.gumbel_topk(logits, B, k, soft=False, dense=True)
+    idx = torch.empty(P, B, k, dtype=torch.int32, device=dev)
+    ysel = torch.empty(P, B, k, dtype=dtype, device=dev)
+    with pytest.raises(L.DransacError):     # y_sel without lse
+        L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", L.ptr(logits), None, L.c_uint64(1), L.scalar(dtype, 1.0), L.c_int(P),
+               L.c_int(B), L.c_int(N), L.c_int(k), L.ptr(idx), L.ptr(ysel), None, None, None, None, L.stream())
+
+
 def test_gumbel_ties_take_the_slow_path(dev):
     from differentiable_ransac_amd import ops
     N, B, k = 300, 5, 4
