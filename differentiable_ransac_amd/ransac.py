@@ -9,7 +9,7 @@ only sequence launches and keep the (tiny) per-pair state.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 

@@ -38,7 +38,7 @@ masks (the reference drops failed samples and so returns ragged tensors);
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -1,5 +1,4 @@
 """K1 / K1u / K2 parity on the GPU."""
-import numpy as np
 import pytest
 import torch
 
