@@ -28,6 +28,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef DR_Q_TIE
 #define DR_Q_TIE 1
 #endif
+#ifndef DR_Q_NOEPI
+#define DR_Q_NOEPI 0   // 1: timing decomposition only -- the epilogue reduced to one add per model (wrong results)
+#endif
 constexpr int kQT = DR_Q_THREADS, kQTile = 64, kQG = 10, kQWavePts = 512, kQChunk = (kQT / 64) * kQWavePts;
 
 // f32 -> (hi, mid, lo) bf16 bit patterns (low 16 bits of each result) by round-to-nearest splits: hi + mid + lo == x exactly
@@ -183,6 +186,10 @@ __global__ __launch_bounds__(kQT) __attribute__((amdgpu_waves_per_eu(DR_Q_WAVES,
             for (int jj = 0; jj < 5; ++jj) {
               const float a0 = C1[3 * jj], a1 = C1[3 * jj + 1], a2 = C1[3 * jj + 2];
               const float b0 = C2[2 * jj], b1f = C2[2 * jj + 1];
+              if (DR_Q_NOEPI) {
+                acc[g][jj] += a0 + b0;
+                continue;
+              }
               const float r = fmaf(x1, a0, fmaf(y1, a1, a2));
               const float J = fmaf(a0, a0, fmaf(a1, a1, fmaf(b0, b0, b1f * b1f)));
               const float sv = fmaf((r * r) * __builtin_amdgcn_rcpf(J), inv_thr2, -1.0f);

@@ -4,7 +4,9 @@ production kernel on the benchmark shape -- scores, mask bits, time.
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
 VARIANTS = {'base': [], 'notie': ['-DDR_Q_TIE=0'], 't128w3': ['-DDR_Q_THREADS=128', '-DDR_Q_WAVES=3'],
-            't128w3notie': ['-DDR_Q_THREADS=128', '-DDR_Q_WAVES=3', '-DDR_Q_TIE=0'], 'slp': []}
+            't128w3notie': ['-DDR_Q_THREADS=128', '-DDR_Q_WAVES=3', '-DDR_Q_TIE=0'], 'slp': [],
+            'noepi': ['-DDR_Q_NOEPI=1']}   # noepi: timing decomposition only (wrong results)
+NOMASK = os.environ.get('K4_NOMASK') == '1'   # pass masks = NULL: no mask stores, no zero rows
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -42,7 +44,7 @@ for name in (sys.argv[1:] or list(VARIANTS)):
   def run():
       rc = lib.dr_msac_score_bf16x3_f32(ctypes.c_void_p(mt.data_ptr()), ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(vflat.data_ptr()),
                                         ctypes.c_void_p(thr.data_ptr()), P, M, N, ctypes.c_void_p(scores.data_ptr()),
-                                        ctypes.c_void_p(masks.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                        None if NOMASK else ctypes.c_void_p(masks.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
       assert rc == 0, rc
   run(); torch.cuda.synchronize()
   v = valid.reshape(P, -1)
