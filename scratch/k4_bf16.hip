@@ -28,6 +28,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef DR_Q_TIE
 #define DR_Q_TIE 1
 #endif
+#ifndef DR_Q_PIPE
+#define DR_Q_PIPE 0    // 1: step s+1's MFMAs are issued before step s's epilogue (explicit software pipeline; UNTESTED on the
+                       // device at the time of writing -- compiles, 0 spills, MFMAs sit in front of the epilogues in the ISA)
+#endif
 #ifndef DR_Q_NOEPI
 #define DR_Q_NOEPI 0   // 1: timing decomposition only -- the epilogue reduced to one add per model (wrong results)
 #endif
@@ -160,6 +164,76 @@ __global__ __launch_bounds__(kQT) __attribute__((amdgpu_waves_per_eu(DR_Q_WAVES,
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
 
+#if DR_Q_PIPE
+    // ---- software pipeline over the 4 * ng (point, group) steps of a four-point batch
+    auto epilogue = [&](const f32x16 &C1, const f32x16 &C2, float x1, float y1, int ti, float (&ac)[5], uint32_t (&mw)[5]) {
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) {
+        const float a0 = C1[3 * jj], a1 = C1[3 * jj + 1], a2 = C1[3 * jj + 2];
+        const float b0 = C2[2 * jj], b1f = C2[2 * jj + 1];
+        const float r = fmaf(x1, a0, fmaf(y1, a1, a2));
+        const float J = fmaf(a0, a0, fmaf(a1, a1, fmaf(b0, b0, b1f * b1f)));
+        const float sv = fmaf((r * r) * __builtin_amdgcn_rcpf(J), inv_thr2, -1.0f);
+        const uint32_t bits = __float_as_uint(sv);
+        ac[jj] += __int_as_float(min((int)bits, 0));
+        mw[jj] = sign_into_byte(ti, bits, mw[jj]);
+      }
+    };
+    float4 nxt[4];   // the next batch's points, requested one batch ahead
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) nxt[ti] = have ? mt[n0 + ti] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int tq = 0; tq < 4; ++tq) {
+      float x1[4], y1[4];
+      bf16x8 B1[4], B2[4];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        uint32_t w1[2], w2[2];
+        point_frag(half ? nxt[ti].w : nxt[ti].z, w1);
+        point_frag(half ? nxt[ti].y : nxt[ti].x, w2);
+        B1[ti] = point_operand(w1);
+        B2[ti] = point_operand(w2);
+        x1[ti] = nxt[ti].x;
+        y1[ti] = nxt[ti].y;
+      }
+      if (tq < 3) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) nxt[ti] = have ? mt[n0 + 4 * (tq + 1) + ti] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      uint32_t mkq[ng][5];
+#pragma unroll
+      for (int g = 0; g < ng; ++g)
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) mkq[g][jj] = 0u;
+      constexpr int S = 4 * ng;
+      f32x16 Ca1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1[0]), B1[0], z, 0, 0, 0);
+      f32x16 Ca2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2[0]), B2[0], z, 0, 0, 0);
+#pragma unroll
+      for (int st = 0; st < S; ++st) {
+        const int ti = st / ng, g = st % ng;
+        f32x16 Cb1 = Ca1, Cb2 = Ca2;
+        if (st + 1 < S) {
+          const int tn = (st + 1) / ng, gn = (st + 1) % ng;
+          Cb1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1[gn]), B1[tn], z, 0, 0, 0);
+          Cb2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2[gn]), B2[tn], z, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the machine scheduler keeps the MFMAs of step st+1 above this epilogue
+        epilogue(Ca1, Ca2, x1[ti], y1[ti], ti, acc[g], mkq[g]);
+        // and the IR keeps step st+2's MFMAs below it: their model operands pass through an empty asm that reads acc
+        if (st + 2 < S) {
+          const int g2 = (st + 2) % ng;
+          asm volatile("" : "+v"(A1[g2]), "+v"(A2[g2]) : "v"(acc[g][0]), "v"(acc[g][4]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Ca1 = Cb1;
+        Ca2 = Cb2;
+      }
+#pragma unroll
+      for (int g = 0; g < ng; ++g)
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) stage[wv][g * 5 + jj][tq][lane] = mkq[g][jj] & 0x01010101u;
+    }
+#else
 #pragma unroll 1
     for (int tq = 0; tq < 4; ++tq) {
       float4 pt[4];
@@ -208,6 +282,7 @@ __global__ __launch_bounds__(kQT) __attribute__((amdgpu_waves_per_eu(DR_Q_WAVES,
 #pragma unroll
         for (int jj = 0; jj < 5; ++jj) stage[wv][g * 5 + jj][tq][lane] = mkq[g][jj] & 0x01010101u;
     }
+#endif
     // the staged words are read back by the lane that wrote them: no barrier, only the LDS counter
 #pragma unroll
     for (int g = 0; g < ng; ++g) {

@@ -5,7 +5,7 @@ import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
 VARIANTS = {'base': [], 'notie': ['-DDR_Q_TIE=0'], 't128w3': ['-DDR_Q_THREADS=128', '-DDR_Q_WAVES=3'],
             't128w3notie': ['-DDR_Q_THREADS=128', '-DDR_Q_WAVES=3', '-DDR_Q_TIE=0'], 'slp': [],
-            'noepi': ['-DDR_Q_NOEPI=1']}   # noepi: timing decomposition only (wrong results)
+            'noepi': ['-DDR_Q_NOEPI=1'], 'pipe': ['-DDR_Q_PIPE=1'], 'pipe128': ['-DDR_Q_PIPE=1', '-DDR_Q_THREADS=128']}   # noepi: timing decomposition only (wrong results)
 NOMASK = os.environ.get('K4_NOMASK') == '1'   # pass masks = NULL: no mask stores, no zero rows
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
