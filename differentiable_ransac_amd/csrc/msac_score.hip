@@ -40,6 +40,7 @@
 // instructions fewer per 16 points, identical masks, and 206.6 vs 198.1 us on the same box (scratch/ab_k4_pair.py; 208 us
 // with the addend in an SGPR): slower -- dropped.  Instruction count is not what bounds this loop any more.
 #include "dr_common.hpp"
+#include "msac_filter.hpp"
 
 namespace dr {
 
@@ -730,10 +731,17 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
   for (int n = threadIdx.x; n < N; n += blockDim.x) best_mask[(size_t)p * N + n] = 0;
 }
 
+// path: 0 = choose (the matrix-core filter kernel of msac_filter.hip when the shape allows and fills the chip, else the
+// general kernels here), 1 = general kernels, 2 = filter kernel (the caller has checked msac_filter_supported)
 template <typename T>
 int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, const T *thr, int P, int M, int N,
-                      T *scores, uint8_t *masks, hipStream_t st) {
+                      T *scores, uint8_t *masks, hipStream_t st, int path = 0) {
   constexpr bool kFast = sizeof(T) == 4;
+  if constexpr (kFast) {
+    if (path == 2 || (path == 0 && msac_filter_supported(N) && msac_filter_profitable(P, M, N)))
+      return msac_filter_launch((const float *)matches, (const float *)models, valid, (const float *)thr, P, M, N,
+                                (float *)scores, masks, st);
+  }
   const bool fast16 = kFast && DR_K4_FAST16 && (N % 16 == 0);
   const int tile = fast16 ? DR_K4_TILE16 : (kFast ? kFastTile : kModelsPerBlock);
   const int tiles = (M + tile - 1) / tile;
@@ -779,6 +787,15 @@ int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   DR_REQUIRE(matches && models && thr && scores, "null pointer");
   return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
+}
+
+int dr_msac_score_path_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
+                           int M, int N, float *scores, uint8_t *masks, int path, void *stream) {
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && thr && scores, "null pointer");
+  DR_REQUIRE(path >= 0 && path <= 2, "path must be 0 (auto), 1 (general kernels) or 2 (filter kernel)");
+  DR_REQUIRE(path != 2 || dr::msac_filter_supported(N), "the filter kernel needs N % 16 == 0 and 16 <= N <= 2048");
+  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream, path);
 }
 
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,

@@ -23,9 +23,11 @@ def _thr_tensor(threshold, P: int, like: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------ K4 / K6
 def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_masks: bool = True,
-               valid: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               valid: Optional[torch.Tensor] = None, path: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None.
-    valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row)."""
+    valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row).
+    path (f32 only): 0 = kernel family chosen by shape, 1 = general kernels, 2 = matrix-core filter kernel
+    (include/dransac.h: dr_msac_score_path_f32)."""
     P, N, _ = matches.shape
     M = models.shape[1]
     matches = matches.contiguous()
@@ -34,6 +36,12 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
     scores = torch.empty((P, M), device=matches.device, dtype=matches.dtype)
     masks = torch.empty((P, M, N), device=matches.device, dtype=torch.bool) if want_masks else None
     v = None if valid is None else valid.contiguous().view(torch.uint8)
+    if path != 0:
+        if matches.dtype != torch.float32:
+            raise L.DransacError("msac_score: an explicit kernel path exists for f32 only")
+        L.call("dr_msac_score_path_f32", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N),
+               ptr(scores), ptr(masks), c_int(path), stream())
+        return scores, masks
     L.call(f"dr_msac_score_{L.suffix(matches.dtype)}", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M),
            c_int(N), ptr(scores), ptr(masks), stream())
     return scores, masks
