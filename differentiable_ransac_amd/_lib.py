@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_double, c_float, c_int, c_uint64, c_void_p
 from typing import Optional
 
@@ -44,6 +45,19 @@ def check(status: int, what: str) -> None:
         raise DransacError(f"{what} failed with status {status}: {msg}")
 
 
+# Devices of the tensors whose pointers were taken since the last call(): every wrapper builds its argument list with
+# ptr(...) ... stream() and hands it to call(), so call() can check that one launch never mixes GPUs and can make that
+# GPU current for the launch (HIP launches on the CURRENT device, whatever device the pointers belong to).
+_ctx = threading.local()
+
+
+def _devices() -> set:
+    d = getattr(_ctx, "devs", None)
+    if d is None:
+        d = _ctx.devs = set()
+    return d
+
+
 def ptr(t: Optional[torch.Tensor]) -> c_void_p:
     """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
     if t is None:
@@ -52,11 +66,22 @@ def ptr(t: Optional[torch.Tensor]) -> c_void_p:
         raise DransacError("libdransac operates on GPU tensors only (got a CPU tensor)")
     if not t.is_contiguous():
         raise DransacError("tensor must be contiguous")
+    _devices().add(t.device.index)
     return c_void_p(t.data_ptr())
 
 
+def _launch_device() -> Optional[int]:
+    devs = _devices()
+    if len(devs) > 1:
+        _ctx.devs = set()
+        raise DransacError(f"tensors of one call live on different GPUs: {sorted(devs)}")
+    return next(iter(devs)) if devs else None
+
+
 def stream() -> c_void_p:
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current torch stream OF THE DEVICE THE CALL'S TENSORS LIVE ON (not of the current device)."""
+    dev = _launch_device()
+    return c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def suffix(dtype: torch.dtype) -> str:
@@ -74,7 +99,14 @@ def scalar(dtype: torch.dtype, v: float):
 def call(name: str, *args) -> None:
     fn = getattr(lib(), name)
     fn.restype = c_int
-    check(fn(*args), name)
+    dev = _launch_device()
+    _ctx.devs = set()
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):       # tensors on another GPU than the current one: launch there
+            status = fn(*args)
+    else:
+        status = fn(*args)
+    check(status, name)
 
 
 __all__ = ["lib", "check", "ptr", "stream", "suffix", "scalar", "call", "DransacError", "LIB_PATH", "HEADER_PATH",

@@ -592,11 +592,14 @@ int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float 
   DR_REQUIRE(samples && models && grad_models && grad_samples, "null pointer");
   DR_REQUIRE(Bt > 0 && n >= 8, "need Bt > 0 and n >= 8");
   const size_t smem = sizeof(double) * 162 * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: remember which devices of this process have it (one process may drive several GPUs)
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dr::f8_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(dr::f8_bwd_kernel, dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream, samples, weights,
                      models, grad_models, Bt, n, grad_samples, grad_weights);

@@ -34,6 +34,19 @@
 #include "dr_common.hpp"
 #include "msac_filter.hpp"
 
+// stage timing for profiling builds: accumulated in (scalar) registers, written once per wave at the end -- the generic
+// DR_STAGE macro's global atomic per stage perturbs a loop this short beyond use
+#ifdef DR_PROFILE_STAGES
+#define KF_STAGE_BEGIN() unsigned long long kf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long kf_prev = __builtin_readcyclecounter()
+#define KF_STAGE(i) do { const unsigned long long kf_now = __builtin_readcyclecounter(); kf_acc[i] += kf_now - kf_prev; kf_prev = kf_now; } while (0)
+#define KF_STAGE_END() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&::dr::g_stage_cycles[i_], kf_acc[i_]); \
+                                 atomicAdd(&::dr::g_stage_cycles[8 + (threadIdx.x >> 6)], kf_acc[0] + kf_acc[1] + kf_acc[2] + kf_acc[3] + kf_acc[5]); } } while (0)
+#else
+#define KF_STAGE_BEGIN() do {} while (0)
+#define KF_STAGE(i) do {} while (0)
+#define KF_STAGE_END() do {} while (0)
+#endif
+
 namespace dr {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -41,9 +54,22 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
-#ifndef DR_KF_NT
-#define DR_KF_NT 1          // 1: non-temporal mask stores
+#ifndef DR_KF_STORE
+#define DR_KF_STORE 1       // cache policy of the mask stores: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1
+#endif                      // (write-once stream, never re-read by this kernel: nt measured 128-140 us for the stream alone
+                            // against 207-222 us with plain stores)
+#ifndef DR_KF_STOREONLY
+#define DR_KF_STOREONLY 0   // 1: timing decomposition only -- no filter, no candidates: the mask stream alone (all-zero masks)
 #endif
+#ifndef DR_KF_RAWBAR
+#define DR_KF_RAWBAR 1      // 1: the per-chunk block barrier orders LDS only (s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads()
+                            // also waits for the wave's outstanding global stores (vmcnt(0)): the mask stream of chunk c would
+                            // have to be acknowledged by memory before chunk c + 1 may pass its barrier.  No thread of the block
+                            // ever reads global memory another thread wrote, so LDS ordering is all the barrier has to give.
+#endif
+#ifndef DR_KF_SKIP
+#define DR_KF_SKIP 0        // timing decomposition only (wrong results): 1 no consumer, 2 no matrix-core filter (and so no
+#endif                      // consumer), 4 no per-chunk operand preparation; bits may be combined
 #ifndef DR_KF_GROUP
 #define DR_KF_GROUP 4       // tiles whose matrix instructions are issued before their compares
 #endif
@@ -67,6 +93,30 @@ struct FilterShared {
   unsigned long long acc[2][kFSlots];
   float red[kFW];
 };
+
+__device__ __forceinline__ void block_sync_lds() {
+#if DR_KF_RAWBAR
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+}
+
+__device__ __forceinline__ void mask_store(u4 *dst, u4 v) {
+#if DR_KF_STORE == 0
+  *dst = v;
+#elif DR_KF_STORE == 1
+  __builtin_nontemporal_store(v, dst);
+#elif DR_KF_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#elif DR_KF_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#elif DR_KF_STORE == 4
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#endif
+}
 
 __device__ __forceinline__ void split2(float v, _Float16 &h, _Float16 &l) {
   h = (_Float16)v;
@@ -92,10 +142,13 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
                                                           uint8_t *__restrict__ masks) {
   __shared__ FilterShared sh;
   const int p = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: branches on it stay on the scalar unit
   const int row = lane & 15, kg = lane >> 4;
   const int T = N >> 4;                                   // 16-point tiles (N % 16 == 0)
-  const int ntw = min(kFTilesW, max(0, T - kFTilesW * w));   // this wave's tiles
+  // wave w owns the tiles 8 t + w (t = 0..15): interleaved, so that spatially sorted inliers (the synthetic pairs keep
+  // them in the second half of the point list) load the eight waves evenly
+  const int ntw = (T > w) ? min(kFTilesW, (T - w + kFW - 1) / kFW) : 0;   // this wave's tiles
   const int C = (M + kFSlots - 1) / kFSlots;              // 16-slot chunks of the pair
   const int c0 = (int)(((long)C * blockIdx.x) / gridDim.x), c1 = (int)(((long)C * (blockIdx.x + 1)) / gridDim.x);
   if (c0 >= c1) return;
@@ -194,14 +247,12 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
         }
       }
       __syncthreads();
-      if ((w >> 1) == rd) {                               // the two waves whose points were staged this round
-        const int base = (w & 1) * 256;
+      // the round staged the tiles [32 rd, 32 rd + 32): every wave owns four of them (local tiles 4 rd + u)
 #pragma unroll
-        for (int t = 0; t < kFTilesW; ++t) {
-          const _Float16 *src = stage + (base + 16 * t + row) * kStagePitch + 8 * kg;
-          Ar[t] = *reinterpret_cast<const h8 *>(src);
-          Aj[t] = *reinterpret_cast<const h8 *>(src + 32);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const _Float16 *src = stage + (16 * (kFW * u + w) + row) * kStagePitch + 8 * kg;
+        Ar[4 * rd + u] = *reinterpret_cast<const h8 *>(src);
+        Aj[4 * rd + u] = *reinterpret_cast<const h8 *>(src + 32);
       }
     }
   }
@@ -280,7 +331,7 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
       sh.cin[nb][i][1] = filt ? A * qc : (allc ? kFBig : -kFBig);
 #pragma unroll
       for (int q = 0; q < 9; ++q) sh.mraw[nb][i][q] = pm[q];
-      sh.flags[nb][i] = (live ? 1 : 0) | ((pv && !fin) ? 2 : 0);
+      sh.flags[nb][i] = (live ? 1 : 0) | ((pv && (!fin || !nz)) ? 2 : 0);   // bit 1: score NaN (non-finite or all-zero model)
     }
   };
   prep_load(c0);
@@ -289,6 +340,7 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
 
   const uint32_t pay = (uint32_t)row | ((uint32_t)kg << 4);
 
+  KF_STAGE_BEGIN();
   for (int c = c0; c < c1; ++c) {
     const int b = (c - c0) & 1;
     if (c + 1 < c1) prep_load(c + 1);
@@ -298,11 +350,13 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
     const float cr = sh.cin[b][row][0], cj = sh.cin[b][row][1];
     const f4 Cr = {cr, cr, cr, cr}, Cj = {cj, cj, cj, cj};
 
-    // ---- filter: candidates -> queue ----
-    int qn = 0;
+    KF_STAGE(0);
+    // ---- filter: per lane one candidate bit per tile (any of the lane's four (point, model) evaluations), no branches;
+    // then the set bits become queue entries ----
+    uint32_t cbits = 0u;                                   // bit t = tile t
 #pragma unroll
     for (int t0 = 0; t0 < kFTilesW; t0 += DR_KF_GROUP) {
-      if (t0 < ntw) {                                      // wave-uniform
+      if (!DR_KF_STOREONLY && !(DR_KF_SKIP & 2) && t0 < ntw) {   // wave-uniform
         f4 Dr[DR_KF_GROUP], Dj[DR_KF_GROUP];
 #pragma unroll
         for (int u = 0; u < DR_KF_GROUP; ++u) {
@@ -311,29 +365,48 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
         }
 #pragma unroll
         for (int u = 0; u < DR_KF_GROUP; ++u) {
-          const bool any = (Dr[u][0] * Dr[u][0] <= Dj[u][0]) | (Dr[u][1] * Dr[u][1] <= Dj[u][1]) |
-                           (Dr[u][2] * Dr[u][2] <= Dj[u][2]) | (Dr[u][3] * Dr[u][3] <= Dj[u][3]);
-          const unsigned long long bal = __ballot(any && (t0 + u < ntw));
-          if (bal) {
-            if (any && (t0 + u < ntw)) {
-              const int idx = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-              queue[idx] = pay | ((uint32_t)(t0 + u) << 6);
-            }
-            qn += __popcll(bal);
-          }
+          // d = Jt - rt^2 >= 0  <=>  candidate; NaN (non-finite point) never is: fmaxf drops NaN operands
+          const float d0 = fmaf(-Dr[u][0], Dr[u][0], Dj[u][0]), d1 = fmaf(-Dr[u][1], Dr[u][1], Dj[u][1]);
+          const float d2 = fmaf(-Dr[u][2], Dr[u][2], Dj[u][2]), d3 = fmaf(-Dr[u][3], Dr[u][3], Dj[u][3]);
+          const float mx = fmaxf(fmaxf(fmaxf(d0, d1), d2), d3);
+          cbits |= (mx >= 0.f && (t0 + u < ntw)) ? (1u << (t0 + u)) : 0u;
         }
       }
     }
+    int qn = 0;
+    {
+      // exclusive prefix of the per-lane counts (DPP scan), then every lane appends its own entries
+      const int cnt = __popc(cbits);
+      int incl = cnt;
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);   // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);   // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);   // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);   // row_shr:8  -> inclusive scan inside each row of 16
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+      qn = __builtin_amdgcn_readlane(incl, 63);
+      int off = incl - cnt;
+      uint32_t rem = cbits;
+      while (rem) {                                         // lanes drop out as their bits run out
+        const int t = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        queue[off++] = pay | ((uint32_t)t << 6);
+      }
+    }
 
+    KF_STAGE(1);
+#ifdef DR_PROFILE_STAGES
+    kf_acc[6] += (unsigned long long)qn; kf_acc[7] += (unsigned long long)((qn + 63) / 64);
+#endif
     // ---- exact evaluation of the queued (model, four points) entries ----
     unsigned char *mbuf = mask0 + b * 32768;
 #pragma unroll 1
-    for (int base = 0; base < qn; base += 64) {
+    for (int base = 0; base < ((DR_KF_SKIP & 1) ? 0 : qn); base += 64) {
       const int i = base + lane;
       if (i < qn) {
         const uint32_t e = queue[i];
         const int col = e & 15, qq = (e >> 4) & 3, t = e >> 6;
-        const int n0 = 16 * (kFTilesW * w + t) + 4 * qq;
+        const int n0 = 16 * (kFW * t + w) + 4 * qq;
         const float *mm = sh.mraw[b][col];
         const float4 ma = *reinterpret_cast<const float4 *>(mm), mb = *reinterpret_cast<const float4 *>(mm + 4);
         const float m[9] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mm[8]};
@@ -350,38 +423,49 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
         if (qs) atomicAdd(&sh.acc[b][col], (unsigned long long)qs);
       }
     }
-    if (c + 1 < c1) prep_compute(c + 1, b ^ 1);
-    __syncthreads();
+    KF_STAGE(2);
+    if (c + 1 < c1 && !(DR_KF_SKIP & 4)) prep_compute(c + 1, b ^ 1);
+    KF_STAGE(3);
+    block_sync_lds();
+    KF_STAGE(4);
 
     // ---- stream the chunk's mask image out, leave the buffer clean; scores ----
     const int rows = min(kFSlots, M - kFSlots * c);
     if (masks) {
-      const int nvec = (rows * N) >> 4;
+      const int nvec = (rows * N) >> 4;                      // <= 2048 vectors: at most four per thread
       u4 *src = reinterpret_cast<u4 *>(mbuf);
       u4 *dst = reinterpret_cast<u4 *>(masks + ((size_t)p * M + (size_t)kFSlots * c) * N);
-      for (int i = tid; i < nvec; i += kFT) {
-        const u4 v = src[i];
-#if DR_KF_NT
-        __builtin_nontemporal_store(v, dst + i);
-#else
-        dst[i] = v;
-#endif
-        src[i] = (u4){0u, 0u, 0u, 0u};
+      u4 v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tid + kFT * r;
+        if (i < nvec) v[r] = src[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tid + kFT * r;
+        if (i < nvec) {
+          mask_store(dst + i, v[r]);
+          src[i] = (u4){0u, 0u, 0u, 0u};
+        }
       }
     }
     if (tid < rows) {
       const unsigned long long a = sh.acc[b][tid];
       sh.acc[b][tid] = 0ull;
       float sc = (float)a * 1.862645149230957e-09f;       // 2^-29
-      if (myflag & 2) sc = NAN;                             // valid slot holding a non-finite model (as the general kernel)
+      if (myflag & 2) sc = NAN;                             // valid slot holding a non-finite or all-zero model (as the general kernel)
       scores[(size_t)p * M + kFSlots * c + tid] = sc;
     }
+    KF_STAGE(5);
   }
+  KF_STAGE_END();
 }
 
 bool msac_filter_supported(int N) { return N % 16 == 0 && N >= 16 && N <= kFMaxN; }
 
 bool msac_filter_profitable(int P, int M, int N) {
+  return false;   // until the kernel beats the general one on the device (path 2 selects it explicitly)
   if (N < 256) return false;
   const long chunks = (long)P * ((M + kFSlots - 1) / kFSlots);
   return chunks >= 1024;    // at least ~4 chunks per block of a chip-filling grid: the prologue has to amortise
@@ -397,6 +481,8 @@ int msac_filter_launch(const float *matches, const float *models, const uint8_t 
 }
 
 }  // namespace dr
+
+DR_DEFINE_STAGE_READER(dr_kf_stage_cycles)
 
 #ifdef DR_KF_STANDALONE   // scratch/k4f_check.py builds variants of this file alone (A/B of the knobs above)
 extern "C" int dr_kf_run(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P, int M,

@@ -111,11 +111,14 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
     for (int ml = 0; ml < mcount; ++ml) {
       T m[9];
       bool finite = !valid || valid[(size_t)p * M + m0 + ml];   // invalid slots: score 0, empty mask, no arithmetic
+      bool nonzero = false;
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         m[q] = md[ml * 9 + q];
         finite = finite && is_finite(m[q]);
+        nonzero = nonzero || (m[q] != T(0));
       }
+      finite = finite && nonzero;   // all-zero model: like a non-finite one (reference: NaN score, all-false mask)
       T acc = T(0);
       uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -301,10 +304,16 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
           for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
         }
         // scalar-unit finiteness test: largest exponent field over the nine coefficients
-        uint32_t ex = 0;
+        uint32_t ex = 0, anybit = 0;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
-        const bool finite = ex != 0x7f800000u;
+        for (int q = 0; q < 9; ++q) {
+          const uint32_t mb = __builtin_amdgcn_readfirstlane(__float_as_uint(m[q]));
+          ex = max(ex, mb & 0x7f800000u);
+          anybit |= mb & 0x7fffffffu;
+        }
+        // an all-zero model is treated like a non-finite one (score NaN, empty mask): the reference's 0/0 gives NaN
+        // scores and `NaN < thr` = False masks (msac_score.py:42-48)
+        const bool finite = ex != 0x7f800000u && anybit != 0u;
 
         v2f acc = splat(0.f);
         uint32_t sb[kPts];
@@ -470,10 +479,16 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
 #pragma unroll
           for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
         }
-        uint32_t ex = 0;
+        uint32_t ex = 0, anybit = 0;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) ex = max(ex, __builtin_amdgcn_readfirstlane(__float_as_uint(m[q])) & 0x7f800000u);
-        const bool finite = ex != 0x7f800000u;
+        for (int q = 0; q < 9; ++q) {
+          const uint32_t mb = __builtin_amdgcn_readfirstlane(__float_as_uint(m[q]));
+          ex = max(ex, mb & 0x7f800000u);
+          anybit |= mb & 0x7fffffffu;
+        }
+        // an all-zero model is treated like a non-finite one (score NaN, empty mask): the reference's 0/0 gives NaN
+        // scores and `NaN < thr` = False masks (msac_score.py:42-48)
+        const bool finite = ex != 0x7f800000u && anybit != 0u;
         v2f nacc = splat(0.f);
         const uint4 q = msac_eval16(x1, y1, x2, y2, m, inv_thr2, finite, nacc);
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;

@@ -3,8 +3,10 @@ equal to f32 rounding; then timing at the benchmark shape, A/B of the build knob
   build (CPU box):  python scratch/k4f_check.py --build        run (GPU box):  python scratch/k4f_check.py [--quick]"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
-VARIANTS = {'nt1g4': ['-DDR_KF_NT=1', '-DDR_KF_GROUP=4'], 'nt0g4': ['-DDR_KF_NT=0', '-DDR_KF_GROUP=4'],
-            'nt1g2': ['-DDR_KF_NT=1', '-DDR_KF_GROUP=2'], 'nt1g8': ['-DDR_KF_NT=1', '-DDR_KF_GROUP=8']}
+VARIANTS = {'base': [], 'g2': ['-DDR_KF_GROUP=2'], 'g8': ['-DDR_KF_GROUP=8'],
+            'storeonly': ['-DDR_KF_STOREONLY=1'],
+            **{f'skip{k}': [f'-DDR_KF_SKIP={k}'] for k in (1, 2, 4, 6, 7)},
+            'prof': ['-DDR_PROFILE_STAGES']}
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -139,7 +141,24 @@ for name in VARIANTS:
                           ctypes.c_void_p(thr.data_ptr()), P, M, N, ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(masks.data_ptr()), st)
         assert rc == 0, rc
     run_v(); torch.cuda.synchronize()
+    if name == 'prof':
+        buf = (ctypes.c_ulonglong * 16)()
+        vl.dr_kf_stage_cycles(buf)          # discard the warm-up call's counts
+        run_v(); torch.cuda.synchronize()
+        vl.dr_kf_stage_cycles(buf)
+        names = ['top (operand reads, model loads issued)', 'filter', 'consume', 'prep_compute', 'barrier wait', 'flush + scores']
+        tot = sum(buf[i] for i in range(6))
+        nw = 256 * 8
+        for i in range(6):
+            print(f'   stage {names[i]:42s} {buf[i] / nw:10.0f} cycles per wave  {100.0 * buf[i] / tot:5.1f} %')
+        print('   busy cycles (all but the barrier wait) by wave id:', [int(buf[8 + i] / 256) for i in range(8)])
+        print(f'   entries {buf[6]}  batches {buf[7]}  entries per batch {buf[6] / max(1, buf[7]):.1f}  per wave-chunk {buf[6] / (nw * 80):.1f}')
     okv = torch.equal(masks.view(torch.bool), kb)
     med, mn = timeit(run_v)
-    print(f'variant {name}: median {med:.1f} us  min {mn:.1f} us  masks equal {okv}')
+    def run_v0():
+        rc = vl.dr_kf_run(ctypes.c_void_p(mt.data_ptr()), ctypes.c_void_p(fm.data_ptr()), ctypes.c_void_p(vflat.data_ptr()),
+                          ctypes.c_void_p(thr.data_ptr()), P, M, N, ctypes.c_void_p(scores.data_ptr()), None, st)
+        assert rc == 0, rc
+    med0, mn0 = timeit(run_v0)
+    print(f'variant {name}: median {med:.1f} us  min {mn:.1f} us  masks equal {okv}     without masks: median {med0:.1f} us')
 sys.exit(1 if bad else 0)
