@@ -39,6 +39,10 @@
 // s = d2 - thr2 by ONE packed fma (score scaled by 1/thr2 once per model) instead of the mul + fma of d2/thr2 - 1: eight
 // instructions fewer per 16 points, identical masks, and 206.6 vs 198.1 us on the same box (scratch/ab_k4_pair.py; 208 us
 // with the addend in an SGPR): slower -- dropped.  Instruction count is not what bounds this loop any more.
+// Round 2: non-temporal mask stores 226 vs 208 us (they help a contiguous LDS-assembled stream, not 1 KiB row pieces);
+// a persistent grid (one resident wave of blocks, every block five 32-slot tiles of one pair, points loaded once) 218 vs
+// 200 us, with 64-slot tiles 247 us: the hardware's dynamic dispatch of 5 120 unequal blocks balances better than equal
+// static shares started in lock step (scratch/ab_k4nt.py).  The matrix-core candidate filter is csrc/msac_filter.hip.
 #include "dr_common.hpp"
 #include "msac_filter.hpp"
 
@@ -162,6 +166,22 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
 //  * the soft score is acc = fma(max(-s, 0), w, acc) with a per-point 0/1 weight (tail handling for free) and the
 //    mask byte is the sign bit of s, packed four at a time with v_perm_b32.
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Store policy of the mask rows.  Non-temporal stores, which help the LDS-assembled contiguous stream of msac_filter.hip
+// (130 against 207-222 us for the stream alone), LOSE here, where a wave store is a 1 KiB row piece: 226 against 208 us
+// (scratch/ab_k4nt.py) -- plain stores stay.
+#ifndef DR_K4_STORE
+#define DR_K4_STORE 0   // 0 plain, 1 nt
+#endif
+__device__ __forceinline__ void mask_row_store(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  const u32x4 v = {a, b, c, d};
+#if DR_K4_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+#else
+  *reinterpret_cast<u32x4 *>(dst) = v;
+#endif
+}
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
@@ -195,6 +215,7 @@ __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 #ifndef DR_K4_FAST16
 #define DR_K4_FAST16 0
 #endif
+
 constexpr int kFastTile = DR_K4_TILE;   // model slots per block in the f32 fast path (32-bit validity words)
 
 __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const float *__restrict__ matches,
@@ -492,7 +513,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
         v2f nacc = splat(0.f);
         const uint4 q = msac_eval16(x1, y1, x2, y2, m, inv_thr2, finite, nacc);
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;
-        if (write_masks && have) *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + cur) * N + n0) = q;
+        if (write_masks && have) mask_row_store(masks + ((size_t)p * M + m0 + cur) * N + n0, q.x, q.y, q.z, q.w);
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
         if (lane == 63) atomicAdd(&part[wv][cur], finite ? a : NAN);   // ds_add_f32, no return: nothing to wait for (-2 %)
         if (!more) break;
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
         while (inv) {
           const int ml = 32 * wd + __builtin_ctz(inv);
           inv &= inv - 1;
-          *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + ml) * N + n0) = make_uint4(0u, 0u, 0u, 0u);
+          mask_row_store(masks + ((size_t)p * M + m0 + ml) * N + n0, 0u, 0u, 0u, 0u);
         }
       }
     }

@@ -3,9 +3,9 @@ equal to f32 rounding; then timing at the benchmark shape, A/B of the build knob
   build (CPU box):  python scratch/k4f_check.py --build        run (GPU box):  python scratch/k4f_check.py [--quick]"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
-VARIANTS = {'base': [], 'g2': ['-DDR_KF_GROUP=2'], 'g8': ['-DDR_KF_GROUP=8'],
+VARIANTS = {'base': [], 'gs0': ['-DDR_KF_GSHIFT=0'],  
             'storeonly': ['-DDR_KF_STOREONLY=1'],
-            **{f'skip{k}': [f'-DDR_KF_SKIP={k}'] for k in (1, 2, 4, 6, 7)},
+            **{f'skip{k}': [f'-DDR_KF_SKIP={k}'] for k in (1, 2, 6, 32, 96, 128, 224)},
             'prof': ['-DDR_PROFILE_STAGES']}
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
@@ -152,6 +152,13 @@ for name in VARIANTS:
         for i in range(6):
             print(f'   stage {names[i]:42s} {buf[i] / nw:10.0f} cycles per wave  {100.0 * buf[i] / tot:5.1f} %')
         print('   busy cycles (all but the barrier wait) by wave id:', [int(buf[8 + i] / 256) for i in range(8)])
+        tr = (ctypes.c_ulonglong * 128)()
+        vl.dr_kf_trace(tr)
+        t0 = min(tr[16 * wv] for wv in range(8))
+        lab = ['start', 'loads issued', 'flush done (A)', 'filter done', 'consume done', 'before stage B', 'stage B done', 'stage A done', 'after barrier', 'filter: matrix+compare done']
+        print('   timeline of interval 40, block (0,0), cycles since the first wave entered it; group A = waves 0-3: flush, filter, consume; B = waves 4-7: consume, filter')
+        for k in (0, 1, 2, 9, 3, 4, 5, 6, 7, 8):
+            print(f'     {lab[k]:32s}', ' '.join(f'{int(tr[16 * wv + k]) - int(t0):7d}' for wv in range(8)))
         print(f'   entries {buf[6]}  batches {buf[7]}  entries per batch {buf[6] / max(1, buf[7]):.1f}  per wave-chunk {buf[6] / (nw * 80):.1f}')
     okv = torch.equal(masks.view(torch.bool), kb)
     med, mn = timeit(run_v)
