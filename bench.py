@@ -4,17 +4,28 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One *step* = one pass of the hot path (test mode, ransac.py:55-144, one RANSAC batch) over one batch of
-synthetic image pairs resident in HBM: K1 Gumbel top-k sampling (in-kernel Philox) -> K2 gather ->
-K3 Nister 5-point -> K4 MSAC scoring of all 10*B models against all N points (masks materialised, as
-MSACScore.score's contract requires) -> K6 per-pair arg-max / best mask / inlier count.
-Workload = BASELINE.json configs[1]: Nister 5-pt, N = 2000 points, B = 1024 hypotheses per pair, Gumbel
-sampler, MSAC; `--pairs` pairs per GPU per step (weak scaling: pairs shard across ranks, no data-path
-collective -- SURVEY 8(e)).  Prints ONE JSON line on rank 0.
+One *step* = one pass of the hot path (test mode, ransac.py:55-144, one RANSAC batch) over one batch of synthetic image
+pairs resident in HBM: K1 Gumbel top-k sampling (in-kernel Philox) -> K2 gather -> K3 Nister 5-point -> K4 MSAC scoring
+of all 10*B models against all N points (masks materialised, as MSACScore.score's contract requires) -> K6 per-pair
+arg-max / best mask / inlier count.
+Headline workload = BASELINE.json configs[1] ("c2"): Nister 5-pt, N = 2000 points, B = 1024 hypotheses per pair, Gumbel
+sampler, MSAC; `--pairs` pairs per GPU per step (weak scaling: pairs shard across ranks, no data-path collective --
+SURVEY 8(e)).  Prints ONE JSON line on rank 0.
+
+The other BASELINE configs are measured after the headline region (N = 1 only) and reported under "configs":
+  c1  8-point F, 128 points, 64 hypotheses, uniform sampler (256 pairs per step: one pair is launch-bound)
+  c3  Stewenius 5-point, 2000 points, 4096 hypotheses, 32 pairs
+  c4  rigid SVD, 50 000 points, 2048 hypotheses, one pair
+`--workload c1|c3|c4` makes one of them the timed region instead (for profiling).
+`--mode train`: sampler -> solver -> best-of-10 vs GT -> MatchLoss -> backward to the logits; with N > 1 every step ends
+with the training step's one collective (train.py:150-175): a flat RCCL all-reduce of the scores network's gradient
+bucket (622 616 f32, the reference's CLNet) + the logits gradient.  `--split hypotheses`: fewer pairs than GPUs -- every
+rank draws B / N hypotheses for the SAME pairs and the per-pair winners are merged (strong scaling).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,40 +39,230 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_PEAK_TFLOPS = 157.3   # packed-f32 VALU = f32 MFMA dense peak
+CLNET_PARAMS = 622616      # parameters of the reference's scores network
+# the reference's own code imported in the survey container (8 CPU cores, torch 2.10 CPU, f32,
+# no_grad, the same synthetic recipe) -- hypotheses/s per BASELINE config.  Quoted next to cpu_baseline so that nobody
+# compares the GPU figure with the (faster, vectorised) oracle alone.
+REFERENCE_IMPORT = {"c1": 1.6e3, "c2": 1.05e3, "c3": 3.1e3, "c4": 0.68e3}
+
+WORKLOADS = {
+    "c1": dict(solver="f8", pairs=256, points=128, hyps=64, sampler="uniform", baseline_config=0,
+               text="8-point F, 128 pts x 64 hyps per pair, uniform sampler, MSAC with masks"),
+    # 128 pairs per step since round 2: the step's kernels are grid-size limited at 32 pairs (K3 has one wave per SIMD, K4
+    # 2.5 rounds of blocks); measured 80.1 / 90.9 / 98.0 / 91.4 M hypotheses/s at 32 / 64 / 128 / 256 pairs per step
+    # (2.6 GB of masks at 128).  The 32-pair figure of round 1 stays in the line as configs["c2_p32"].
+    "c2": dict(solver="nister", pairs=128, points=2000, hyps=1024, sampler="gumbel", baseline_config=1,
+               text="nister 5-pt E, 2000 pts x 1024 hyps per pair, Gumbel top-k sampler (in-kernel Philox), MSAC scoring with masks"),
+    "c3": dict(solver="stewenius", pairs=32, points=2000, hyps=4096, sampler="gumbel", baseline_config=2,
+               text="stewenius 5-pt E, 2000 pts x 4096 hyps per pair, Gumbel top-k sampler, MSAC scoring with masks"),
+    "c4": dict(solver="rigid", pairs=1, points=50000, hyps=2048, sampler="gumbel", baseline_config=3,
+               text="rigid SVD (3-D registration), 50000 pts x 2048 hyps, Gumbel top-k sampler, squared residuals with masks"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
-    ap.add_argument("--points", type=int, default=2000)
-    ap.add_argument("--hyps", type=int, default=1024)
-    ap.add_argument("--solver", default="nister", choices=["nister", "stewenius", "f8"])
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="which BASELINE config is the timed region")
+    ap.add_argument("--pairs", type=int, default=None, help="image pairs per GPU per step (default: the workload's)")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--hyps", type=int, default=None)
+    ap.add_argument("--solver", default=None, choices=["nister", "stewenius", "f8"], help="(legacy) overrides the workload's solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-records of the other BASELINE configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--profile-kernels", action="store_true", help="per-kernel HIP-event breakdown (extra syncs)")
-    ap.add_argument("--mode", default="test", choices=["test", "train"],
-                    help="test: the headline inference path; train: sampler -> solver -> best-of-10 vs GT -> loss, forward "
-                         "+ backward to the logits (ransac.py:78-108 + train.py:150), reported with the same JSON shape")
+    ap.add_argument("--mode", default="test", choices=["test", "train"])
+    ap.add_argument("--split", default="pairs", choices=["pairs", "hypotheses"],
+                    help="pairs: every rank owns its own pairs (weak scaling); hypotheses: every rank draws hyps/N hypotheses "
+                         "for the SAME pairs and the winners are merged with two tiny all_gathers (strong scaling, P < G)")
     ap.add_argument("--extras", action="store_true",
-                    help="after the official timed region also measure (a) two-stream overlap of consecutive batches and "
-                         "(b) the step followed by the final refit; off by default so that a profiler sees only the official loop")
-    ap.add_argument("--sampler", default="gumbel", choices=["gumbel", "topdown"],
-                    help="gumbel: the reference's sampler (noise for every point of every hypothesis + top-k, in-kernel "
-                         "Philox); topdown: the same index-set distribution drawn as k soft-max draws without replacement "
-                         "(test mode only) -- reported as a variant, never the default")
+                    help="after the timed region also measure the step followed by the final refit and the top-down sampler")
+    ap.add_argument("--sampler", default=None, choices=["gumbel", "topdown", "uniform"])
+    ap.add_argument("--logits-fixture", action="store_true",
+                    help="timed region on tests/golden/clnet_logits.npz: reader-produced pairs scored by the REFERENCE's network "
+                         "with its shipped weights (generated in the build container by tests/golden/gen_clnet_logits.py), "
+                         "tiled to --pairs; the default run reports the same thing as the sub-record `clnet_logits`")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the K timed steps are issued on round-robin.  Default 1: strictly one kernel at a "
                          "time, so that the HIP-event duration of the scoring kernel in the timed region is its own "
-                         "(roofline attribution).  2 = two batches in flight (the latency-bound sampler/solver of batch "
-                         "i+1 runs under the VALU-bound scoring of batch i): +14 % throughput, always measured after the "
-                         "timed region and reported as `two_batches_in_flight`")
+                         "(roofline attribution).  Two batches in flight are always measured after the timed region and "
+                         "reported as `two_batches_in_flight`")
     return ap.parse_args()
 
 
-def cpu_baseline(args, pairs_data):
+def resolve(args):
+    w = dict(WORKLOADS[args.workload])
+    if args.mode == "train" and args.workload == "c2":
+        w["pairs"] = 32                      # BASELINE configs[4]: 256 pairs over 8 GPUs = 32 per GPU and step
+    if args.solver:
+        w["solver"] = args.solver
+    for k in ("pairs", "points", "hyps", "sampler"):
+        v = getattr(args, k)
+        if v is not None:
+            w[k] = v
+    return w
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def load_logits_fixture(P):
+    """tests/golden/clnet_logits.npz tiled to P pairs: matches, the network's log-probabilities (`-p 2`, the reference's
+    default input of the sampler), intrinsics, the geometric inlier mask."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "clnet_logits.npz"))
+    rep = (P + z["matches"].shape[0] - 1) // z["matches"].shape[0]
+    t = lambda k: torch.from_numpy(z[k]).repeat(rep, *([1] * (z[k].ndim - 1)))[:P].contiguous()
+    return {"matches": t("matches"), "logits": t("log_probs"), "K1": t("K1"), "K2": t("K2"), "gt_E": t("gt_E"),
+            "inliers": t("geometric_inliers"), "gt_F": t("gt_E")}
+
+
+def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=False):
+    """Builds the resident inputs of a workload and returns (step callable, info dict)."""
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.ransac import BatchedRANSAC, BatchedRANSAC3D
+    P, N, B = w["pairs"], w["points"], w["hyps"]
+    if w["solver"] == "rigid":
+        items = [synth.rigid_pair(rank * P + p, N) for p in range(P)]
+        matches = torch.stack([it["matches"] for it in items]).to(dev)
+        logits = torch.stack([it["logits"] for it in items]).to(dev)
+        rn = BatchedRANSAC3D(ransac_batch_size=B, train=False, threshold=0.03, max_iterations=B, seed=seed + rank, flag=False,
+                             keep_masks=keep_masks)
+
+        def step():
+            return rn(matches, logits)
+        return step, dict(rn=rn, matches=matches, logits=logits, S=1, data=None, K=(None, None))
+    data = load_logits_fixture(P) if fixture else synth.batch_two_view(P, N, seed0=rank * P, pixel=(w["solver"] == "f8"))
+    matches, logits = data["matches"].to(dev), data["logits"].to(dev)
+    K1, K2 = data["K1"].to(dev), data["K2"].to(dev)
+    S = 1 if w["solver"] == "f8" else 10
+    if mode == "train":
+        from differentiable_ransac_amd.loss import MatchLoss
+        gt = data["gt_E"].to(dev) if w["solver"] != "f8" else data["gt_F"].to(dev)
+        tr = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=True, max_iterations=B, seed=99 + rank)
+        lg = logits.clone().requires_grad_(True)
+        match_loss = MatchLoss()                     # the reference's default training loss (-w2 1, train.py:70-79)
+        gt_mask = data["inliers"].to(dev)
+
+        def step():
+            lg.grad = None
+            chosen, keep = tr(matches, lg, gt_model=gt)
+            if w["solver"] == "f8":                  # pixel coordinates: plain distance to the ground-truth F
+                d = torch.minimum(((chosen - gt[:, None]) ** 2).sum((-1, -2)), ((chosen + gt[:, None]) ** 2).sum((-1, -2)))
+                loss = (d * keep).sum()
+            else:
+                loss = match_loss(chosen, matches, gt_mask, keep)
+            loss.backward()
+            return {"inliers": torch.zeros(P, device=dev), "grad": lg.grad}
+        return step, dict(rn=tr, matches=matches, logits=lg, S=S, data=data, K=(K1, K2))
+    rn = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B, seed=seed + rank,
+                       keep_masks=keep_masks, refit=False, sampling=w["sampler"])
+
+    def step():
+        return rn(matches, logits, K1, K2)
+    return step, dict(rn=rn, matches=matches, logits=logits, S=S, data=data, K=(K1, K2))
+
+
+class CallTimer:
+    """HIP events around selected libdransac launches (the ctypes call), recorded on the stream the launch goes to."""
+
+    def __init__(self, prefixes, slots):
+        from differentiable_ransac_amd import _lib as L
+        self.L, self.prefixes = L, tuple(prefixes)
+        self.ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in range(slots)]
+        self.i = -1
+        self.orig = L.call
+        L.call = self._call
+
+    def _call(self, name, *a):
+        i = self.i
+        if 0 <= i < len(self.ev) and name.startswith(self.prefixes):
+            self.ev[i][0].record()
+            self.orig(name, *a)
+            self.ev[i][1].record()
+        else:
+            self.orig(name, *a)
+
+    def mean_ms(self, n=None):
+        ev = self.ev if n is None else self.ev[:n]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+
+    def close(self):
+        self.L.call = self.orig
+
+
+def per_call_breakdown(step, reps=10):
+    """Average device time of every libdransac entry point of one step (events around each ctypes call; one stream)."""
+    from differentiable_ransac_amd import _lib as L
+    orig = L.call
+    rec = []
+
+    def call(name, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(name, *a)
+        e1.record()
+        rec.append((name, e0, e1))
+
+    step()
+    torch.cuda.synchronize()
+    L.call = call
+    try:
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        L.call = orig
+    out = {}
+    for name, a, b in rec:
+        out[name] = out.get(name, 0.0) + a.elapsed_time(b) / reps
+    return out
+
+
+def k4_bytes(P, N, M):
+    return P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
+
+
+def k4r_bytes(P, N, M):
+    return P * (24 * N + 48 * M + 4 * M + 4 + M * N)     # SURVEY 8(d): rigid residuals with masks
+
+
+def config_record(key, dev, steps, warmup, pairs=None):
+    """Sub-record of one BASELINE config: ms/step, hypotheses/s, the dominant libdransac launch and its roofline share."""
+    w = dict(WORKLOADS[key])
+    if pairs is not None:
+        w["pairs"] = pairs
+    step, info = make_step(w, dev)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    calls = per_call_breakdown(step)
+    dom = max(calls, key=calls.get)
+    P, N, B = w["pairs"], w["points"], w["hyps"]
+    M = B * info["S"]
+    rec = {"baseline_config_index": w["baseline_config"], "workload": f"{w['text']}, {P} pair(s) per step",
+           "steps": steps, "ms_per_step": el / steps * 1e3, "hypotheses_per_s": P * B * steps / el,
+           "pairs_per_s": P * steps / el, "launch_ms": {k: round(v, 5) for k, v in sorted(calls.items(), key=lambda kv: -kv[1])},
+           "dominant_launch": dom, "dominant_ms": calls[dom],
+           "reference_import_hypotheses_per_s": REFERENCE_IMPORT.get(key)}
+    score_call = "dr_rigid_residual_f32" if w["solver"] == "rigid" else "dr_msac_score_f32"
+    if score_call in calls:
+        nbytes = k4r_bytes(P, N, M) if w["solver"] == "rigid" else k4_bytes(P, N, M)
+        ach = nbytes / (calls[score_call] * 1e-3) / 1e9
+        rec["scoring_roofline"] = {"bound": "hbm", "launch": score_call, "avg_launch_ms": calls[score_call],
+                                   "algorithmic_bytes_per_launch": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    return rec
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args, w, pairs_data):
     """The CPU oracle (oracle/cpu_ref.py, a vectorised torch restatement of the reference path) timed on the host
     cores, on a bounded sample of the same workload: whole pairs (N points x B hypotheses), one after the other like
     the reference's per-pair loop (model_cl.py:488), until the time budget is spent.  The thread count is calibrated
@@ -69,22 +270,23 @@ def cpu_baseline(args, pairs_data):
     from oracle import cpu_ref as O
     from differentiable_ransac_amd import synth
     cores = os.cpu_count() or 1
-    k = 8 if args.solver == "f8" else 5
+    solver, N, B = w["solver"], w["points"], w["hyps"]
+    k = 8 if solver == "f8" else 5
     noise_cache = {}
 
     def one_pair(i):
         m = pairs_data["matches"][i % pairs_data["matches"].shape[0]]
         lg = pairs_data["logits"][i % pairs_data["logits"].shape[0]]
         if i not in noise_cache:
-            noise_cache[i] = synth.gumbel_noise((args.hyps, args.points), seed=1000 + i)
+            noise_cache[i] = synth.gumbel_noise((B, N), seed=1000 + i)
         noise = noise_cache[i]
         t0 = time.perf_counter()
         with torch.no_grad():
             idx, ret, _ = O.gumbel_topk(lg, noise, 1.0, k)
             smp = O.gather_samples(m, ret)
-            if args.solver == "f8":
+            if solver == "f8":
                 models = O.fundamental_8pt(smp)
-            elif args.solver == "stewenius":
+            elif solver == "stewenius":
                 models = O.stewenius_5pt(smp)[0].reshape(-1, 3, 3)
             else:
                 E, ok, _ = O.nister_5pt(smp)
@@ -106,12 +308,42 @@ def cpu_baseline(args, pairs_data):
     while t_used < args.cpu_seconds and done < 4096:
         t_used += one_pair(1 + done % 64)
         done += 1
-    return {"value": done * args.hyps / max(t_used, 1e-9), "unit": "hypotheses/s", "cores": best_n, "kind": "port",
+    return {"value": done * B / max(t_used, 1e-9), "unit": "hypotheses/s", "cores": best_n, "kind": "port",
             "host_cores": cores,
-            "sample": f"{done} pair(s) x {args.points} pts x {args.hyps} hyps, torch-CPU f32 oracle "
-                      f"(sample+gather+solve+score+argmax), {t_used:.1f} s, threads calibrated over 1/8/16/32"}
+            "sample": f"{done} pair(s) x {N} pts x {B} hyps, torch-CPU f32 oracle "
+                      f"(sample+gather+solve+score+argmax), {t_used:.1f} s, threads calibrated over 1/8/16/32",
+            "reference_import": {"value": REFERENCE_IMPORT.get(args.workload), "unit": "hypotheses/s", "cores": 8,
+                                 "kind": "reference",
+                                 "note": "the reference's own Python imported in the build container (BASELINE.md section 2: 8 "
+                                         "cores, torch CPU f32, no_grad, same synthetic recipe); it cannot travel to the GPU box, "
+                                         "so this figure is quoted, not re-measured here.  The oracle above is a vectorised "
+                                         "restatement and therefore faster than the reference's per-sample Python loops"}}
 
 
+def pmc_traffic(kernel_key, shape):
+    """HBM bytes per launch of the scoring kernel from the committed rocprofv3 PMC passes, valid only for the kernel
+    source they were collected on: the JSON carries the sha256 of the source files, compared with the tree's."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_fetch_write.json")
+    if not os.path.exists(path):
+        return None, "no PMC capture committed for this round"
+    rec = json.load(open(path))
+    srcs = rec.get("kernel_sources", {})
+    for rel, sha in srcs.items():
+        p = os.path.join(ROOT, rel)
+        if not os.path.exists(p) or hashlib.sha256(open(p, "rb").read()).hexdigest() != sha:
+            return None, f"{rel} changed since profiles/r2_pmc_fetch_write.json was collected: traffic not attributable"
+    if rec.get("workload") != shape:
+        return None, f"profiles/r2_pmc_fetch_write.json was collected on {rec.get('workload')}, this run is {shape}"
+    pmc = rec.get("kernels", {}).get(kernel_key, {})
+    if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
+        return None, f"no counters for {kernel_key} in profiles/r2_pmc_fetch_write.json"
+    # gfx950: FETCH_SIZE shows half the bytes of 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled (upper bound:
+    # most of this kernel's reads are scalar-cache model loads); WRITE_SIZE taken as is (matches the mask bytes to 0.2 %)
+    return ((2.0 * pmc["FETCH_SIZE"]["avg"] + pmc["WRITE_SIZE"]["avg"]) * 1024.0,
+            "profiles/r2_pmc_fetch_write.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, source hashes match")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,80 +359,68 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from differentiable_ransac_amd import ops, synth
+    from differentiable_ransac_amd import ops, sharding
     from differentiable_ransac_amd.ransac import BatchedRANSAC
 
-    P, N, B = args.pairs, args.points, args.hyps
-    S = 1 if args.solver == "f8" else 10
-    M = B * S
-    data = synth.batch_two_view(P, N, seed0=rank * P, pixel=(args.solver == "f8"))
-    matches = data["matches"].to(dev)
-    logits = data["logits"].to(dev)
-    K1, K2 = data["K1"].to(dev), data["K2"].to(dev)
-    thr_px = 0.75
-    rn = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
-                       seed=1234 + rank, keep_masks=True, refit=False, sampling=args.sampler)
+    w = resolve(args)
+    P, N, B = w["pairs"], w["points"], w["hyps"]
+    split_h = args.split == "hypotheses" and world > 1
+    if split_h:
+        if args.mode != "test" or w["solver"] == "rigid":
+            raise SystemExit("--split hypotheses is a test-mode option of the two-view workloads")
+        if B % world:
+            raise SystemExit("--split hypotheses needs hyps divisible by the number of GPUs")
+        w = dict(w, hyps=B // world)
+    # hypothesis split: every rank holds the SAME pairs (rank 0's data) and its own sampler stream
+    if args.logits_fixture and (w["solver"] in ("f8", "rigid") or N != 2000):
+        raise SystemExit("--logits-fixture holds 2000-point essential-matrix pairs: use it with the c2 / c3 workloads")
+    step, info = make_step(w, dev, rank=0 if split_h else rank, mode=args.mode,
+                           seed=sharding.hypothesis_seed(1234, rank) if split_h else 1234, fixture=args.logits_fixture)
+    rn, matches, logits, S = info["rn"], info["matches"], info["logits"], info["S"]
+    K1, K2 = info["K"]
+    M = w["hyps"] * S
+    score_prefix = "dr_rigid_residual_f" if w["solver"] == "rigid" else "dr_msac_score_f"
+    timer = CallTimer((score_prefix,), args.steps)
 
-    # HIP events bracket exactly the dr_msac_score launch (the ctypes call), on the stream it is launched on
-    from differentiable_ransac_amd import _lib as L
-    ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in range(args.steps)]
-    state = {"i": -1}
-    orig_call = L.call
-
-    def timed_call(name, *a):
-        i = state["i"]
-        if 0 <= i < args.steps and name.startswith("dr_msac_score_f"):
-            ev[i][0].record()
-            orig_call(name, *a)
-            ev[i][1].record()
-        else:
-            orig_call(name, *a)
-
-    L.call = timed_call
-
-    if args.mode == "train":
-        gt = data["gt_E"].to(dev) if args.solver != "f8" else data["gt_F"].to(dev)
-        tr = BatchedRANSAC(args.solver, ransac_batch_size=B, train=True, max_iterations=B, seed=99 + rank)
-        lg = logits.clone().requires_grad_(True)
-
-        from differentiable_ransac_amd.loss import MatchLoss
-        match_loss = MatchLoss()                     # the reference's default training loss (-w2 1, train.py:70-79)
-        gt_mask = data["inliers"].to(dev)
-
+    # the training step's collective: one flat bucket = the scores network's gradient (random stand-in of the reference
+    # CLNet's size: the network itself is out of scope) + the logits gradient
+    coll_ev, net_grad = [], None
+    if args.mode == "train" and world > 1:
+        net_grad = torch.randn(CLNET_PARAMS, device=dev)
+    base_step = step
+    if args.mode == "train" and world > 1:
         def step():
-            lg.grad = None
-            chosen, keep = tr(matches, lg, gt_model=gt)
-            if args.solver == "f8":                  # pixel coordinates: plain distance to the ground-truth F
-                d = torch.minimum(((chosen - gt[:, None]) ** 2).sum((-1, -2)), ((chosen + gt[:, None]) ** 2).sum((-1, -2)))
-                loss = (d * keep).sum()
-            else:
-                loss = match_loss(chosen, matches, gt_mask, keep)
-            loss.backward()
-            return {"inliers": torch.zeros(P, device=dev), "grad": lg.grad}
-    else:
+            out = base_step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sharding.allreduce_mean_([net_grad, out["grad"]], dist)
+            e1.record()
+            coll_ev.append((e0, e1))
+            return out
+    elif split_h:
         def step():
-            return rn(matches, logits, K1, K2)
+            out = base_step()
+            sc, md, win, inl = sharding.merge_best(out["score"], out["model"], (out["inliers"],), dist)
+            return dict(out, score=sc, model=md, inliers=inl, winner=win)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
     outs = [None] * len(streams)
 
     def issue(i):
-        if args.streams <= 0:      # torch's default stream
-            outs[0] = step()
-            return
         st = streams[i % len(streams)]
         with torch.cuda.stream(st):
             outs[i % len(streams)] = step()
 
-    for w in range(args.warmup):
-        issue(w)
+    for i in range(args.warmup):
+        issue(i)
     torch.cuda.synchronize()
+    coll_ev.clear()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        state["i"] = i
+        timer.i = i
         issue(i)
     torch.cuda.synchronize()
     if dist is not None:
@@ -208,15 +428,45 @@ def main():
     torch.cuda.synchronize()
     out = outs[(args.steps - 1) % len(streams)]
     elapsed = time.perf_counter() - t0
-    state["i"] = -1
-    # whole-job rate = sum of hypotheses over ranks / max elapsed over ranks (no data-path collective: SURVEY 8(e))
-    from differentiable_ransac_amd import sharding
-    job_hyps_per_s, elapsed = sharding.job_throughput(P * B * args.steps, elapsed, dist, dev)
+    timer.i = -1
+    # whole-job rate = sum of hypotheses over ranks / max elapsed over ranks
+    job_hyps_per_s, elapsed = sharding.job_throughput(P * w["hyps"] * args.steps, elapsed, dist, dev)
+    n_ranks_seen = 1
+    if dist is not None:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        n_ranks_seen = int(one.item())
+    collective_ms = None
+    if coll_ev:
+        collective_ms = sum(a.elapsed_time(b) for a, b in coll_ev) / len(coll_ev)
 
-    # informational second region: the same K steps with the other issue policy -- two batches in flight on two streams
-    # when the official region ran strictly serial, and vice versa
+    common = {"unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+              "scaling": "strong" if split_h else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "n_ranks_seen": n_ranks_seen}
+
+    if args.mode == "train":
+        if rank == 0:
+            print(json.dumps({"metric": "hypotheses/sec, train step (forward + backward to the logits"
+                                        + (", gradient all-reduce)" if world > 1 else ")"),
+                              "value": job_hyps_per_s, **common,
+                              "config": {"workload": f"{w['solver']} train step (sample, solve, best-of-10 vs GT, MatchLoss, "
+                                                     f"backward), {N} pts x {B} hyps per pair, {P} pairs/GPU",
+                                         "mode": "train",
+                                         "parallelism": f"pairs sharded over {world} GPU(s); one flat RCCL all-reduce of "
+                                                        f"{CLNET_PARAMS} + {P * N} f32 per step" if world > 1 else "single GPU"},
+                              "collective_ms": collective_ms,
+                              "collective_share_of_step": (collective_ms / (elapsed / args.steps * 1e3)) if collective_ms else None,
+                              "collective_bytes": 4 * (CLNET_PARAMS + P * N) if world > 1 else 0,
+                              "grad_finite": bool(torch.isfinite(out["grad"]).all())}))
+        timer.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # informational second region: the same K steps with two batches in flight on two streams
     overlap = None
-    if world == 1 and args.mode == "test":
+    if world == 1:
         n2 = 1 if len(streams) > 1 else 2
         s2 = [torch.cuda.Stream(device=dev) for _ in range(n2)]
         keep = [None] * n2
@@ -233,116 +483,74 @@ def main():
         overlap = {"streams": n2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
         del keep
 
-    if args.mode == "train":
-        if rank == 0:
-            print(json.dumps({"metric": "hypotheses/sec, train step (forward + backward to the logits)",
-                              "value": job_hyps_per_s, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"{args.solver} train step (sample, solve, best-of-10 vs GT, MatchLoss, backward), "
-                                                     f"{N} pts x {B} hyps per pair, {P} pairs/GPU",
-                                         "mode": "train"},
-                              "grad_finite": bool(torch.isfinite(out["grad"]).all())}))
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    # informational: the same step followed by the final refit of ransac.py:148-195 (K7: Nister on all points in f64 on a
-    # side stream, re-score, keep if better) -- a per-pair epilogue, not part of the hypothesis loop the metric counts
-    with_refit = None
-    if args.extras and world == 1:
-        rn_refit = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
+    with_refit, topdown = None, None
+    if args.extras and world == 1 and w["solver"] != "rigid":
+        n_x = min(args.steps, 200)
+        rn_refit = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B,
                                  seed=4321, keep_masks=True, refit=True)
         for _ in range(3):
             rn_refit(matches, logits, K1, K2)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(n_x):
             rn_refit(matches, logits, K1, K2)
         torch.cuda.synchronize()
         e3 = time.perf_counter() - t2
-        with_refit = {"value": P * B * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3}
+        with_refit = {"value": P * B * n_x / e3, "ms_per_step": e3 / n_x * 1e3}
+        if w["sampler"] == "gumbel":
+            rn_td = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B,
+                                  seed=77, keep_masks=True, refit=False, sampling="topdown")
+            for _ in range(3):
+                rn_td(matches, logits, K1, K2)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(n_x):
+                rn_td(matches, logits, K1, K2)
+            torch.cuda.synchronize()
+            e4 = time.perf_counter() - t3
+            topdown = {"value": P * B * n_x / e4, "ms_per_step": e4 / n_x * 1e3, "streams": 1}
 
-    # informational (--extras): the same K steps with the top-down draw of the index sets instead of the dense Gumbel
-    # sampler (identical set distribution, tests/test_gpu_sampler.py; not the reference's sampler kernel, so not the headline)
-    topdown = None
-    if args.extras and world == 1 and args.sampler == "gumbel":
-        rn_td = BatchedRANSAC(args.solver, ransac_batch_size=B, train=False, threshold=thr_px, max_iterations=B,
-                              seed=77, keep_masks=True, refit=False, sampling="topdown")
-        keep = [None] * len(streams)
-        for i in range(2 * len(streams)):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                keep[i % len(streams)] = rn_td(matches, logits, K1, K2)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for i in range(args.steps):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                keep[i % len(streams)] = rn_td(matches, logits, K1, K2)
-        torch.cuda.synchronize()
-        e4 = time.perf_counter() - t3
-        topdown = {"value": P * B * args.steps / e4, "ms_per_step": e4 / args.steps * 1e3, "streams": len(streams)}
-        del keep
-
-    k4_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    # the same launch with nothing else on the GPU (one stream, a few extra untimed steps): with two batches in flight
-    # the scoring kernel shares the CUs with the next batch's sampler/solver, so its wall duration above is longer than
-    # its own cost; both are reported
+    k4_ms = timer.mean_ms()
     iso_ms = k4_ms
-    if len(streams) > 1:
+    if len(streams) > 1:      # with two batches in flight the kernel shares the CUs: also measure it alone
         n_iso = min(10, args.steps)
         for i in range(n_iso):
-            state["i"] = i
+            timer.i = i
             step()
         torch.cuda.synchronize()
-        state["i"] = -1
-        iso_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(n_iso)) / n_iso
-    bytes_per_launch = P * (16 * N + 36 * M + 4 * M + M * N)          # SURVEY 8(d), masks included (all M rows are written)
-    # executed flops: only the slots the solver marked valid are evaluated
-    with torch.no_grad():
-        _, v_, _ = rn.hypotheses(matches, logits)
-    valid_frac = float(v_.float().mean())
-    flops_per_launch = 39.0 * P * M * N * valid_frac
+        timer.i = -1
+        iso_ms = timer.mean_ms(n_iso)
+    timer.close()
+    rigid = w["solver"] == "rigid"
+    bytes_per_launch = k4r_bytes(P, N, M) if rigid else k4_bytes(P, N, M)
+    valid_frac = None
+    flops_per_launch = 28.0 * P * M * N
+    if not rigid:
+        with torch.no_grad():
+            _, v_, _ = rn.hypotheses(matches, logits)
+        valid_frac = float(v_.float().mean())
+        flops_per_launch = 39.0 * P * M * N * valid_frac   # only the slots the solver marked valid are evaluated
     achieved = bytes_per_launch / (k4_ms * 1e-3) / 1e9
+    kernel_name = "rigid_residual_kernel" if rigid else ("msac_score_kernel_f32_fast16" if N % 16 == 0 else "msac_score_kernel_f32_fast")
+    traffic, traffic_note = (None, "PMC capture exists for the c2 workload only")
+    if args.workload == "c2" and not split_h:
+        traffic, traffic_note = pmc_traffic("dr::" + kernel_name, {"pairs": P, "points": N, "hyps": B})
 
-    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (profiles/, collected with
-    # `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 5`; KiB per dispatch)
-    traffic, traffic_note = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_fetch_write.json")
-    if os.path.exists(pmc_path) and (P, N, B, args.solver) == (32, 2000, 1024, "nister"):
-        pmc_all = json.load(open(pmc_path))
-        pmc = pmc_all.get("dr::msac_score_kernel_f32_fast16", pmc_all.get("dr::msac_score_kernel_f32_fast", {}))
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            # gfx950: FETCH_SIZE shows half the bytes of 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled (upper bound:
-            # most of this kernel's reads are scalar-cache model loads); WRITE_SIZE taken as is (matches the mask bytes to 0.2 %)
-            traffic = (2.0 * pmc["FETCH_SIZE"]["avg"] + pmc["WRITE_SIZE"]["avg"]) * 1024.0
-            traffic_note = "profiles/r1_pmc_fetch_write.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch"
-
-    # sanity of the result (cheap, outside the timed region): the synthetic pairs have 50 % inliers
-    inl_frac = float(out["inliers"].float().mean()) / N
+    inl_frac = None if rigid else float(out["inliers"].float().mean()) / N
 
     result = {
         "metric": "hypotheses/sec (and image-pairs/sec) at 2000 pts x 1024 hyps, 1/2/4/8 GPU",
         "value": job_hyps_per_s,
-        "unit": "hypotheses/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"{args.solver} 5-pt E, {N} pts x {B} hyps per pair, "
-                               + ("Gumbel top-k sampler (in-kernel Philox)" if args.sampler == "gumbel" else
-                                  "top-down (Plackett-Luce) draw of the Gumbel top-k index sets")
-                               + f", MSAC scoring with masks, test mode, {P} pairs/GPU/step",
-                   "sampler": args.sampler,
-                   "pairs_per_gpu": P, "points": N, "hypotheses_per_pair": B, "models_per_pair": M,
-                   "solver": args.solver, "parallelism": f"pairs sharded over {world} GPU(s), no collective",
+        **common,
+        "config": {"workload": f"{w['text']}, test mode, {P} pairs/GPU/step", "baseline_config_index": w["baseline_config"],
+                   "sampler": w["sampler"], "pairs_per_gpu": P, "points": N, "hypotheses_per_pair": B,
+                   "hypotheses_per_pair_per_gpu": w["hyps"], "models_per_pair": B * S, "solver": w["solver"],
+                   "parallelism": (f"hypotheses of the same {P} pair(s) split over {world} GPUs, per-pair winners merged by two "
+                                   "all_gathers per step" if split_h else f"pairs sharded over {world} GPU(s), no collective"),
                    "streams": len(streams),
                    "issue": f"{len(streams)} batch(es) in flight, round-robin over {len(streams)} HIP stream(s)"},
-        "pairs_per_s": world * P * args.steps / elapsed,
-        "roofline": {"bound": "hbm", "kernel": "msac_score_kernel_f32_fast16", "valid_slot_fraction": valid_frac, "achieved": achieved,
+        "pairs_per_s": (1 if split_h else world) * P * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "valid_slot_fraction": valid_frac, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -357,20 +565,43 @@ def main():
         "with_final_refit": with_refit,
         "sampler_topdown": topdown,
     }
-    if args.profile_kernels and rank == 0:
-        result["kernel_breakdown_ms"] = kernel_breakdown(args, rn, matches, logits, K1, K2, ops)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, data)
+    if args.profile_kernels and rank == 0 and not rigid:
+        result["kernel_breakdown_ms"] = kernel_breakdown(w, rn, matches, logits, ops)
+    if rank == 0 and world == 1 and not args.no_configs:
+        n_cfg = {"c1": 300, "c2": 200, "c3": 60, "c4": 150}
+        result["configs"] = {k: config_record(k, dev, n_cfg[k], 5) for k in sorted(WORKLOADS) if k != args.workload}
+        if args.workload == "c2" and P != 32:
+            result["configs"]["c2_p32"] = config_record("c2", dev, 300, 5, pairs=32)   # round 1's batch size
+        if not args.logits_fixture and os.path.exists(os.path.join(ROOT, "tests", "golden", "clnet_logits.npz")):
+            # the c2 workload on reader-produced pairs with the reference network's scores instead of synthetic logits
+            fstep, finfo = make_step(dict(WORKLOADS["c2"], pairs=32), dev, fixture=True)
+            for _ in range(5):
+                fout = fstep()
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(200):
+                fout = fstep()
+            torch.cuda.synchronize()
+            ef = time.perf_counter() - tf
+            gi = finfo["data"]["inliers"].to(dev)
+            result["clnet_logits"] = {
+                "workload": "c2 on tests/golden/clnet_logits.npz (4 reader-produced pairs tiled to 32; sampler input = the "
+                            "reference CLNet's log-probabilities, shipped weights saved_model_5PC_l_epi)",
+                "steps": 200, "ms_per_step": ef / 200 * 1e3, "hypotheses_per_s": 32 * 1024 * 200 / ef,
+                "mean_inlier_fraction_of_best_model": float(fout["inliers"].float().mean()) / 2000,
+                "geometric_inlier_fraction_of_the_data": float(gi.float().mean()),
+                "best_mask_agreement_with_geometric_inliers": float((fout["mask"] == gi).float().mean())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and info["data"] is not None:
+        result["cpu_baseline"] = cpu_baseline(args, w, info["data"])
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def kernel_breakdown(args, rn, matches, logits, K1, K2, ops):
+def kernel_breakdown(w, rn, matches, logits, ops):
     """Per-stage device time by HIP events (each stage synchronised): sampler / gather / solver / scoring / select."""
-    import torch
-    P, N, B = args.pairs, args.points, args.hyps
+    P, N, B = w["pairs"], w["points"], w["hyps"]
     k = rn.k
     out = {}
 
@@ -387,10 +618,10 @@ def kernel_breakdown(args, rn, matches, logits, K1, K2, ops):
 
     out["K1_gumbel_topk"], r = t(lambda: ops.gumbel_topk(logits, B, k, 1.0, None, seed=1))
     out["K2_gather"], smp = t(lambda: ops.gather(matches, r["idx"], r["y_sel"]))
-    if args.solver == "f8":
+    if w["solver"] == "f8":
         out["K3_solver"], (F, v) = t(lambda: ops.solve_f8(smp))
         models, valid = F.unsqueeze(2), v.unsqueeze(2)
-    elif args.solver == "stewenius":
+    elif w["solver"] == "stewenius":
         out["K3_solver"], (models, valid) = t(lambda: ops.solve_stewenius5(smp))
     else:
         out["K3_solver"], (models, valid) = t(lambda: ops.solve_nister5(smp))
@@ -400,6 +631,8 @@ def kernel_breakdown(args, rn, matches, logits, K1, K2, ops):
     out["K4_msac_masks"], (sc, mk) = t(lambda: ops.msac_score(matches, flat, thr, True, vflat))
     out["K4_msac_nomask"], _ = t(lambda: ops.msac_score(matches, flat, thr, False, vflat))
     out["K4_msac_masks_all_slots"], _ = t(lambda: ops.msac_score(matches, flat, thr, True))
+    if N % 16 == 0 and 16 <= N <= 2048:
+        out["K4_msac_masks_filter_kernel_path2"], _ = t(lambda: ops.msac_score(matches, flat, thr, True, vflat, path=2))
     out["valid_fraction"] = float(valid.float().mean())
     out["K6_select_best"], _ = t(lambda: ops.select_best(matches, flat, sc, thr, valid.reshape(P, -1)))
     return out

@@ -262,11 +262,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st,
                   double *models64 = nullptr) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};   // per device: one process may drive several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nister5_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kFiveWs * 64));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   if (n == 5) {
     // minimal samples: two lanes per sample, 100 doubles of LDS per SAMPLE (25 KiB per block => six blocks per CU)

@@ -426,7 +426,13 @@ class _SolveEssential(torch.autograd.Function):
 
 
 def solve_essential(samples, weights=None, which="nister"):
-    """Differentiable five-point solve: samples [...,n,4] -> (models [...,10,3,3], valid [...,10])."""
+    """Differentiable five-point solve: samples [...,n,4] -> (models [...,10,3,3], valid [...,10]).
+    Gradients exist for MINIMAL samples only (n = 5): a non-minimal sample that requires grad (the reference's `-sam 3`
+    eight-point Gumbel sampler feeding the five-point estimator in train mode) is refused here, at forward time, instead
+    of failing inside .backward()."""
+    if samples.shape[-2] != 5 and samples.requires_grad and torch.is_grad_enabled():
+        raise L.DransacError("five-point solve of non-minimal samples (n = %d) is not differentiable here: train mode needs "
+                             "the five-point sampler (sampler ids 1/2), or detach the samples" % samples.shape[-2])
     return _SolveEssential.apply(samples, weights, which)
 
 

@@ -60,6 +60,7 @@ class RANSAC(object):
         self.eps = eps
         self.fused = True        # test mode with this package's own plugins: run on the device-resident batched driver
         self._fast = None
+        self._fast_cfg = None
         if lo:
             raise NotImplementedError("local optimisation is out of scope (it never ran in the reference either: "
                                       "lo defaults to 0 and lo=3 raises TypeError, SURVEY Q2)")
@@ -68,7 +69,8 @@ class RANSAC(object):
     def _hypotheses(self, matches, logits, gumbels=None):
         B = self.ransac_batch_size
         k = self.sampler.num_samples
-        if _is_gumbel(self.sampler_id):
+        own_sampler = hasattr(self.sampler, "_next_seed") and hasattr(self.sampler, "tau")
+        if _is_gumbel(self.sampler_id) and own_sampler:
             seed = self.sampler._next_seed()
             g = None if gumbels is None else gumbels.unsqueeze(0)
             lg = logits.unsqueeze(0).to(matches.dtype)
@@ -79,11 +81,31 @@ class RANSAC(object):
             else:
                 samples, w, _ = ops.SampleGather.apply(matches.unsqueeze(0), lg, B, k, self.sampler.tau, g, seed)
                 samples, w = samples[0], w[0]
+        elif _is_gumbel(self.sampler_id):
+            # a third-party sampler with the reference's duck-typed contract only (ransac.py:63-65,73):
+            # sample(logits) -> (ret [B,N], y_soft [B,N]); the straight-through gather in plain torch ops
+            ret, y_soft = self.sampler.sample(logits)
+            pts = matches.repeat([ret.shape[0], 1, 1]) * ret.unsqueeze(-1)
+            samples = pts[ret != 0].view(ret.shape[0], -1, matches.shape[-1])
+            w = y_soft[ret != 0].view(ret.shape[0], -1)
         else:
-            idx = self.sampler.sample(matches.shape[0])
+            try:
+                idx = self.sampler.sample(matches.shape[0])
+            except TypeError:                                   # the reference calls sampler.sample() (ransac.py:59)
+                idx = self.sampler.sample()
             samples, w = matches[idx], None
-        models, valid = self.estimator.estimate_model_slots(samples, w if self.weighted else None)
-        return models, valid
+        wts = w if self.weighted else None
+        if hasattr(self.estimator, "estimate_model_slots"):
+            return self.estimator.estimate_model_slots(samples, wts)
+        # a third-party estimator with the reference's contract only (ransac.py:71-76): estimate_model(samples[, w]) ->
+        # [S*B', 3, 3]; slots = consecutive groups per sample, every finite model valid
+        models = self.estimator.estimate_model(samples, wts) if wts is not None else self.estimator.estimate_model(samples)
+        nb = samples.shape[0]
+        if models is None or models.shape[0] == 0 or models.shape[0] % nb != 0:
+            raise ValueError("a plugin estimator must return S models per sample in sample order (got %s for %d samples)"
+                             % (None if models is None else tuple(models.shape), nb))
+        models = models.reshape(nb, models.shape[0] // nb, 3, 3)
+        return models, torch.isfinite(models).flatten(2).all(-1)
 
     def _fused_solver(self):
         """Name of the BatchedRANSAC solver equivalent to this object's plugins, or None (custom plugins, uniform
@@ -109,11 +131,14 @@ class RANSAC(object):
         """`gumbels` (optional, list of [B,N] tensors, one per batch) replaces the in-kernel noise: parity runs."""
         solver = self._fused_solver() if self.fused else None
         if solver is not None and matches.is_cuda:
-            if self._fast is None or self._fast.solver != solver:
+            cfg = (solver, self.ransac_batch_size, self.threshold, self.confidence, self.max_iterations, self.sampler.tau,
+                   self.weighted, self.eps)
+            if self._fast is None or self._fast_cfg != cfg:     # public attributes may change between calls (sweeps)
                 self._fast = BatchedRANSAC(solver, ransac_batch_size=self.ransac_batch_size, train=False,
                                            threshold=self.threshold, confidence=self.confidence,
                                            max_iterations=self.max_iterations, tau=self.sampler.tau, weighted=self.weighted,
                                            refit=True, eps=self.eps)
+                self._fast_cfg = cfg
             self._fast.seed = self.sampler._next_seed()
             out = self._fast(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), K1, K2,
                              gumbels=None if gumbels is None else [g.unsqueeze(0) for g in gumbels])
@@ -165,11 +190,20 @@ class RANSAC(object):
         # final refit on the inliers (ransac.py:148-195); not differentiable
         with torch.no_grad():
             inl = best_mask.nonzero(as_tuple=True)[0]
+            slots = hasattr(self.estimator, "estimate_model_slots")
+            cvalid = None
             if self.fmat:
-                cand = self.estimator.estimate_model(matches[inl].unsqueeze(0)) if inl.numel() >= 8 else None
+                pts_ = matches[inl].unsqueeze(0) if inl.numel() >= 8 else None
             else:
                 # pymagsac absent: Nister on ALL points in f64 as one sample (ransac.py:157-165 -> nister.py:64-65)
-                cand = self.estimator.estimate_model(matches.unsqueeze(0).double())
+                pts_ = matches.unsqueeze(0).double()
+            if pts_ is None:
+                cand = None
+            elif slots:      # fixed-shape slots + validity: the eye(3) fillers of failed solves must not compete
+                cand, cvalid = self.estimator.estimate_model_slots(pts_)
+                cand, cvalid = cand.reshape(-1, 3, 3), cvalid.reshape(-1)
+            else:
+                cand = self.estimator.estimate_model(pts_)
             if cand is None or cand.shape[0] == 0:
                 if not isinstance(best_model, torch.Tensor):
                     best_model = torch.eye(3, device=matches.device, dtype=matches.dtype)
@@ -177,6 +211,8 @@ class RANSAC(object):
                 cand = cand.to(matches.dtype)
                 scores, _ = self.scoring.score(matches, cand, threshold)
                 scores = torch.where(torch.isnan(scores), torch.full_like(scores, -1.0), scores)
+                if cvalid is not None:
+                    scores = torch.where(cvalid, scores, torch.full_like(scores, -1.0))
                 if scores.max() > best_score:
                     b = torch.argmax(scores)
                     best_model, best_score = cand[b], scores[b]
@@ -216,7 +252,12 @@ class RANSAC3D(object):
                 g = gumbels[batch].unsqueeze(0)
             batch += 1
             if _is_gumbel(self.sampler_id):
-                samples, _, _ = ops.SampleGather.apply(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), B, 3,
+                # the sampler's own sample size: 3, or 8 for sampler id 3 (model_cl.py:185-207 builds an 8-point sampler and
+                # the reference feeds its 8-point samples to the rigid solver, which accepts n >= 3)
+                k = int(getattr(self.sampler, "num_samples", 3))
+                if not 3 <= k <= 8:
+                    raise ValueError("RANSAC3D needs a sampler with 3 <= num_samples <= 8")
+                samples, _, _ = ops.SampleGather.apply(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), B, k,
                                                        self.sampler.tau, g, self.sampler._next_seed())
                 samples = samples[0]
             else:
@@ -256,10 +297,12 @@ class BatchedRANSAC(object):
         # sampling: "gumbel" = the reference's sampler (noise for every point of every hypothesis, top-k);
         # "topdown" = the same index-set distribution drawn as k sequential soft-max draws without replacement
         # (ops.topdown_sample, O(B k log N)); test mode only, no soft weights (weighted=0), no explicit noise.
-        if sampling not in ("gumbel", "topdown"):
-            raise ValueError("sampling must be 'gumbel' or 'topdown'")
-        if sampling == "topdown" and (train or weighted):
-            raise ValueError("top-down sampling yields index sets only: train mode and weighted=1 need the Gumbel sampler")
+        # "uniform" = UniformSampler.batch_generate (samplers/uniform_sampler.py:15-19: randint(0, N - 1), with replacement,
+        # the last point never drawn) for all pairs in one launch; index sets only, logits ignored.
+        if sampling not in ("gumbel", "topdown", "uniform"):
+            raise ValueError("sampling must be 'gumbel', 'topdown' or 'uniform'")
+        if sampling in ("topdown", "uniform") and (train or weighted):
+            raise ValueError(f"{sampling} sampling yields index sets only: train mode and weighted=1 need the Gumbel sampler")
         self.sampling = sampling
         self.pipeline = True     # test mode: issue round r+1's sampler/solver on a second stream while round r is scored
         self.sync_every = max(1, 256 // max(1, ransac_batch_size))   # rounds between termination read-backs
@@ -288,7 +331,10 @@ class BatchedRANSAC(object):
 
     def hypotheses(self, matches, logits, gumbels=None):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
-        if self.sampling == "topdown" and gumbels is None:
+        if self.sampling == "uniform" and gumbels is None:
+            idx = ops.uniform_sample(matches.shape[0], self.B, self.k, matches.shape[1], self._next_seed(), matches.device)
+            samples, w = ops.gather(matches, idx), None
+        elif self.sampling == "topdown" and gumbels is None:
             idx = ops.topdown_sample(logits, self.B, self.k, self._next_seed())
             samples, w = ops.gather(matches, idx), None
         elif not self.train and not self.weighted:
@@ -412,3 +458,68 @@ class BatchedRANSAC(object):
                 ops.refit_accept(matches, cand, cvalid, thr, best_score, best_model)
             return dict(model=best_model, mask=best_mask, score=best_score, iterations=iters, inliers=best_inl,
                         masks=all_masks)
+
+
+class BatchedRANSAC3D(object):
+    """RANSAC3D (ransac.py:303-450) over a batch of point-cloud pairs in one go: matches [P,N,6] = (p, q), logits [P,N].
+
+    One round = K1 Gumbel top-k (k = 3) -> K2 gather -> K3r rigid SVD solver -> K4r squared residuals of every model
+    against every point (+ inlier masks).  Train mode returns what the reference's train branch collects
+    (models [P, rounds*B, 4, 4], keep, residual sums [P, rounds*B], mean residual per round) with autograd to the
+    logits; test mode (dead code upstream) keeps the arg-min of the residual sum per pair."""
+
+    def __init__(self, ransac_batch_size=2048, train=False, threshold=0.03, max_iterations=1000, tau=1.0, seed=0,
+                 flag=True, keep_masks=False):
+        self.B = ransac_batch_size
+        self.train = train
+        self.threshold = threshold
+        self.max_iterations = max_iterations
+        self.tau = tau
+        self.seed = seed
+        self.calls = 0
+        self.flag = flag
+        self.keep_masks = keep_masks
+
+    def _next_seed(self):
+        s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
+        self.calls += 1
+        return s
+
+    def __call__(self, matches, logits, gumbels=None):
+        P, N, _ = matches.shape
+        rounds = max(1, math.ceil(self.max_iterations / self.B))
+        if gumbels is not None:
+            rounds = min(rounds, len(gumbels))
+        if self.train:
+            out = []
+            for r in range(rounds):
+                g = None if gumbels is None else gumbels[r]
+                samples, _, _ = ops.SampleGather.apply(matches, logits, self.B, 3, self.tau, g, self._next_seed())
+                model, R, t, scale, valid = ops.solve_rigid_autograd(samples.reshape(P * self.B, 3, 6), None, self.flag)
+                model = model.reshape(P, self.B, 4, 4)
+                res, _ = ops.rigid_residual_autograd(matches, model, self.threshold)
+                out.append((model, valid.reshape(P, self.B), res, res.sum(1) / (self.B * N)))
+            return dict(models=torch.cat([o[0] for o in out], 1), keep=torch.cat([o[1] for o in out], 1),
+                        residuals=torch.cat([o[2] for o in out], 1), mean_residuals=torch.stack([o[3] for o in out], 1))
+        with torch.no_grad():
+            best = torch.full((P,), float("inf"), device=matches.device, dtype=matches.dtype)
+            best_model = torch.eye(4, device=matches.device, dtype=matches.dtype).repeat(P, 1, 1)
+            best_mask, masks = None, None
+            ar = torch.arange(P, device=matches.device)
+            for r in range(rounds):
+                g = None if gumbels is None else gumbels[r]
+                idx = ops.gumbel_topk(logits, self.B, 3, self.tau, g, self._next_seed(), soft=False)["idx"]
+                samples = ops.gather(matches, idx)
+                model, R, t, scale, valid = ops.solve_rigid(samples.reshape(P * self.B, 3, 6), None, self.flag)
+                model = model.reshape(P, self.B, 4, 4)
+                res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks)
+                res = torch.where(valid.reshape(P, self.B), res, torch.full_like(res, float("inf")))
+                val, b = res.min(1)
+                better = val < best
+                best = torch.where(better, val, best)
+                best_model = torch.where(better[:, None, None], model[ar, b], best_model)
+                if self.keep_masks:
+                    pick = masks[ar, b]
+                    best_mask = pick if best_mask is None else torch.where(better[:, None], pick, best_mask)
+            return dict(model=best_model, residual=best, mask=best_mask, masks=masks)
+

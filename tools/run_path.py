@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Thin harness around the hot path with the reference's command-line flags (utils.py:7-83): what train.py:40 /
+test.py:38 / train_point.py:20 do with the RANSAC layer, minus the scores network (out of scope: random or fixture logits
+stand in for it).
+
+    python tools/run_path.py -nf 2000 -bs 32 -rbs 1024 -fmat 0 -sam 2 -tr 0 -t 0.75          # test.py's call
+    python tools/run_path.py -nf 2000 -bs 32 -rbs 1024 -fmat 0 -sam 2 -tr 1 -w2 1 -t 0.75    # train.py's call (+ MatchLoss, backward)
+    python tools/run_path.py -nf 2000 -bs 4 -rbs 256 -sam 2 -tr 1 --three-d                  # train_point.py's call
+
+Input: synthetic correspondences (differentiable_ransac_amd.synth) unless `-pth` names a directory of NG-RANSAC `.npy`
+pair files (differentiable_ransac_amd.data.NGRansacPairs).  Prints one JSON line: pairs/s, seconds per pair and the
+shapes the reference's callers receive (model_cl.py:236-256, 488-511).  Flags the reference parses but never uses in
+this path (-s, -topk, -k, -sch, -eta, -m, -m2, -dt, -nw, -e, -lr, -sid, -ds, -bm, -p ...) are accepted and ignored.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def create_parser():
+    """Same option names, short forms, types and defaults as the reference's create_parser (utils.py:7-83)."""
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    add = ap.add_argument
+    add("--model", "-m", default=None)
+    add("--model_loftr", "-m2", default="pretrained_models/outdoor_ds.ckpt")
+    add("--data_path", "-pth", default="dataset")
+    add("--device", "-d", default="cuda")
+    add("--detector", "-dt", default="rootsift")
+    add("--snn", "-snn", default=0.80, type=float)
+    add("--nfeatures", "-nf", type=int, default=2000)
+    add("--batch_size", "-bs", type=int, default=32)
+    add("--ransac_batch_size", "-rbs", type=int, default=64)
+    add("--fmat", "-fmat", type=int, default=0)
+    add("--scoring", "-s", type=int, default=1)
+    add("--sampler", "-sam", type=int, default=1)
+    add("--precision", "-pr", type=int, default=1)
+    add("--tr", "-tr", type=int, default=0)
+    add("--threshold", "-t", type=float, default=0.75)
+    add("--epochs", "-e", type=int, default=10)
+    add("--learning_rate", "-lr", type=float, default=1e-4)
+    add("--num_workers", "-nw", type=int, default=0)
+    add("--w0", "-w0", type=float, default=0)
+    add("--w1", "-w1", type=float, default=0)
+    add("--w2", "-w2", type=float, default=0)
+    add("--weighted", "-wei", type=int, default=0)
+    add("--datasets", "-ds", default="st_peters_square")
+    add("--batch_mode", "-bm", type=int, default=0)
+    add("--prob", "-p", type=int, default=2)
+    add("--session", "-sid", default="")
+    add("--topk", "-topk", default=False)
+    add("--k", "-k", type=int, default=300)
+    add("--scheduler", "-sch", type=int, default=0)
+    add("--eta_min", "-eta", type=float, default=1e-4)
+    # additions of this harness
+    add("--three-d", action="store_true", help="3-D registration path (train_point.py): RANSACLayer3D's solver on [N,6] pairs")
+    add("--batches", type=int, default=3, help="timed batches of -bs pairs")
+    add("--seed", type=int, default=0)
+    return ap
+
+
+def parse(argv=None):
+    opt, unknown = create_parser().parse_known_args(argv)
+    opt.ignored = unknown          # e.g. -us / -max of test_magsac_point.py
+    return opt
+
+
+def load_batch(opt, device):
+    """-> dict(points [P,N,4|6], weights [P,N], K1, K2, im1, im2, gt [P,3,3] | None)"""
+    import torch
+    from differentiable_ransac_amd import synth
+    P, N = opt.batch_size, opt.nfeatures
+    if opt.three_d:
+        items = [synth.rigid_pair(opt.seed + p, N) for p in range(P)]
+        return dict(points=torch.stack([i["matches"] for i in items]).to(device),
+                    weights=torch.stack([i["logits"] for i in items]).to(device), gt=None, source="synthetic 3-D pairs")
+    if os.path.isdir(opt.data_path) and any(f.endswith(".npy") for f in os.listdir(opt.data_path)):
+        from differentiable_ransac_amd.data import NGRansacPairs, collate_two_view
+        ds = NGRansacPairs([opt.data_path.rstrip("/") + "/"], opt.snn, N, bool(opt.fmat))
+        items = [ds[i % len(ds)] for i in range(P)]
+        c = collate_two_view(items, device)
+        im1 = torch.stack([torch.as_tensor(it["im_size1"], dtype=torch.float32) for it in items]).to(device)
+        im2 = torch.stack([torch.as_tensor(it["im_size2"], dtype=torch.float32) for it in items]).to(device)
+        # no scores network here: the side information's SNN ratio stands in for the logits (smaller ratio = better match)
+        return dict(points=c["matches"], weights=-c["side"][..., 0].contiguous(), K1=c["K1"], K2=c["K2"], im1=im1, im2=im2,
+                    gt=c["gt_F"] if opt.fmat else c["gt_E"], inliers=None,
+                    source=f"{len(ds)} pair file(s) under {opt.data_path}")
+    d = synth.batch_two_view(P, N, seed0=opt.seed, pixel=False)
+    pts = d["matches"]
+    im = torch.tensor([[1000.0, 1000.0]]).repeat(P, 1)
+    if opt.fmat:    # the F branch receives image-size-normalised points and de-normalises them (model_cl.py:240-242)
+        px = synth.batch_two_view(P, N, seed0=opt.seed, pixel=True)["matches"]
+        pts = torch.cat(((px[..., :2] - 500.0) / 1000.0, (px[..., 2:] - 500.0) / 1000.0), -1)
+    return dict(points=pts.to(device), weights=d["logits"].to(device), K1=d["K1"].to(device), K2=d["K2"].to(device),
+                im1=im.to(device), im2=im.to(device), gt=(d["gt_F"] if opt.fmat else d["gt_E"]).to(device),
+                inliers=d["inliers"].to(device), source="synthetic two-view pairs (SURVEY 8(d) recipe)")
+
+
+def run(opt):
+    import torch
+    if opt.device != "cuda" or not torch.cuda.is_available():
+        raise SystemExit("run_path.py drives the MI355X hot path: -d cuda on a GPU box (there is no CPU fallback; the CPU "
+                         "restatement is oracle/cpu_ref.py)")
+    from differentiable_ransac_amd import layers
+    from differentiable_ransac_amd.ransac import BatchedRANSAC3D
+    dev = torch.device("cuda")
+    b = load_batch(opt, dev)
+    P, N = b["points"].shape[:2]
+    weights = b["weights"].clone().requires_grad_(bool(opt.tr))
+    rec = {"flags": {k: getattr(opt, k) for k in ("nfeatures", "batch_size", "ransac_batch_size", "fmat", "sampler", "tr",
+                                                  "threshold", "weighted", "precision")},
+           "ignored_arguments": opt.ignored, "input": b["source"]}
+    if opt.three_d:
+        drv = BatchedRANSAC3D(opt.ransac_batch_size, train=bool(opt.tr), max_iterations=1000 if opt.tr else opt.ransac_batch_size)
+        call = lambda: drv(b["points"], weights)
+    else:
+        call = lambda: layers.batched_forward(opt, b["points"], weights, b["K1"], b["K2"], b.get("im1"), b.get("im2"),
+                                              b["gt"] if opt.tr else None)
+    call()                                  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(opt.batches):
+        out = call()
+        if opt.tr:
+            if opt.three_d:
+                loss = out["mean_residuals"].mean()       # train_point.py:28
+            elif opt.fmat:
+                # sign-invariant distance to the ground-truth F of the kept models (the reference's F losses need OpenCV)
+                loss = sum(torch.minimum(((e - b["gt"][p]) ** 2).sum((-1, -2)), ((e + b["gt"][p]) ** 2).sum((-1, -2))).mean()
+                           for p, e in enumerate(out[0])) / P
+            else:
+                from differentiable_ransac_amd.loss import MatchLoss       # -w2 1: the reference's default (train.py:70-79)
+                ml = MatchLoss()
+                loss = sum(ml(e[None], b["points"][p:p + 1], None if b.get("inliers") is None else b["inliers"][p:p + 1],
+                              gt_E=b["gt"][p:p + 1]) for p, e in enumerate(out[0])) / P
+            weights.grad = None
+            loss.backward()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec.update(pairs_per_s=P * opt.batches / dt, seconds_per_pair=dt / (P * opt.batches), pairs=P, points=N,
+               hypotheses_per_pair_per_round=opt.ransac_batch_size)
+    if opt.three_d:
+        rec["returns"] = {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}
+    else:
+        rec["returns"] = {"models_per_pair": [list(e.shape) for e in out[0][:4]], "seconds_per_pair_reported": out[1]}
+    if opt.tr:
+        rec["loss"] = float(loss)
+        rec["grad_finite"] = bool(torch.isfinite(weights.grad).all())
+        rec["grad_nonzero"] = bool((weights.grad != 0).any())
+    print(json.dumps(rec))
+    return rec
+
+
+if __name__ == "__main__":
+    run(parse())
