@@ -14,6 +14,7 @@
 // Backward: forward-mode differentiation (dual numbers, one pass per entry of E) of Horn + error at the selected
 // candidate -- 9 passes of ~200 flops per model; the skew matrix [b]x is a constant, as in the reference (:144-148).
 #include "dr_common.hpp"
+#include "solver_common.hpp"   // jacobi_eig3
 
 namespace dr {
 
@@ -98,6 +99,62 @@ __device__ __forceinline__ void horn_decompose(const S (&E)[9], S (&R1)[9], S (&
     R1[i] = (cof[i] - BE[i]) / bb;
     R2[i] = (cof[i] + BE[i]) / bb;
   }
+}
+
+// decompose_E (cv_utils.py:83-116): E = U S V^T, R1 = U_ W V_^T, R2 = U_ W^T V_^T (U_, V_: negated when their determinant is
+// negative), t = last column of U.  Whatever signs an SVD routine returns, {R1, R2} is the set {A + C, -A + C} with
+// A = u1 v0^T - u0 v1^T, C = u2 v2^T, u2 = u0 x u1, v2 = v0 x v1 (a joint sign flip of a pair (u_k, v_k), a lone flip of
+// u2 or v2 when sigma_3 = 0, and the determinant fix-ups all just swap the two), and t = +-u2: the four candidate poses
+// are fixed as a set; their ORDER (hence `which`, and the winner of an exact tie of votes) is a LAPACK artefact.
+// Here: V from the symmetric Jacobi eigen-decomposition of E^T E, u_k = E v_k / sigma_k.  Forward only.
+__device__ __forceinline__ void svd_decompose(const double (&E)[9], double (&R1)[9], double (&R2)[9], double (&t)[3]) {
+  double A[3][3], V[3][3], d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) A[i][j] = E[0 + i] * E[0 + j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+  jacobi_eig3(A, V, d);
+  // indices of the two largest eigenvalues (static select network)
+  const int i0 = (d[0] >= d[1] && d[0] >= d[2]) ? 0 : (d[1] >= d[2] ? 1 : 2);
+  const int ia = i0 == 0 ? 1 : 0, ib = i0 == 2 ? 1 : 2;
+  const int i1 = d[ia] >= d[ib] ? ia : ib;
+  double v0[3], v1[3], v2[3], u0[3], u1[3], u2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v0[k] = i0 == 0 ? V[k][0] : (i0 == 1 ? V[k][1] : V[k][2]);
+    v1[k] = i1 == 0 ? V[k][0] : (i1 == 1 ? V[k][1] : V[k][2]);
+  }
+  cross3(v0, v1, v2);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    u0[k] = E[3 * k] * v0[0] + E[3 * k + 1] * v0[1] + E[3 * k + 2] * v0[2];
+    u1[k] = E[3 * k] * v1[0] + E[3 * k + 1] * v1[1] + E[3 * k + 2] * v1[2];
+  }
+  const double n0 = 1.0 / sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) u0[k] *= n0;
+  const double pr = u1[0] * u0[0] + u1[1] * u0[1] + u1[2] * u0[2];   // re-orthogonalise (sigma_1 = sigma_2 for a true E)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) u1[k] -= pr * u0[k];
+  const double n1 = 1.0 / sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) u1[k] *= n1;
+  cross3(u0, u1, u2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double a = u1[i] * v0[j] - u0[i] * v1[j], c = u2[i] * v2[j];
+      R1[3 * i + j] = a + c;
+      R2[3 * i + j] = -a + c;
+    }
+    t[i] = u2[i];
+  }
+}
+
+__device__ __forceinline__ void pose_decompose(const double (&E)[9], double (&R1)[9], double (&R2)[9], double (&t)[3], int svd) {
+  if (svd) svd_decompose(E, R1, R2, t);
+  else horn_decompose<double>(E, R1, R2, t);
 }
 
 // evaluate_R_t_tensor (cv_utils.py:361-380) in degrees (eval_essential_matrix :525); tg = t_gt / (|t_gt| + 1e-8)
@@ -195,7 +252,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_error_kernel(const T *__res
                                                                  const T *__restrict__ gt_R, const T *__restrict__ gt_t, int M,
                                                                  int N, double dist_thr, T *__restrict__ err_R,
                                                                  T *__restrict__ err_t, int32_t *__restrict__ which,
-                                                                 int32_t *__restrict__ votes_out) {
+                                                                 int32_t *__restrict__ votes_out, int svd) {
   __shared__ int s_votes[kPoseTile][4];
   const int p = blockIdx.y, m0 = blockIdx.x * kPoseTile, tid = threadIdx.x;
   const int mcount = min(kPoseTile, M - m0);
@@ -219,7 +276,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_error_kernel(const T *__res
       double E[9], R1[9], R2[9], t[3];
 #pragma unroll
       for (int q = 0; q < 9; ++q) E[q] = (double)models[((size_t)p * M + m0 + ml) * 9 + q];
-      horn_decompose<double>(E, R1, R2, t);
+      pose_decompose(E, R1, R2, t, svd);
       int v[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < kPosePts; ++j) {   // unrolled: the point arrays stay in registers
@@ -263,7 +320,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_error_kernel(const T *__res
     tn = 1.0 / (sqrt(tn) + 1e-8);
 #pragma unroll
     for (int q = 0; q < 3; ++q) tg[q] *= tn;
-    horn_decompose<double>(E, R1, R2, t);
+    pose_decompose(E, R1, R2, t, svd);
     double R[9], ts[3], eq, et;
 #pragma unroll
     for (int q = 0; q < 9; ++q) R[q] = (best & 1) ? R2[q] : R1[q];
@@ -374,10 +431,10 @@ __global__ __launch_bounds__(kPoseThreads) void recover_pose_mask_kernel(const T
 
 template <typename T>
 int pose_error_launch(const T *matches, const T *models, const T *gt_R, const T *gt_t, int P, int M, int N,
-                      double dist_thr, T *err_R, T *err_t, int32_t *which, int32_t *votes, hipStream_t st) {
+                      double dist_thr, T *err_R, T *err_t, int32_t *which, int32_t *votes, hipStream_t st, int svd = 0) {
   dim3 grid((M + kPoseTile - 1) / kPoseTile, P);
   hipLaunchKernelGGL((pose_error_kernel<T>), grid, dim3(kPoseThreads), 0, st, matches, models, gt_R, gt_t, M, N, dist_thr,
-                     err_R, err_t, which, votes);
+                     err_R, err_t, which, votes, svd);
   return check_launch("pose_error_kernel");
 }
 
@@ -410,6 +467,24 @@ int dr_pose_error_fwd_f64(const double *matches, const double *models, const dou
   DR_REQUIRE(matches && models && gt_R && gt_t && err_R && err_t && which, "null pointer");
   return dr::pose_error_launch<double>(matches, models, gt_R, gt_t, P, M, N, distance_threshold, err_R, err_t, which,
                                        votes, (hipStream_t)stream);
+}
+
+int dr_pose_error_svd_fwd_f32(const float *matches, const float *models, const float *gt_R, const float *gt_t, int P, int M,
+                              int N, double distance_threshold, float *err_R, float *err_t, int32_t *which, int32_t *votes,
+                              void *stream) {
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && gt_R && gt_t && err_R && err_t && which, "null pointer");
+  return dr::pose_error_launch<float>(matches, models, gt_R, gt_t, P, M, N, distance_threshold, err_R, err_t, which, votes,
+                                      (hipStream_t)stream, 1);
+}
+
+int dr_pose_error_svd_fwd_f64(const double *matches, const double *models, const double *gt_R, const double *gt_t, int P,
+                              int M, int N, double distance_threshold, double *err_R, double *err_t, int32_t *which,
+                              int32_t *votes, void *stream) {
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && gt_R && gt_t && err_R && err_t && which, "null pointer");
+  return dr::pose_error_launch<double>(matches, models, gt_R, gt_t, P, M, N, distance_threshold, err_R, err_t, which,
+                                       votes, (hipStream_t)stream, 1);
 }
 
 int dr_pose_error_bwd_f32(const float *models, const float *gt_R, const float *gt_t, const int32_t *which,

@@ -165,11 +165,13 @@ __global__ __launch_bounds__(64) void f7_kernel(const T *__restrict__ samples, i
 template <typename T>
 int f8_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st) {
   const size_t smem = (n == 8) ? 0 : sizeof(double) * kF8Ws * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};   // per device: one process may drive several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f8_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(double) * kF8Ws * 64));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((f8_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, n, models, valid);
   return check_launch("f8_kernel");

@@ -63,9 +63,10 @@ class MatchLoss(object):
 
 
 class PoseLoss(object):
-    """PoseLoss (loss.py:11-68), essential-matrix branch with the Horn decomposition (`svd=False`, what train.py:82-93
-    passes): per pair the mean over the pair's models of (err_R + err_t) / 2 in degrees, then the mean over pairs.  One
-    launch (`dr_pose_error_fwd`) instead of a Python loop over models with four cv2.triangulatePoints calls each."""
+    """PoseLoss (loss.py:11-68): per pair the mean over the pair's models of (err_R + err_t) / 2 in degrees, then the mean
+    over pairs; `svd=False` (Horn decomposition, what train.py:82-93 passes; differentiable) or `svd=True` (decompose_E,
+    forward only).  One launch (`dr_pose_error_fwd` / `dr_pose_error_svd_fwd`) instead of a Python loop over models with
+    four cv2.triangulatePoints calls each."""
 
     def __init__(self, fmat=False):
         self.fmat = fmat
@@ -75,12 +76,11 @@ class PoseLoss(object):
         """estimated_models [P,M,3,3] (F in the F branch); pts1, pts2 [P,N,2] (calibrated coordinates, or image-size
         normalised ones + K1, K2, im sizes in the F branch); gt_R [P,3,3]; gt_t [P,3]; keep [P,M] bool (models to average
         over, e.g. the solver's validity flags; None = all) -> scalar loss."""
-        if svd:
-            raise NotImplementedError("PoseLoss: only the Horn decomposition (svd=False, what train.py passes) is implemented")
+        # svd=True: decompose_E (cv_utils.py:83-116) instead of Horn's closed form; forward only (ops.pose_error)
         if self.fmat:
             estimated_models, pts1, pts2 = calibrate(estimated_models, pts1, pts2, K1, K2, im_size1, im_size2)
         matches = torch.cat((pts1, pts2), dim=-1).to(estimated_models.dtype).contiguous()
-        err_R, err_t, _, _ = ops.pose_error(matches, estimated_models, gt_R, gt_t)
+        err_R, err_t, _, _ = ops.pose_error(matches, estimated_models, gt_R, gt_t, svd=bool(svd))
         per_model = (err_R + err_t) / 2
         if keep is not None:
             k = keep.to(per_model.dtype)

@@ -710,13 +710,30 @@ class _PoseError(torch.autograd.Function):
         return None, gm, None, None, None, None
 
 
-def pose_error(matches, models, gt_R, gt_t, distance_threshold: float = 50.0, want_votes: bool = False):
-    """eval_essential_matrix(svd=False) (cv_utils.py:503-525) for all models of all pairs: matches [P,N,4] normalised,
-    models [P,M,3,3], gt_R [P,3,3], gt_t [P,3] -> err_R, err_t [P,M] in degrees (differentiable w.r.t. models), the
-    chosen candidate [P,M] (0..3 = (R1,t) (R2,t) (R1,-t) (R2,-t)) and, optionally, the four cheirality votes."""
+def pose_error(matches, models, gt_R, gt_t, distance_threshold: float = 50.0, want_votes: bool = False, svd: bool = False):
+    """eval_essential_matrix (cv_utils.py:503-525) for all models of all pairs: matches [P,N,4] normalised,
+    models [P,M,3,3], gt_R [P,3,3], gt_t [P,3] -> err_R, err_t [P,M] in degrees, the chosen candidate [P,M]
+    (0..3 = (R1,t) (R2,t) (R1,-t) (R2,-t)) and, optionally, the four cheirality votes.
+    svd=False: Horn decomposition (what train.py passes), differentiable w.r.t. the models.  svd=True: the SVD
+    decomposition of decompose_E (cv_utils.py:83-116), forward only -- the reference's gradient goes through
+    torch.linalg.svd of a matrix with two equal singular values, where it does not exist."""
     P = matches.shape[0]
     models = models.reshape(P, -1, 3, 3)
-    return _PoseError.apply(matches, models, gt_R.reshape(P, 9), gt_t.reshape(P, 3), distance_threshold, want_votes)
+    if not svd:
+        return _PoseError.apply(matches, models, gt_R.reshape(P, 9), gt_t.reshape(P, 3), distance_threshold, want_votes)
+    if models.requires_grad and torch.is_grad_enabled():
+        raise L.DransacError("pose_error(svd=True) is forward only: the gradient through the SVD of an essential matrix "
+                             "(sigma_1 = sigma_2) is undefined; use svd=False (Horn) for training, as train.py does")
+    N, M = matches.shape[1], models.shape[1]
+    dev, dt = matches.device, matches.dtype
+    err_R = torch.empty((P, M), device=dev, dtype=dt)
+    err_t = torch.empty((P, M), device=dev, dtype=dt)
+    which = torch.empty((P, M), device=dev, dtype=torch.int32)
+    votes = torch.empty((P, M, 4), device=dev, dtype=torch.int32) if want_votes else None
+    L.call(f"dr_pose_error_svd_fwd_{L.suffix(dt)}", ptr(matches.contiguous()), ptr(models.detach().contiguous()),
+           ptr(gt_R.reshape(P, 9).to(dt).contiguous()), ptr(gt_t.reshape(P, 3).to(dt).contiguous()), c_int(P), c_int(M), c_int(N),
+           L.c_double(float(distance_threshold)), ptr(err_R), ptr(err_t), ptr(which), ptr(votes), stream())
+    return err_R, err_t, which, votes
 
 
 def recover_pose_mask(matches, models, distance_threshold: float = 50.0):

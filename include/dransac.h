@@ -311,6 +311,17 @@ int dr_pose_error_fwd_f32(const float *matches, const float *models, const float
 int dr_pose_error_fwd_f64(const double *matches, const double *models, const double *gt_R, const double *gt_t, int P,
                           int M, int N, double distance_threshold, double *err_R, double *err_t, int32_t *which,
                           int32_t *votes, void *stream);
+/* The same with the SVD decomposition of the reference's `svd=True` branch (decompose_E, cv_utils.py:83-116;
+ * eval_essential_matrix's default, cv_utils.py:503): R1,2 = U W^(+-T) V^T, t = +-u3.  The four candidate poses are the
+ * same set for every SVD sign convention; their order -- `which`, and the winner of an exact tie of votes -- is not.
+ * Forward only: the reference's gradient goes through torch.linalg.svd of a matrix with sigma_1 = sigma_2, where it is
+ * undefined. */
+int dr_pose_error_svd_fwd_f32(const float *matches, const float *models, const float *gt_R, const float *gt_t, int P, int M,
+                              int N, double distance_threshold, float *err_R, float *err_t, int32_t *which, int32_t *votes,
+                              void *stream);
+int dr_pose_error_svd_fwd_f64(const double *matches, const double *models, const double *gt_R, const double *gt_t, int P,
+                              int M, int N, double distance_threshold, double *err_R, double *err_t, int32_t *which,
+                              int32_t *votes, void *stream);
 int dr_pose_error_bwd_f32(const float *models, const float *gt_R, const float *gt_t, const int32_t *which,
                           const float *grad_err_R, const float *grad_err_t, int P, int M, float *grad_models,
                           void *stream);

@@ -620,6 +620,16 @@ def horn_decompose(E):
     return R1, R2, b1 / torch.linalg.norm(b1, dim=-1, keepdim=True)
 
 
+def svd_decompose(E):
+    """decompose_E, cv_utils.py:83-116, batched over [...,3,3]: R1 = U_ W V_^T, R2 = U_ W^T V_^T (U_, V_^T negated when
+    their determinant is negative), t = U[:, -1]."""
+    U, _, Vh = torch.linalg.svd(E)
+    W = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]], dtype=E.dtype)
+    U_ = torch.where((torch.linalg.det(U) < 0)[..., None, None], -U, U)
+    Vh_ = torch.where((torch.linalg.det(Vh) < 0)[..., None, None], -Vh, Vh)
+    return U_ @ W @ Vh_, U_ @ W.T @ Vh_, U[..., :, -1]
+
+
 def triangulate_dlt(P0, P1, x1, x2):
     """cv2.triangulatePoints (OpenCV calib3d triangulate.cpp, the call at cv_utils.py:182): per point the 4x4 system
     [x P[2] - P[0]; y P[2] - P[1]] of both cameras, solution = right singular vector of the smallest singular value.
@@ -678,10 +688,11 @@ def rotation_translation_error(R_gt, t_gt, R, t):
     return err_q, err_t
 
 
-def pose_error(E, matches, R_gt, t_gt, distance_threshold: float = 50.0):
-    """eval_essential_matrix(svd=False), cv_utils.py:503-525, for models E [M,3,3] of one pair: (err_R, err_t) in
-    degrees [M], chosen candidate [M] (first arg-max of the votes, as torch.argmax at cv_utils.py:69)."""
-    R1, R2, t = horn_decompose(E)
+def pose_error(E, matches, R_gt, t_gt, distance_threshold: float = 50.0, svd: bool = False):
+    """eval_essential_matrix, cv_utils.py:503-525, for models E [M,3,3] of one pair: (err_R, err_t) in
+    degrees [M], chosen candidate [M] (first arg-max of the votes, as torch.argmax at cv_utils.py:69).  svd selects
+    decompose_E (cv_utils.py:83-116) instead of Horn's new_decompose_E (:118-161)."""
+    R1, R2, t = svd_decompose(E) if svd else horn_decompose(E)
     with torch.no_grad():
         votes = cheirality_votes(R1, R2, t, matches[:, :2], matches[:, 2:], distance_threshold)
         which = votes.argmax(dim=-1)

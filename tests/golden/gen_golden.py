@@ -254,6 +254,14 @@ def main():
          R2=torch.stack(R2s), t=torch.stack(ts), R_sel=torch.stack(Rs), t_sel=torch.stack(tsel),
          err_R=torch.stack(eq), err_t=torch.stack(et), loss=(tot / Eg.shape[0]).detach(), grad_models=Eg.grad)
 
+    # the same models through the reference's svd=True branch (decompose_E, cv_utils.py:83-116; eval_essential_matrix's default)
+    eqs, ets = [], []
+    for E in Es:
+        a, b = ref_cv.eval_essential_matrix(p1, p2, E, pair["R"], pair["t"], svd=True)
+        eqs.append(a); ets.append(b)
+    save("pose_error_svd", matches=pair["matches"], gt_R=pair["R"], gt_t=pair["t"], models=Es, err_R=torch.stack(eqs),
+         err_t=torch.stack(ets))
+
     # ---------------------------------------------------------------- data readers (8(f) rank 4, datasets.py:16-129,311-352)
     # cv2.undistortPoints(pts, K, None) (datasets.py:85-86) does not exist here: without distortion coefficients it is the
     # pinhole inverse, which the stub implements so that the reference's own Dataset code produces the vectors.

@@ -150,3 +150,27 @@ def test_losses_f_branch_equals_e_branch(dev):
     ca = ClassificationLoss(False)(gt_E, d(data["matches"]), probs)
     cb = ClassificationLoss(True)(gt_E, d(torch.cat((p1, p2), -1)), probs, d(K1), d(K2), d(im1), d(im2))
     assert abs(float(ca) - float(cb)) < 2e-2 * abs(float(ca))
+
+
+def test_pose_error_svd_branch(dev):
+    """PoseLoss(svd=True) / eval_essential_matrix's default: decompose_E by SVD (cv_utils.py:83-116), forward only"""
+    from differentiable_ransac_amd import _lib, ops
+    from differentiable_ransac_amd.loss import PoseLoss
+    g = load_golden("pose_error_svd")
+    for dt, tol in ((torch.float64, 1e-7), (torch.float32, 5e-3)):
+        m = g["matches"].to(dt).to(dev)[None]
+        E = g["models"].to(dt).to(dev)[None]
+        eq, et, which, votes = ops.pose_error(m, E, g["gt_R"].to(dev)[None], g["gt_t"].to(dev)[None], want_votes=True, svd=True)
+        assert (eq[0].cpu().double() - g["err_R"]).abs().max() < tol
+        assert (et[0].cpu().double() - g["err_t"]).abs().max() < tol
+        # the four candidates are the oracle's (torch.linalg.svd) as a set: the sorted vote counts agree
+        if dt == torch.float64:
+            R1, R2, t = O.svd_decompose(g["models"])
+            ov = O.cheirality_votes(R1, R2, t, g["matches"][:, :2], g["matches"][:, 2:])
+            assert torch.equal(votes[0].cpu().long().sort(-1).values, ov.sort(-1).values)
+    loss = PoseLoss().forward_average(E, m[..., :2], m[..., 2:], g["gt_R"].to(dev)[None], g["gt_t"].to(dev)[None], svd=True)
+    ref = float(((g["err_R"] + g["err_t"]) / 2).mean())
+    assert abs(float(loss) - ref) < 5e-3
+    with pytest.raises(_lib.DransacError):
+        ops.pose_error(m, E.clone().requires_grad_(True), g["gt_R"].to(dev)[None], g["gt_t"].to(dev)[None], svd=True)
+

@@ -247,3 +247,18 @@ def test_pose_error_matches_reference():
     assert int(ok.sum()) >= 20
     rel = (Eg.grad - g["grad_models"]).abs().amax((-1, -2)) / g["grad_models"].abs().amax((-1, -2))
     assert rel[ok].max() < 1e-8
+
+
+def test_pose_error_svd_matches_reference():
+    """the `svd=True` branch (decompose_E, cv_utils.py:83-116): errors of the pose the cheirality vote selects"""
+    g = load_golden("pose_error_svd")
+    eq, et, _ = O.pose_error(g["models"], g["matches"], g["gt_R"], g["gt_t"], svd=True)
+    _close(eq, g["err_R"], 1e-8), _close(et, g["err_t"], 1e-8)
+    # for a TRUE essential matrix (sigma_1 = sigma_2, sigma_3 = 0: the ground truth and the five-point solutions of the
+    # fixture) both decompositions give the same four poses; for the perturbed models they differ, as they must
+    eh, th, _ = O.pose_error(g["models"], g["matches"], g["gt_R"], g["gt_t"], svd=False)
+    sv = torch.linalg.svdvals(g["models"])
+    ess = ((sv[:, 0] - sv[:, 1]).abs() < 1e-9 * sv[:, 0]) & (sv[:, 2] < 1e-9 * sv[:, 0])
+    assert int(ess.sum()) >= 6
+    assert (eq - eh).abs()[ess].max() < 1e-5 and (et - th).abs()[ess].max() < 1e-5
+

@@ -59,6 +59,15 @@ def _worker(rank, world, port, q):
         assert s.tolist() == [3.0, 4.0, 5.0, 0.5] and i.tolist() == [30, 40, 50, 5]
         assert torch.equal(m[:, 0, 0], w.float())
         assert sharding.hypothesis_seed(7, 0) == 7 and sharding.hypothesis_seed(7, 1) != sharding.hypothesis_seed(7, 2)
+        # the training step's collective as bench.py --mode train issues it (N > 1): ONE flat bucket = the scores network's
+        # gradient (622 616 f32, the reference CLNet) + the logits gradient of the rank's 32 pairs x 2000 points
+        net = torch.full((622616,), float(rank + 1))
+        lgrad = torch.full((32, 2000), 3.0 * (rank + 1))
+        sharding.allreduce_mean_([net, lgrad], dist)
+        assert float(net[0]) == 1.5 and float(net[-1]) == 1.5 and float(lgrad[31, 1999]) == 4.5
+        one = torch.ones(1)
+        dist.all_reduce(one)                       # bench.py's n_ranks_seen
+        assert int(one.item()) == world
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
