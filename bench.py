@@ -85,6 +85,10 @@ def parse():
                     help="timed region on tests/golden/clnet_logits.npz: reader-produced pairs scored by the REFERENCE's network "
                          "with its shipped weights (generated in the build container by tests/golden/gen_clnet_logits.py), "
                          "tiled to --pairs; the default run reports the same thing as the sub-record `clnet_logits`")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend.  nccl = RCCL over xGMI (the real thing).  gloo exists to run the N > 1 code paths "
+                         "on a box with ONE GPU (RCCL refuses two ranks on one device): --gpus-shared lets the ranks share it")
+    ap.add_argument("--gpus-shared", action="store_true", help="functional check only: every rank uses cuda:0")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the K timed steps are issued on round-robin.  Default 1: strictly one kernel at a "
                          "time, so that the HIP-event duration of the scoring kernel in the timed region is its own "
@@ -351,13 +355,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.gpus_shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or "RANK" in os.environ:   # under torch.distributed.run even a single rank initialises RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from differentiable_ransac_amd import ops, sharding
     from differentiable_ransac_amd.ransac import BatchedRANSAC

@@ -59,7 +59,10 @@ def _devices() -> set:
 
 
 def ptr(t: Optional[torch.Tensor]) -> c_void_p:
-    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    """Device pointer of a contiguous CUDA tensor (None -> NULL).  The tensor is kept alive until the call() it is an
+    argument of has enqueued its launch: `ptr(x.contiguous())` / `ptr(x.to(dtype))` create temporaries that would
+    otherwise be freed as soon as ptr() returns, and the caching allocator would hand their block to the next temporary of
+    the same argument list."""
     if t is None:
         return c_void_p(0)
     if not t.is_cuda:
@@ -67,6 +70,10 @@ def ptr(t: Optional[torch.Tensor]) -> c_void_p:
     if not t.is_contiguous():
         raise DransacError("tensor must be contiguous")
     _devices().add(t.device.index)
+    keep = getattr(_ctx, "keep", None)
+    if keep is None:
+        keep = _ctx.keep = []
+    keep.append(t)
     return c_void_p(t.data_ptr())
 
 
@@ -101,11 +108,14 @@ def call(name: str, *args) -> None:
     fn.restype = c_int
     dev = _launch_device()
     _ctx.devs = set()
-    if dev is not None and dev != torch.cuda.current_device():
-        with torch.cuda.device(dev):       # tensors on another GPU than the current one: launch there
+    try:
+        if dev is not None and dev != torch.cuda.current_device():
+            with torch.cuda.device(dev):       # tensors on another GPU than the current one: launch there
+                status = fn(*args)
+        else:
             status = fn(*args)
-    else:
-        status = fn(*args)
+    finally:
+        _ctx.keep = []                         # the launch is enqueued on the tensors' stream: stream order protects them now
     check(status, name)
 
 

@@ -119,8 +119,11 @@ struct Philox {
   __host__ __device__ static inline void gen(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                              uint32_t out[4]) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#ifndef DR_PHILOX_ROUNDS
+#define DR_PHILOX_ROUNDS 10   // (timing experiments only: scratch/ab_k1.py)
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < DR_PHILOX_ROUNDS; ++r) {
       uint32_t h0, l0, h1, l1;
       mulhilo(M0, c0, h0, l0);
       mulhilo(M1, c2, h1, l1);
@@ -139,6 +142,11 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
   // u in [2^-126, 1) and -ln u in [6e-8, 87.4]: both log arguments are normal numbers, so the raw v_log_f32
   // (no denormal fix-up sequence) is exact to its 1-ulp spec
   const float kLn2 = 0.69314718055994530942f;
+#if defined(DR_K1_NOISE_EXPERIMENT) && DR_K1_NOISE_EXPERIMENT == 1   // timing experiment: no logarithm at all
+  return u;
+#elif defined(DR_K1_NOISE_EXPERIMENT) && DR_K1_NOISE_EXPERIMENT == 2   // timing experiment: one logarithm
+  return -kLn2 * __builtin_amdgcn_logf(u);
+#endif
   const float a = -kLn2 * __builtin_amdgcn_logf(u);
   return -kLn2 * __builtin_amdgcn_logf(a);
 }

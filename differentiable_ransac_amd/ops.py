@@ -730,8 +730,11 @@ def pose_error(matches, models, gt_R, gt_t, distance_threshold: float = 50.0, wa
     err_t = torch.empty((P, M), device=dev, dtype=dt)
     which = torch.empty((P, M), device=dev, dtype=torch.int32)
     votes = torch.empty((P, M, 4), device=dev, dtype=torch.int32) if want_votes else None
-    L.call(f"dr_pose_error_svd_fwd_{L.suffix(dt)}", ptr(matches.contiguous()), ptr(models.detach().contiguous()),
-           ptr(gt_R.reshape(P, 9).to(dt).contiguous()), ptr(gt_t.reshape(P, 3).to(dt).contiguous()), c_int(P), c_int(M), c_int(N),
+    # keep every converted tensor alive until the launch is enqueued: a temporary passed straight to ptr() is freed at
+    # once and the caching allocator hands its block to the next temporary
+    mt_, md_ = matches.contiguous(), models.detach().contiguous()
+    gR_, gt_ = gt_R.reshape(P, 9).to(dt).contiguous(), gt_t.reshape(P, 3).to(dt).contiguous()
+    L.call(f"dr_pose_error_svd_fwd_{L.suffix(dt)}", ptr(mt_), ptr(md_), ptr(gR_), ptr(gt_), c_int(P), c_int(M), c_int(N),
            L.c_double(float(distance_threshold)), ptr(err_R), ptr(err_t), ptr(which), ptr(votes), stream())
     return err_R, err_t, which, votes
 

@@ -157,7 +157,8 @@ def test_pose_error_svd_branch(dev):
     from differentiable_ransac_amd import _lib, ops
     from differentiable_ransac_amd.loss import PoseLoss
     g = load_golden("pose_error_svd")
-    for dt, tol in ((torch.float64, 1e-7), (torch.float32, 5e-3)):
+    # (at the ground truth arccos turns 1e-16 of rounding into 1e-6 degrees: entries 0, 1 of the fixture)
+    for dt, tol in ((torch.float64, 2e-6), (torch.float32, 5e-3)):
         m = g["matches"].to(dt).to(dev)[None]
         E = g["models"].to(dt).to(dev)[None]
         eq, et, which, votes = ops.pose_error(m, E, g["gt_R"].to(dev)[None], g["gt_t"].to(dev)[None], want_votes=True, svd=True)

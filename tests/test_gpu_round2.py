@@ -235,16 +235,28 @@ def test_batched_ransac3d(dev):
     from differentiable_ransac_amd import synth
     from differentiable_ransac_amd.ransac import BatchedRANSAC3D
     P, N, B = 3, 4096, 256
-    items = [synth.rigid_pair(20 + p, N) for p in range(P)]
-    m = torch.stack([i["matches"] for i in items]).to(dev)
-    lg = torch.stack([i["logits"] for i in items]).to(dev)
+    # Pure translations: the reference's residual applies model[:3,:3] as a column-vector rotation while its solver
+    # returns the row-vector one, so only R = R^T data is geometrically consistent on this path.  Test mode
+    # keeps the arg-min of the residual SUM (the documented stand-in for the reference's dead test branch, Q4), which
+    # separates models only when the outliers do not dominate the sum: 90 % inliers.
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(P, N, 3, generator=g)
+    t = torch.randn(P, 1, 3, generator=g) * 0.3
+    q = pts + t + 0.01 * torch.randn(P, N, 3, generator=g)
+    out_mask = torch.rand(P, N, generator=g) < 0.1
+    q = torch.where(out_mask[..., None], torch.rand(P, N, 3, generator=g), q)
+    m = torch.cat((pts, q), -1).to(dev)
+    lg = (3.0 * (~out_mask).float() + torch.randn(P, N, generator=g)).to(dev)
     out = BatchedRANSAC3D(B, train=False, max_iterations=4 * B, flag=False, keep_masks=True)(m, lg)
     for p in range(P):
-        # half of the points are outliers; the winner explains (nearly) all the others: d2 < 0.03 for > 45 % of the points,
-        # and its residual sum is that of the outliers alone (uniform points in the unit cube: E d2 = 0.5 per outlier)
-        assert int(out["mask"][p].sum()) > 0.45 * N
-        assert float(out["residual"][p]) < 0.5 * N * 0.5 * 1.25
-    lgg = lg.clone().requires_grad_(True)
+        T = out["model"][p].cpu()
+        d2 = ((q[p] - (pts[p] @ T[:3, :3].T + T[:3, 3])) ** 2).sum(-1)           # the residual the kernel defines
+        assert abs(float(out["residual"][p]) - float(d2.sum())) < 1e-3 * float(d2.sum())
+        assert int((out["mask"][p].cpu() != (d2 < 0.03)).sum()) <= 2
+        assert int(out["mask"][p].sum()) > 0.85 * N and (T[:3, 3] - t[p, 0]).abs().max() < 0.02
+    items = [synth.rigid_pair(20 + p, N) for p in range(P)]
+    m = torch.stack([i["matches"] for i in items]).to(dev)
+    lgg = torch.stack([i["logits"] for i in items]).to(dev).requires_grad_(True)
     tr = BatchedRANSAC3D(B, train=True, max_iterations=2 * B, flag=True)(m, lgg)
     assert tr["models"].shape == (P, 2 * B, 4, 4) and tr["residuals"].shape == (P, 2 * B) and tr["mean_residuals"].shape == (P, 2)
     tr["mean_residuals"].mean().backward()

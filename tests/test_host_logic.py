@@ -56,11 +56,13 @@ def test_ops_refuse_cpu_tensors_without_touching_the_gpu():
         ops.topdown_sample(torch.rand(1, 16), 4, 3)
 
 
-def test_pose_loss_rejects_the_svd_branch_and_calibrate_matches_the_reference_formulas():
+def test_pose_loss_has_no_cpu_path_and_calibrate_matches_the_reference_formulas():
+    from differentiable_ransac_amd import _lib
     from differentiable_ransac_amd.loss import PoseLoss, calibrate
-    with pytest.raises(NotImplementedError):
-        PoseLoss().forward_average(torch.zeros(1, 1, 3, 3), torch.zeros(1, 4, 2), torch.zeros(1, 4, 2), torch.eye(3)[None],
-                                   torch.ones(1, 3), svd=True)
+    for svd in (False, True):      # both decompositions run on the GPU only (no CPU fallback anywhere in the product)
+        with pytest.raises(_lib.DransacError):
+            PoseLoss().forward_average(torch.zeros(1, 1, 3, 3), torch.zeros(1, 4, 2), torch.zeros(1, 4, 2), torch.eye(3)[None],
+                                       torch.ones(1, 3), svd=svd)
     # E = K2^T F K1 ; points: pts * max(im_size) + (w/2, h/2), then (p - c) / f
     g = torch.Generator().manual_seed(0)
     F = torch.randn(2, 3, 3, 3, generator=g)
