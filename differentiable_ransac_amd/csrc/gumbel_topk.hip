@@ -21,6 +21,9 @@
 
 namespace dr {
 
+#ifndef DR_K1_FAST
+#define DR_K1_FAST 1   // 0: always the general kernel (A/B builds)
+#endif
 constexpr int kRowsPerBlock = 4;   // one wave per row
 constexpr int kMaxK = 8;
 constexpr int kMaxCand = 64;
@@ -281,6 +284,154 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
   }
 }
 
+// ---- benchmark-shape specialisation of the kernel above ----------------------------------------------------------------
+// f32, in-kernel Philox, logits given, tau = 1, N % 4 == 0 and N <= 2048, no dense outputs: what every RANSAC round of the
+// drivers asks for.  Same algorithm, same Philox counters, same comparison order -- the index sets are bit-identical to
+// the general kernel's, y_sel / lse agree to rounding (tests/test_gpu_round2.py) -- but a lane keeps its eight 4-element
+// groups of g in 32 REGISTERS instead of an LDS row cache, and none of the per-iteration mode tests of load_group exist.
+// Measured at 32 x 1024 x 2000 (scratch/ab_k1.py): general kernel 77.7 us in test mode (Philox 29.5, the two logarithms
+// 7.7, everything else 42-48), this kernel 60.0 us (everything else: 29); train mode 88.1 -> 74.4 us.
+constexpr int kFastGroups = 8;   // groups per lane: 64 lanes x 8 groups x 4 elements = 2048
+
+template <bool kSoft>
+__global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(const float *__restrict__ logits, uint64_t seed,
+                                                                             int B, int N, int k, int32_t *__restrict__ idx,
+                                                                             float *__restrict__ y_sel,
+                                                                             float *__restrict__ lse_out) {
+  __shared__ float s_val[kRowsPerBlock][kMaxCand];
+  __shared__ int s_idx[kRowsPerBlock][kMaxCand];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
+  if (b >= B) return;   // whole wave exits together (no block-level barrier is used below)
+  const int groups = N >> 2;
+  const size_t row = (size_t)p * B + b;
+  const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
+  float *cand_val = s_val[wv];
+  int *cand_idx = s_idx[wv];
+
+  // ---------------- pass A: g into registers, online soft-max, lane maximum
+  float g[kFastGroups][4];
+  float mx = -INFINITY, sm = 0.f, lmax = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kFastGroups; ++i) {
+    const int q = lane + 64 * i;
+    if (q < groups) {
+      uint32_t r[4];
+      Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+      const float4 l = lg[q];
+      g[i][0] = l.x + gumbel_from_bits(r[0]);
+      g[i][1] = l.y + gumbel_from_bits(r[1]);
+      g[i][2] = l.z + gumbel_from_bits(r[2]);
+      g[i][3] = l.w + gumbel_from_bits(r[3]);
+      const float gm = fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3]));
+      lmax = fmaxf(lmax, gm);
+      if (kSoft) {
+        if (gm > mx) { sm *= exp_t<float>(mx - gm); mx = gm; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += exp_t<float>(g[i][j] - mx);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[i][j] = -INFINITY;
+    }
+  }
+  float wmx = 0.f, lse = 0.f, inv_sm = 0.f;
+  if (kSoft) {
+    wmx = row_max(mx);
+    sm *= (mx == -INFINITY) ? 0.f : exp_t<float>(mx - wmx);
+    sm = row_sum(sm);
+    lse = wmx + log_t<float>(sm);
+    inv_sm = 1.0f / sm;
+  }
+
+  // ---------------- threshold: k-th largest lane maximum
+  float v = lmax, thr = -INFINITY;
+  for (int r = 0; r < k; ++r) {
+    thr = row_max(v);
+    const unsigned long long who = __ballot(v == thr);
+    if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
+  }
+
+  // ---------------- pass B: compact candidates { g >= thr } (same order as the general kernel: group-major, element, lane)
+  int ncand = 0;
+#pragma unroll
+  for (int i = 0; i < kFastGroups; ++i) {
+    if (64 * i >= groups) break;   // wave-uniform
+    const int q = lane + 64 * i;
+    if (!__ballot(fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3])) >= thr)) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool c = g[i][j] >= thr;
+      const unsigned long long bal = __ballot(c);
+      if (bal) {
+        const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+        if (c && pos < kMaxCand) { cand_val[pos] = g[i][j]; cand_idx[pos] = 4 * q + j; }
+        ncand += __popcll(bal);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  if (ncand <= kMaxCand) {
+    const bool have = lane < ncand;
+    const float cv = have ? cand_val[lane] : -INFINITY;
+    const int ci = have ? cand_idx[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < ncand; ++j) {
+      const float ov = cand_val[j];
+      const int oi = cand_idx[j];
+      rank += (ov > cv) || (ov == cv && oi < ci);
+    }
+    const bool win = have && rank < k;
+    const unsigned long long wb = __ballot(win);
+    int pos = 0;
+    for (int j = 0; j < ncand; ++j) {
+      if ((wb >> j) & 1ull) pos += cand_idx[j] < ci;
+    }
+    if (win) {
+      idx[row * k + pos] = ci;
+      if (kSoft) y_sel[row * k + pos] = exp_t<float>(cv - wmx) * inv_sm;
+    }
+  } else {
+    // slow path (massive ties): k rounds of (value desc, index asc) arg-max with exclusion of earlier winners
+    int won[kMaxK];
+    float wong[kMaxK];
+    for (int r = 0; r < k; ++r) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < kFastGroups; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 4 * (lane + 64 * i) + j;
+          bool skip = n >= N;
+          for (int s = 0; s < r; ++s) skip = skip || (won[s] == n);
+          if (!skip && (g[i][j] > bv || (g[i][j] == bv && n < bi))) { bv = g[i][j]; bi = n; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      won[r] = bi;
+      wong[r] = bv;
+    }
+    if (lane < k) {
+      int me = 0;
+      float mg = 0.f;
+      for (int r = 0; r < k; ++r) if (r == lane) { me = won[r]; mg = wong[r]; }
+      int pos = 0;
+      for (int r = 0; r < k; ++r) pos += won[r] < me;
+      idx[row * k + pos] = me;
+      if (kSoft) y_sel[row * k + pos] = exp_t<float>(mg - wmx) * inv_sm;
+    }
+  }
+  if (kSoft && lane == 0) lse_out[row] = lse;
+}
+
 template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st) {
@@ -291,6 +442,17 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
   dim3 grid((B + kRowsPerBlock - 1) / kRowsPerBlock, P);
   dim3 block(kRowsPerBlock * 64);
   const bool soft = y_sel != nullptr;   // the entry points have checked: y_sel and lse both given, or neither (then no dense outputs)
+  if constexpr (sizeof(T) == 4) {
+    if (DR_K1_FAST && logits && !gumbel && tau == T(1) && (N & 3) == 0 && N <= 4 * 64 * kFastGroups && !y_soft && !ret && !gumbel_out) {
+      if (soft)
+        hipLaunchKernelGGL((gumbel_topk_fast_kernel<true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
+                           (float *)y_sel, (float *)lse);
+      else
+        hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
+                           (float *)y_sel, (float *)lse);
+      return check_launch("gumbel_topk_fast_kernel");
+    }
+  }
   if (base + cache <= 64 * 1024) {
     if (soft)
       hipLaunchKernelGGL((gumbel_topk_kernel<T, true, true>), grid, block, base + cache, st, a, idx, y_sel, lse, y_soft, ret,

@@ -2,7 +2,7 @@
   build: python scratch/ab_k1.py --build      run (GPU box): python scratch/ab_k1.py"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
-variants = {'base': [], 'nolog': ['-DDR_K1_NOISE_EXPERIMENT=1'], 'onelog': ['-DDR_K1_NOISE_EXPERIMENT=2'],
+variants = {'base': [], 'general': ['-DDR_K1_FAST=0'], 'nolog': ['-DDR_K1_NOISE_EXPERIMENT=1'], 'onelog': ['-DDR_K1_NOISE_EXPERIMENT=2'],
             'philox7': ['-DDR_PHILOX_ROUNDS=7'], 'philox0': ['-DDR_PHILOX_ROUNDS=0'],
             'philox0_nolog': ['-DDR_PHILOX_ROUNDS=0', '-DDR_K1_NOISE_EXPERIMENT=1']}
 if '--build' in sys.argv:

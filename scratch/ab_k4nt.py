@@ -1,8 +1,8 @@
-"""A/B of the general scoring kernel's mask-store policy (DR_K4_STORE: 0 plain, 1 non-temporal) at the benchmark shape.
+"""A/B of general-scoring-kernel build variants (tile size, mask-store policy) at the benchmark shape (K4_PAIRS pairs).
   build (CPU box): python scratch/ab_k4nt.py --build      run (GPU box): python scratch/ab_k4nt.py"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
-VARIANTS = {'old': ['-DDR_K4_PERSIST=0'], 'persist32': ['-DDR_K4_PERSIST=1', '-DDR_K4_TILEP=32'], 'persist64': ['-DDR_K4_PERSIST=1', '-DDR_K4_TILEP=64']}
+VARIANTS = {'tile64': [], 'tile32': ['-DDR_K4_TILE16=32'], 'tile128': ['-DDR_K4_TILE16=128'], 'nt': ['-DDR_K4_STORE=1']}
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
@@ -12,7 +12,7 @@ if '--build' in sys.argv:
 import torch
 from differentiable_ransac_amd import ops, synth
 dev = 'cuda'
-P, N, B = 32, 2000, 1024
+P, N, B = int(os.environ.get('K4_PAIRS', '32')), 2000, 1024
 data = synth.batch_two_view(P, N)
 r = ops.gumbel_topk(data['logits'].to(dev), B, 5, 1.0, None, seed=1)
 smp = ops.gather(data['matches'].to(dev), r['idx'])

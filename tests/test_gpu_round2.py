@@ -193,6 +193,32 @@ def test_drop_in_class_follows_attribute_changes(dev):
     assert it1 == 128 and int(m2.sum()) > int(m1.sum())
 
 
+# ---------------------------------------------------------------------------------------------------- K1 register kernel
+@pytest.mark.parametrize("N,B,k", [(2000, 1024, 5), (2048, 130, 8), (128, 64, 3), (4, 7, 2), (1996, 33, 5)])
+def test_sampler_register_kernel_equals_general_kernel(dev, N, B, k):
+    """the benchmark-shape specialisation of K1 (g in registers, N <= 2048, tau = 1, Philox) against the general kernel
+    (forced by asking for the noise) and, through the returned noise, against the oracle: bit-identical index sets"""
+    from differentiable_ransac_amd import ops, synth
+    P = 3
+    logits = synth.batch_two_view(P, max(N, 8), seed0=11)["logits"][:, :N].contiguous().to(dev)
+    for seed in (1, 987654321):
+        fast = ops.gumbel_topk(logits, B, k, 1.0, None, seed=seed)                       # register kernel
+        gen = ops.gumbel_topk(logits, B, k, 1.0, None, seed=seed, want_noise=True)        # general kernel (dense output)
+        assert torch.equal(fast["idx"], gen["idx"])
+        # the soft-max statistics agree to rounding (the two kernels contract their fma chains differently)
+        assert torch.allclose(fast["y_sel"], gen["y_sel"], rtol=5e-6, atol=1e-9) and torch.allclose(fast["lse"], gen["lse"], rtol=2e-6, atol=2e-6)
+        fi = ops.gumbel_topk(logits, B, k, 1.0, None, seed=seed, soft=False)
+        assert torch.equal(fi["idx"], gen["idx"]) and fi["y_sel"] is None
+        for p in range(P):                                                                 # oracle on the kernel's own noise
+            oi, _, _ = O.gumbel_topk(logits[p].cpu(), gen["gumbel"][p].cpu(), 1.0, k)
+            assert torch.equal(oi.to(torch.int32), fast["idx"][p].cpu())
+    # massive ties (constant logits, tiny N): the slow path of both kernels agrees too
+    ties = torch.zeros(1, 8, device=dev)
+    a = ops.gumbel_topk(ties, 16, 3, 1.0, None, seed=5)
+    b_ = ops.gumbel_topk(ties, 16, 3, 1.0, None, seed=5, want_noise=True)
+    assert torch.equal(a["idx"], b_["idx"])
+
+
 # ---------------------------------------------------------------------------------------------------- uniform sampler law
 def test_uniform_sampler_chi_square(dev):
     """dr_uniform_sample against the law of torch.randint(0, N - 1): uniform on 0 .. N - 2, the last point never drawn
