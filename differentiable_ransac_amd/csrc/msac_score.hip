@@ -42,7 +42,9 @@
 // Round 2: non-temporal mask stores 226 vs 208 us (they help a contiguous LDS-assembled stream, not 1 KiB row pieces);
 // a persistent grid (one resident wave of blocks, every block five 32-slot tiles of one pair, points loaded once) 218 vs
 // 200 us, with 64-slot tiles 247 us: the hardware's dynamic dispatch of 5 120 unequal blocks balances better than equal
-// static shares started in lock step (scratch/ab_k4nt.py).  The matrix-core candidate filter is csrc/msac_filter.hip.
+// static shares started in lock step (scratch/ab_k4nt.py); register budgets for 3 / 5 / 6 waves per SIMD instead of 4:
+// 233 / 221 / 343 us; 32- and 128-slot tiles at 128 pairs per launch: 793 / 757 against 692 us.  The matrix-core
+// candidate filter is csrc/msac_filter.hip.
 #include "dr_common.hpp"
 #include "msac_filter.hpp"
 
@@ -439,7 +441,15 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 #endif
 constexpr int kT16 = 128, kP16 = 16, kChunk16 = kT16 * kP16;
 
-__global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
+#ifndef DR_K4_WAVES
+#define DR_K4_WAVES 0   // A/B knob: > 0 pins the register budget to that many waves per SIMD (amdgpu_waves_per_eu)
+#endif
+#if DR_K4_WAVES > 0
+#define DR_K4_OCC __attribute__((amdgpu_waves_per_eu(DR_K4_WAVES, DR_K4_WAVES)))
+#else
+#define DR_K4_OCC
+#endif
+__global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
                                                                      const float *__restrict__ models,
                                                                      const uint8_t *__restrict__ valid,
                                                                      const float *__restrict__ thr, int M, int N,
