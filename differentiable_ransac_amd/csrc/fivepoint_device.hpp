@@ -5,6 +5,12 @@
 
 namespace dr {
 
+// 1: the root search of the two-lanes-per-sample kernels deals the brackets that hold a sign change out over the wave
+// (real_roots_half_wave) instead of refining every bracket in every lane
+#ifndef DR_K3_WAVE_ROOTS
+#define DR_K3_WAVE_ROOTS 1
+#endif
+
 constexpr int kFiveWs = 162;   // doubles of LDS per lane: B block (100) for the minimal path, A^T A + V (162) for n > 5
 
 // ---- null-space basis ---------------------------------------------------------------------------------
@@ -212,32 +218,144 @@ __device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&
 // through the five points", not "the root finder said so".
 // `dst64` (optional): the same model in f64 as a second output (train mode keeps it for the backward); it also selects the
 // f64 stopping tolerance.
-template <typename T>
-__device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double x, double y, double z, bool candidate,
-                                                T *__restrict__ dst, bool store, double *__restrict__ dst64 = nullptr) {
+// core: polish + verification; E = the unit-norm matrix sum_k u_k N_k (row-major in the basis' own entry order)
+__device__ __forceinline__ bool finish_core(const double (&nb)[4][9], double x, double y, double z, bool candidate, double tol2,
+                                            double (&E)[9]) {
   const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
   double u[4] = {x * inv, y * inv, z * inv, inv};
   bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
   if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
-  polish_homog(nb, u, good, (sizeof(T) == 4 && !dst64) ? 1e-17 : 1e-28);
-  double E[9], r[10];
+  polish_homog(nb, u, good, tol2);
+  double r[10];
 #pragma unroll
   for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
   essential_residual(E, r);
   double rn = 0;
 #pragma unroll
   for (int q = 0; q < 10; ++q) rn += r[q] * r[q];
-  good = good && is_finite(rn) && rn <= 1e-14;
-  if (good && store) {
+  return good && is_finite(rn) && rn <= 1e-14;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_model(const double (&E)[9], T *__restrict__ dst, double *__restrict__ dst64) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int jx = 0; jx < 3; ++jx) {
-        dst[3 * i + jx] = (T)E[3 * jx + i];   // stored transposed (nister.py:407)
-        if (dst64) dst64[3 * i + jx] = E[3 * jx + i];
-      }
-  }
+    for (int jx = 0; jx < 3; ++jx) {
+      dst[3 * i + jx] = (T)E[3 * jx + i];   // stored transposed (nister.py:407)
+      if (dst64) dst64[3 * i + jx] = E[3 * jx + i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double x, double y, double z, bool candidate,
+                                                T *__restrict__ dst, bool store, double *__restrict__ dst64 = nullptr) {
+  double E[9];
+  const bool good = finish_core(nb, x, y, z, candidate, (sizeof(T) == 4 && !dst64) ? 1e-17 : 1e-28, E);
+  if (good && store) store_model<T>(E, dst, dst64);
   return good;
+}
+
+// ---- balanced final stage of the two-lanes-per-sample kernels -------------------------------------------------
+// After the root search a lane holds 0..10 candidate solutions (x, y, z) of its half of its sample; a wave's 64 lanes hold
+// ~130 of them in total, but the lane with the most has 6-7, and a loop "every lane finishes its own" runs that long
+// with two thirds of the lanes idle.  Here the candidates of the whole wave go into one LDS queue (in lane order, then
+// root order) and are dealt out 64 at a time: lane l of round r polishes and verifies candidate 64 r + l, whichever
+// sample it came from (the sample's null-space basis waits in LDS: `nb_lds[(9 t + q) * 32 + j]`, sample j of the block).
+// Output slots are what the per-lane loop produced: the verified solutions of half 0 fill a sample's slots upwards from 0
+// in root order, those of half 1 downwards from 9, eye(3) in between (rank of a candidate among the verified ones of its
+// (sample, half) = verified ones before it in this round, by ballot, + the running count kept in LDS).
+// Block = ONE wave, so LDS traffic is ordered by program order and no barrier is needed.
+struct FinishQueue {
+  double *nb_lds;    // 36 x 32 doubles
+  double *q;         // 3 x 320 doubles: x | y | z of the candidates
+  uint16_t *meta;    // 320: source lane | candidate flag << 6
+  int *cnt;          // 64: verified solutions so far of (sample, half) = source lane
+  static constexpr int kDoubles = 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2;
+  __device__ __forceinline__ explicit FinishQueue(double *lds)
+      : nb_lds(lds), q(lds + 36 * 32), meta(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 3 * 320)),
+        cnt(reinterpret_cast<int *>(lds + 36 * 32 + 3 * 320 + 320 / 4)) {}
+};
+
+__device__ __forceinline__ void park_basis(const FinishQueue &fq, const double (&nb)[4][9], int lane) {
+  if ((lane & 1) == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int qq = 0; qq < 9; ++qq) fq.nb_lds[(9 * t + qq) * 32 + (lane >> 1)] = nb[t][qq];
+  }
+}
+
+// xs/ys/zs[0..n-1]: this lane's candidates (dense), cand: bit i = candidate i is finite / solvable.  s0 = first sample of
+// the block.  Lanes of samples >= Bt pass n = 0.
+template <typename T>
+__device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane, int n, const double (&xs)[10], const double (&ys)[10],
+                                                const double (&zs)[10], unsigned cand, size_t s0, bool active,
+                                                T *__restrict__ models, uint8_t *__restrict__ valid, double *__restrict__ models64) {
+  // exclusive prefix sum of n over the wave
+  int incl = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    incl += (lane >= d) ? o : 0;
+  }
+  const int total = __shfl(incl, 63, 64);
+  const int off = incl - n;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    if (i < n) {
+      fq.q[off + i] = xs[i];
+      fq.q[320 + off + i] = ys[i];
+      fq.q[640 + off + i] = zs[i];
+      fq.meta[off + i] = (uint16_t)(lane | (((cand >> i) & 1u) << 6));
+    }
+  }
+  fq.cnt[lane] = 0;
+  const double tol2 = (sizeof(T) == 4 && !models64) ? 1e-17 : 1e-28;
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    const bool has = e < total;
+    const int ec = has ? e : total - 1;
+    const double x = fq.q[ec], y = fq.q[320 + ec], z = fq.q[640 + ec];
+    const unsigned m = fq.meta[ec];
+    const int src = m & 63;
+    const int j = src >> 1;
+    double nb[4][9];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int qq = 0; qq < 9; ++qq) nb[t][qq] = fq.nb_lds[(9 * t + qq) * 32 + j];
+    double E[9];
+    const bool good = finish_core(nb, x, y, z, has && ((m >> 6) & 1u), tol2, E);
+    // rank among the verified candidates of the same source lane
+    const int gid = has ? src : 64 + lane;
+    const int prev = __shfl_up(gid, 1, 64);
+    const bool is_start = lane == 0 || prev != gid;
+    const unsigned long long sm = __ballot(is_start), gm = __ballot(good);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+    const int st = 63 - __clzll((long long)(sm & upto));
+    const unsigned long long below = ((1ull << lane) - 1ull) & ~((1ull << st) - 1ull);
+    const int rank = fq.cnt[src] + __popcll(gm & below);
+    const bool is_end = lane == 63 || ((sm >> (lane + 1)) & 1ull);
+    if (has && is_end) fq.cnt[src] = rank + (good ? 1 : 0);
+    if (good && rank < 10) {
+      const int slot = (src & 1) ? 9 - rank : rank;
+      const size_t sm_ = s0 + (size_t)j;
+      store_model<T>(E, models + sm_ * 90 + 9 * slot, models64 ? models64 + sm_ * 90 + 9 * slot : nullptr);
+      valid[sm_ * 10 + slot] = 1;
+    }
+  }
+  // eye(3) between the two halves' solutions
+  if (active && (lane & 1) == 0) {
+    const int lo = min(fq.cnt[lane], 10), hi = min(fq.cnt[lane + 1], 10);
+    const size_t sm_ = s0 + (size_t)(lane >> 1);
+    for (int s = min(lo, 10 - hi); s < 10 - hi; ++s) {
+      write_identity<T>(models + sm_ * 90 + 9 * s);
+      if (models64) write_identity<double>(models64 + sm_ * 90 + 9 * s);
+      valid[sm_ * 10 + s] = 0;
+    }
+  }
 }
 
 // ---- Nister: B(z) from the reduced rows, det B(z), roots, back-substitution -----------------------------
@@ -343,6 +461,126 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
       valid[s] = 0;
     }
   }
+}
+
+// LDS doubles per 32-sample block of the two-lanes-per-sample Nister kernel: basis (36 x 32) + B(z) (39 x 32; the
+// candidate queue overlays it later), then the root-search workspace
+constexpr int kPairFinishDoubles = (36 + 39) * 32;
+constexpr int kNisterPairDoubles = kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0) > 100 * 32
+                                       ? kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0)
+                                       : 100 * 32;
+
+// Two lanes per sample, balanced final stage (see balanced_finish).  LDS use after the constraint solve: the basis (36
+// doubles per sample) for the whole stage; B(z) (39 doubles per sample) only across the root search, where it would
+// otherwise occupy 78 registers -- the candidate queue reuses that space afterwards.
+template <typename T>
+__device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], const double (&X)[6][10], bool ok, double *lds, int lane,
+                                                   size_t s0, bool active, T *__restrict__ models, uint8_t *__restrict__ valid,
+                                                   double *__restrict__ models64) {
+  const FinishQueue fq(lds);
+  const int half = lane & 1;
+  park_basis(fq, nb, lane);
+  double cs[11];
+  double *bz = fq.q + (lane >> 1);   // B(z): element k of sample j at bz[k * 32]
+  {
+    double bx[3][4], by[3][4], b1[3][5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double(&hi)[10] = X[2 * r];
+      const double(&lo)[10] = X[2 * r + 1];
+      bx[r][0] = hi[2]; bx[r][1] = hi[1] - lo[2]; bx[r][2] = hi[0] - lo[1]; bx[r][3] = -lo[0];
+      by[r][0] = hi[5]; by[r][1] = hi[4] - lo[5]; by[r][2] = hi[3] - lo[4]; by[r][3] = -lo[3];
+      b1[r][0] = hi[9]; b1[r][1] = hi[8] - lo[9]; b1[r][2] = hi[7] - lo[8]; b1[r][3] = hi[6] - lo[7];
+      b1[r][4] = -lo[6];
+    }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) cs[i] = 0;
+    auto minor_acc = [&](int a, int b, int r, double sgn) {
+      double mn[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) mn[i] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mn[i + j] += bx[a][i] * by[b][j] - bx[b][i] * by[a][j];
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) cs[i + j] += sgn * mn[i] * b1[r][j];
+    };
+    minor_acc(1, 2, 0, 1.0);
+    minor_acc(0, 2, 1, -1.0);
+    minor_acc(0, 1, 2, 1.0);
+    if (half == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bz[(13 * r + i) * 32] = bx[r][i];
+          bz[(13 * r + 4 + i) * 32] = by[r][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) bz[(13 * r + 8 + i) * 32] = b1[r][i];
+      }
+    }
+  }
+  double roots[10];
+  int nroots;
+  DR_STAGE_BEGIN();
+#if DR_K3_WAVE_ROOTS
+  real_roots_half_wave<10>(cs, half != 0, roots, nroots, lds + kPairFinishDoubles, lane);
+#else
+  real_roots_half<10>(cs, half != 0, roots, nroots);
+#endif
+  DR_STAGE(3);
+  if (!ok || !active) nroots = 0;
+  double xs[10], ys[10];
+  unsigned cand = 0;
+  {
+    double bx[3][4], by[3][4], b1[3][5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bx[r][i] = bz[(13 * r + i) * 32];
+        by[r][i] = bz[(13 * r + 4 + i) * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) b1[r][i] = bz[(13 * r + 8 + i) * 32];
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      xs[i] = 0;
+      ys[i] = 0;
+      if (!__any(i < nroots)) continue;
+      const double z = roots[i];
+      // rows of B(z): (bx(z), by(z), b1(z)) . (x, y, 1) = 0 ; null vector = best-conditioned cross product
+      double rx[3], ry[3], r1[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        rx[r] = ((bx[r][3] * z + bx[r][2]) * z + bx[r][1]) * z + bx[r][0];
+        ry[r] = ((by[r][3] * z + by[r][2]) * z + by[r][1]) * z + by[r][0];
+        r1[r] = (((b1[r][4] * z + b1[r][3]) * z + b1[r][2]) * z + b1[r][1]) * z + b1[r][0];
+      }
+      double bestn = -1, vx = 0, vy = 0, vw = 1;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 3; ++b) {
+          const double cx = ry[a] * r1[b] - r1[a] * ry[b];
+          const double cy = r1[a] * rx[b] - rx[a] * r1[b];
+          const double cw = rx[a] * ry[b] - ry[a] * rx[b];
+          const double nn = cw * cw;  // we divide by the w component: pick the largest
+          if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
+        }
+      const double x = vx / vw, y = vy / vw;
+      xs[i] = x;
+      ys[i] = y;
+      if (is_finite(x) && is_finite(y)) cand |= 1u << i;
+    }
+  }
+  DR_STAGE(4);
+  balanced_finish<T>(fq, lane, nroots, xs, ys, roots, cand, s0, active, models, valid, models64);
 }
 
 }  // namespace dr

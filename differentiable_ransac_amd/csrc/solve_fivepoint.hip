@@ -11,6 +11,15 @@
 // -> Gauss-Newton polish on the defining constraints -> verification.
 #include "fivepoint_device.hpp"
 
+// waves per SIMD the minimal-sample kernels are compiled for (register budget = 512 / DR_K3_WAVES)
+#ifndef DR_K3_WAVES
+#define DR_K3_WAVES 1
+#endif
+// 1: the candidates of a wave are dealt out evenly over its lanes for the polish / verification stage (balanced_finish)
+#ifndef DR_K3_BALANCED
+#define DR_K3_BALANCED 1
+#endif
+
 namespace dr {
 
 template <typename T>
@@ -41,15 +50,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // Minimal samples, two lanes per sample (32 samples per 64-lane block).  At the benchmark size there are fewer samples
 // than SIMD lanes on the chip (32 768 vs 65 536), so the redundancy is free: both lanes build the same system (they even
-// share its LDS slot), then each runs ONE of the two root searches and finishes its own roots -- the longest serial
-// stage is cut in half.
+// share its LDS slot), then each owns ONE of the two root searches (|z| <= 1 / |z| > 1).  From there on the work is dealt
+// out over the wave instead of staying with its lane: brackets that hold a sign change (real_roots_half_wave: 1083 of the
+// 3520 bracket refinements a wave used to run) and candidate solutions (balanced_finish: ~150 per wave, 2.3 per lane,
+// where the busiest lane has 6-7).  Same arithmetic per bracket / candidate, so the output is bit-identical to the
+// per-lane version (-DDR_K3_BALANCED=0 -DDR_K3_WAVE_ROOTS=0); 105 -> 72 us at 32 pairs x 1024, 386 -> 265 us at 128 pairs.
 template <typename T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_pair_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void nister5_pair_kernel(
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models,
     uint8_t *__restrict__ valid, double *__restrict__ models64) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
-  const int half = lane & 1;
   const int s = blockIdx.x * 32 + (lane >> 1);
   const bool active = s < Bt;
   const int sc = active ? s : Bt - 1;
@@ -65,8 +76,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
   DR_STAGE(2);
-  nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, half,
+#if DR_K3_BALANCED
+  nister_finish_pair<T>(nb, X, ok, lds, lane, (size_t)blockIdx.x * 32, active, models, valid, models64);
+#else
+  nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, lane & 1,
                          models64 ? models64 + (size_t)sc * 90 : nullptr);
+#endif
   DR_STAGE(5);
 }
 
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // QR.  Everything after the constraint solve is statically indexed and lives in VGPRs; like the Nister kernel, two
 // lanes share one sample and each takes one half of the root search.
 template <typename T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_pair_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void stewenius5_pair_kernel(
     const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
@@ -178,7 +193,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   }
   double roots[10];
   int nroots;
+#if DR_K3_WAVE_ROOTS
+  real_roots_half_wave<10>(cs, half != 0, roots, nroots, lds, lane);   // the right block's LDS is free again
+#else
   real_roots_half<10>(cs, half != 0, roots, nroots);
+#endif
   if (!ok) nroots = 0;
 
   T *mdl = models + (size_t)sc * 90;
@@ -271,8 +290,9 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   if (n == 5) {
-    // minimal samples: two lanes per sample, 100 doubles of LDS per SAMPLE (25 KiB per block => six blocks per CU)
-    const size_t smem = sizeof(double) * 100 * 32;
+    // minimal samples: two lanes per sample; LDS per 32-sample block: 100 doubles per sample for the constraint solve,
+    // later basis + B(z) / candidate queue + root-search workspace (36.5 KiB => four blocks per CU, one per SIMD)
+    const size_t smem = sizeof(double) * (DR_K3_BALANCED ? kNisterPairDoubles : 100 * 32);
     hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, weights, Bt, models,
                        valid, models64);
     return check_launch("nister5_pair_kernel");

@@ -82,6 +82,22 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
 //     of width 2^(1-kBis); the five-point callers polish (x, y, z) on the defining constraints afterwards.
 // Replaces the per-sample companion-matrix eigvals of nister.py:361-370 / the Sturm recursion of math_utils.py.
 // ------------------------------------------------------------------------------------------------
+// DR_ROOT_F32_LOW = 1: the levels below the polynomial itself (which only provide the breakpoints between which the next
+// level looks for sign changes) run in f32 -- half the cycles per FMA and per select on gfx950.  A breakpoint y~ = y* + e
+// (y* a critical point of the next level's polynomial g, g'(y*) = 0) is used only through sign g(y~) = sign(g(y*) +
+// g''(y*) e^2 / 2): second order in e, so f32 breakpoints bracket the same roots unless two of them are closer than ~1e-6
+// (nearly a double root, where the f64 search is at the mercy of rounding as well).  The last level, which produces the
+// roots, is always f64.
+#ifndef DR_ROOT_F32_LOW
+#define DR_ROOT_F32_LOW 0
+#endif
+#ifndef DR_ROOT_BIS_LOW
+#define DR_ROOT_BIS_LOW 6
+#define DR_ROOT_NEWT_LOW 4
+#endif
+__device__ __forceinline__ double root_rcp(double v) { return __builtin_amdgcn_rcp(v); }
+__device__ __forceinline__ float root_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+
 template <int D, int kBisLast, int kNewtLast>
 __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (&x)[D], unsigned &mask, double tail_tol) {
   double pts[D + 1];
@@ -89,9 +105,10 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
   for (int i = 0; i <= D; ++i) pts[i] = 1.0;
   pts[0] = -1.0;
   mask = 0;
-#pragma unroll
-  for (int d = 1; d <= D; ++d) {
-    double q[D + 1];  // q = p^(D-d): degree d, ascending
+  // one level: F = arithmetic type of the level, d = degree (a constant after unrolling)
+  auto level = [&](auto tag, const int d) {
+    using F = decltype(tag);
+    F q[D + 1];  // q = p^(D-d): degree d, ascending
 #pragma unroll
     for (int i = 0; i <= D; ++i) q[i] = 0;
 #pragma unroll
@@ -99,15 +116,15 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
       double f = 1;
 #pragma unroll
       for (int t = 0; t < D - d; ++t) f *= (double)(i + D - d - t);
-      q[i] = c[i + D - d] * f;
+      q[i] = (F)(c[i + D - d] * f);
     }
-    auto evalf = [&](double t) {
-      double fx = q[d];
+    auto evalf = [&](F t) {
+      F fx = q[d];
 #pragma unroll
       for (int i = d - 1; i >= 0; --i) fx = fx * t + q[i];
       return fx;
     };
-    auto eval2 = [&](double t, double &fx, double &dfx) {
+    auto eval2 = [&](F t, F &fx, F &dfx) {
       fx = q[d];
       dfx = 0;
 #pragma unroll
@@ -116,23 +133,22 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
         fx = fx * t + q[i];
       }
     };
-    double a[D], b[D], y[D];
+    F a[D], b[D], y[D];
     bool neg_a[D];
     unsigned has = 0;
-    double fprev = evalf(pts[0]);
+    F fprev = evalf((F)pts[0]);
 #pragma unroll
     for (int i = 0; i < d; ++i) {
-      const double lo = pts[i], hi = (i == d - 1) ? 1.0 : pts[i + 1];
-      const double fhi = evalf(hi);
+      const F lo = (F)pts[i], hi = (i == d - 1) ? (F)1 : (F)pts[i + 1];
+      const F fhi = evalf(hi);
       if (((fprev < 0) != (fhi < 0)) && (hi > lo)) has |= 1u << i;
       a[i] = lo;
       b[i] = hi;
       neg_a[i] = fprev < 0;
       fprev = fhi;
     }
-#ifndef DR_ROOT_BIS_LOW
-#define DR_ROOT_BIS_LOW 6
-#define DR_ROOT_NEWT_LOW 4
+#ifdef DR_PROFILE_STAGES
+    if (D == 10) atomicAdd(&::dr::g_stage_cycles[5 + d], (unsigned long long)__popc(has));   // brackets with a sign change, per level
 #endif
     const int kBis = (d == D) ? kBisLast : DR_ROOT_BIS_LOW;
     const int kNewt = (d == D) ? kNewtLast : DR_ROOT_NEWT_LOW;
@@ -140,26 +156,26 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
     for (int it = 0; it < kBis; ++it) {
 #pragma unroll
       for (int i = 0; i < d; ++i) {
-        const double m = 0.5 * (a[i] + b[i]);
+        const F m = (F)0.5 * (a[i] + b[i]);
         const bool left = (evalf(m) < 0) == neg_a[i];
         a[i] = left ? m : a[i];
         b[i] = left ? b[i] : m;
       }
     }
 #pragma unroll
-    for (int i = 0; i < d; ++i) y[i] = 0.5 * (a[i] + b[i]);
+    for (int i = 0; i < d; ++i) y[i] = (F)0.5 * (a[i] + b[i]);
 #pragma unroll 1
     for (int it = 0; it < kNewt; ++it) {
 #pragma unroll
       for (int i = 0; i < d; ++i) {
-        double fx, dfx;
+        F fx, dfx;
         eval2(y[i], fx, dfx);
         const bool left = (fx < 0) == neg_a[i];
         a[i] = left ? y[i] : a[i];
         b[i] = left ? b[i] : y[i];
-        double yn = y[i] - fx * __builtin_amdgcn_rcp(dfx);
-        if (!(yn > a[i] && yn < b[i])) yn = 0.5 * (a[i] + b[i]);
-        y[i] = (fx == 0.0) ? y[i] : yn;
+        F yn = y[i] - fx * root_rcp(dfx);
+        if (!(yn > a[i] && yn < b[i])) yn = (F)0.5 * (a[i] + b[i]);
+        y[i] = (fx == 0) ? y[i] : yn;
       }
     }
     if (d == D && tail_tol > 0) {
@@ -167,44 +183,51 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
       // bring below `tail_tol` keep alternating safeguarded Newton / bisection.  The five-point solvers skip this --
       // over 64 samples x 10 brackets some bracket is always slow and the whole wave would wait for it; their roots
       // are refined by the Gauss-Newton polish on the defining constraints instead, which is well conditioned.
-      const double tol = tail_tol;
+      const F tol = (F)tail_tol;
       unsigned live = 0;
 #pragma unroll
       for (int i = 0; i < d; ++i) {
-        double fx, dfx;
+        F fx, dfx;
         eval2(y[i], fx, dfx);
-        const double step = fabs(fx * __builtin_amdgcn_rcp(dfx));
-        if (((has >> i) & 1u) && !(step <= tol * (1.0 + fabs(y[i]))) && (b[i] - a[i]) > tol) live |= 1u << i;
+        const F step = fabs(fx * root_rcp(dfx));
+        if (((has >> i) & 1u) && !(step <= tol * ((F)1 + fabs(y[i]))) && (b[i] - a[i]) > tol) live |= 1u << i;
       }
       for (int it = 0; it < 100 && __any(live != 0); ++it) {
 #pragma unroll
         for (int i = 0; i < d; ++i) {
           if (!((live >> i) & 1u)) continue;
-          double fx, dfx;
+          F fx, dfx;
           eval2(y[i], fx, dfx);
           const bool left = (fx < 0) == neg_a[i];
           a[i] = left ? y[i] : a[i];
           b[i] = left ? b[i] : y[i];
-          double yn = y[i] - fx / dfx;
-          if (!(yn > a[i] && yn < b[i]) || (it & 1)) yn = 0.5 * (a[i] + b[i]);
-          const double dx = fabs(yn - y[i]);
+          F yn = y[i] - fx / dfx;
+          if (!(yn > a[i] && yn < b[i]) || (it & 1)) yn = (F)0.5 * (a[i] + b[i]);
+          const F dx = fabs(yn - y[i]);
           y[i] = yn;
-          if (dx <= tol * (1.0 + fabs(yn)) || fx == 0.0 || (b[i] - a[i]) <= tol * (1.0 + fabs(yn))) live &= ~(1u << i);
+          if (dx <= tol * ((F)1 + fabs(yn)) || fx == 0 || (b[i] - a[i]) <= tol * ((F)1 + fabs(yn))) live &= ~(1u << i);
         }
       }
     }
+    // breakpoints of the next level (kept in double so that an empty bracket's right end stays exact)
+    double nxt[D];
 #pragma unroll
     for (int i = 0; i < d; ++i) {
       const double hi = (i == d - 1) ? 1.0 : pts[i + 1];
-      y[i] = ((has >> i) & 1u) ? y[i] : hi;
+      nxt[i] = ((has >> i) & 1u) ? (double)y[i] : hi;
     }
 #pragma unroll
-    for (int i = 0; i < d; ++i) pts[i + 1] = y[i];
+    for (int i = 0; i < d; ++i) pts[i + 1] = nxt[i];
     if (d == D) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) x[i] = y[i];
+      for (int i = 0; i < D; ++i) x[i] = nxt[i];
       mask = has;
     }
+  };
+#pragma unroll
+  for (int d = 1; d <= D; ++d) {
+    if (DR_ROOT_F32_LOW && d < D) level(float{}, d);
+    else level(double{}, d);
   }
 }
 
@@ -239,6 +262,187 @@ __device__ __forceinline__ void real_roots_half(const double (&c)[D + 1], bool o
   for (int k = 0; k < D; ++k) {
     const double v = outer ? 1.0 / x[k] : x[k];
     const bool take = ((mk >> k) & 1u) && (!outer || (fabs(x[k]) > 1e-9 && fabs(x[k]) < 1.0));
+    if (take) {
+#pragma unroll
+      for (int t = 0; t < D; ++t) roots[t] = (t == count) ? v : roots[t];
+    }
+    count += take ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same search, organised per WAVE instead of per lane (blocks of exactly one wave; LDS workspace `RootWs`).
+// roots_in_unit refines all d brackets of level d in every lane, although on the five-point polynomials only 0.6 (level 1)
+// to 2.3 (levels 8-10) of them hold a sign change: 3520 bracket refinements per wave, 1083 of them useful.  Here a lane
+// only evaluates its level's polynomial at its breakpoints (d (d + 1) FMAs); the brackets that do change sign become
+// tasks (source lane, bracket) in an LDS queue and the 64 lanes take them R at a time (R interleaved tasks per lane hide
+// the f64 FMA latency the d brackets of the per-lane version used to hide): 1-3 rounds per level instead of d.  A task
+// gathers its source lane's coefficients and bracket ends from LDS, runs the SAME bisection / Newton schedule on them as
+// roots_in_unit (so the results are bit-identical) and writes the root into the source lane's breakpoint list of the
+// next level (double-buffered: tasks of one level must all see the old breakpoints).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct RootWs {
+  double *pts[2];    // (D + 1) x 64 each: breakpoint i of lane l at [i * 64 + l]
+  double *q;         // (D + 1) x 64: coefficient i of lane l's current polynomial
+  uint16_t *queue;   // D x 64 tasks: source lane | bracket << 6 | (sign at the left end) << 10
+  static constexpr int kDoubles = 3 * (D + 1) * 64 + (D * 64 + 3) / 4;
+  __device__ __forceinline__ explicit RootWs(double *ws)
+      : pts{ws, ws + (D + 1) * 64}, q(ws + 2 * (D + 1) * 64), queue(reinterpret_cast<uint16_t *>(ws + 3 * (D + 1) * 64)) {}
+};
+
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int D, int d, int R>
+__device__ __forceinline__ void root_tasks(const RootWs<D> &ws, const double *__restrict__ cur, double *__restrict__ nxt, int total, int lane,
+                                           int kBis, int kNewt) {
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64 * R) {
+    double a[R], b[R], y[R], qq[R][d + 1];
+    bool neg[R], val[R];
+    int dst[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int t = base + 64 * r + lane;
+      val[r] = t < total;
+      const unsigned m = ws.queue[val[r] ? t : base];
+      const int src = m & 63, i = (m >> 6) & 15;
+      neg[r] = (m >> 10) & 1u;
+      a[r] = cur[i * 64 + src];
+      b[r] = cur[(i + 1) * 64 + src];
+      dst[r] = (i + 1) * 64 + src;
+#pragma unroll
+      for (int k = 0; k <= d; ++k) qq[r][k] = ws.q[k * 64 + src];
+    }
+#pragma unroll 1
+    for (int it = 0; it < kBis; ++it) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double m = 0.5 * (a[r] + b[r]);
+        double fx = qq[r][d];
+#pragma unroll
+        for (int k = d - 1; k >= 0; --k) fx = fx * m + qq[r][k];
+        const bool left = (fx < 0) == neg[r];
+        a[r] = left ? m : a[r];
+        b[r] = left ? b[r] : m;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r] = 0.5 * (a[r] + b[r]);
+#pragma unroll 1
+    for (int it = 0; it < kNewt; ++it) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double fx = qq[r][d], dfx = 0;
+#pragma unroll
+        for (int k = d - 1; k >= 0; --k) {
+          dfx = dfx * y[r] + fx;
+          fx = fx * y[r] + qq[r][k];
+        }
+        const bool left = (fx < 0) == neg[r];
+        a[r] = left ? y[r] : a[r];
+        b[r] = left ? b[r] : y[r];
+        double yn = y[r] - fx * __builtin_amdgcn_rcp(dfx);
+        if (!(yn > a[r] && yn < b[r])) yn = 0.5 * (a[r] + b[r]);
+        y[r] = (fx == 0.0) ? y[r] : yn;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (val[r]) nxt[dst[r]] = y[r];
+  }
+}
+
+template <int D, int d, int kBisLast, int kNewtLast>
+__device__ __forceinline__ void root_levels_wave(const double (&c)[D + 1], const RootWs<D> &ws, int lane, unsigned &mask) {
+  const double *cur = ws.pts[(d - 1) & 1];
+  double *nxt = ws.pts[d & 1];
+  double q[d + 1];  // q = p^(D-d): degree d, ascending
+#pragma unroll
+  for (int i = 0; i <= d; ++i) {
+    double f = 1;
+#pragma unroll
+    for (int t = 0; t < D - d; ++t) f *= (double)(i + D - d - t);
+    q[i] = c[i + D - d] * f;
+    ws.q[i * 64 + lane] = q[i];
+  }
+  auto evalf = [&](double t) {
+    double fx = q[d];
+#pragma unroll
+    for (int i = d - 1; i >= 0; --i) fx = fx * t + q[i];
+    return fx;
+  };
+  double p[d + 1];
+#pragma unroll
+  for (int i = 0; i <= d; ++i) p[i] = cur[i * 64 + lane];
+  // an empty bracket hands its right end to the next level: that is the old breakpoint itself (or the interval's end)
+#pragma unroll
+  for (int i = 1; i < d; ++i) nxt[i * 64 + lane] = p[i];
+  unsigned has = 0;
+  int offs = 0;
+  double fprev = evalf(p[0]);
+#pragma unroll
+  for (int i = 0; i < d; ++i) {
+    const double lo = p[i], hi = (i == d - 1) ? 1.0 : p[i + 1];
+    const double fhi = evalf(hi);
+    const bool h = ((fprev < 0) != (fhi < 0)) && (hi > lo);
+    const unsigned long long bm = __ballot(h);
+    const int pos = offs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+    if (h) {
+      has |= 1u << i;
+      ws.queue[pos] = (uint16_t)(lane | (i << 6) | ((fprev < 0) ? 1 << 10 : 0));
+    }
+    offs += __popcll(bm);
+    fprev = fhi;
+  }
+  wave_lds_order();
+  const int kBis = (d == D) ? kBisLast : DR_ROOT_BIS_LOW;
+  const int kNewt = (d == D) ? kNewtLast : DR_ROOT_NEWT_LOW;
+  if (offs <= 64) root_tasks<D, d, 1>(ws, cur, nxt, offs, lane, kBis, kNewt);
+  else if (offs <= 128) root_tasks<D, d, 2>(ws, cur, nxt, offs, lane, kBis, kNewt);
+  else root_tasks<D, d, 3>(ws, cur, nxt, offs, lane, kBis, kNewt);
+  wave_lds_order();
+  if constexpr (d < D) root_levels_wave<D, d + 1, kBisLast, kNewtLast>(c, ws, lane, mask);
+  else mask = has;
+}
+
+// wave-cooperative real_roots_half: every lane of the (single-wave) block must call it
+template <int D, int kBisLast = DR_ROOT_BIS_LAST, int kNewtLast = DR_ROOT_NEWT_LAST>
+__device__ __forceinline__ void real_roots_half_wave(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count, double *lds_ws,
+                                                     int lane) {
+  const RootWs<D> ws(lds_ws);
+  double cmax = 0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
+  const bool ok = is_finite(cmax) && cmax > 0;
+  const double sc = ok ? 1.0 / cmax : 0.0;
+  double ch[D + 1];
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    const double a = ok ? c[i] * sc : (i == 0 ? 1.0 : 0.0);
+    const double b = ok ? c[D - i] * sc : (i == 0 ? 1.0 : 0.0);
+    ch[i] = outer ? b : a;
+  }
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    ws.pts[0][i * 64 + lane] = i == 0 ? -1.0 : 1.0;
+    ws.pts[1][i * 64 + lane] = i == 0 ? -1.0 : 1.0;
+  }
+  unsigned mk;
+  root_levels_wave<D, 1, kBisLast, kNewtLast>(ch, ws, lane, mk);
+  if (!ok) mk = 0;
+  const double *res = ws.pts[D & 1];
+  count = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) roots[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double xk = res[(k + 1) * 64 + lane];
+    const double v = outer ? 1.0 / xk : xk;
+    const bool take = ((mk >> k) & 1u) && (!outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0));
     if (take) {
 #pragma unroll
       for (int t = 0; t < D; ++t) roots[t] = (t == count) ? v : roots[t];
