@@ -106,103 +106,111 @@ __device__ __forceinline__ void essential_residual(const double (&E)[9], double 
 // `tol2`: squared residual norm at which a sample stops iterating -- 1e-28 for f64 output (rounding level of the
 // unit-norm E; 1e-24 is not measurably faster), 1e-17 for f32 output (E to 3e-9, below the f32 rounding that follows;
 // usually ONE Gauss-Newton step: K3 119.6 -> 106.3 us at C2 x 32 pairs).
+// one Gauss-Newton step from u: un = the normalised new vector, n0 / n1 = squared residual norms before / after
+__device__ __forceinline__ void polish_step(const double (&nb)[4][9], const double (&u)[4], double (&un)[4], double &n0_out, double &n1_out) {
+  double E[9], r[10];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
+  essential_residual(E, r);
+  double n0 = 0;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
+  double J[4][10];
+  double EEt[9], EtE[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx) {
+      EEt[3 * i + jx] = E[3 * i] * E[3 * jx] + E[3 * i + 1] * E[3 * jx + 1] + E[3 * i + 2] * E[3 * jx + 2];
+      EtE[3 * i + jx] = E[i] * E[jx] + E[3 + i] * E[3 + jx] + E[6 + i] * E[6 + jx];
+    }
+  const double tr = EEt[0] + EEt[4] + EEt[8];
+  const double cof[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
+                         E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
+                         E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double(&H)[9] = nb[k];
+    double HEt[9];
+    double trEHt = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx)
+        HEt[3 * i + jx] = H[3 * i] * E[3 * jx] + H[3 * i + 1] * E[3 * jx + 1] + H[3 * i + 2] * E[3 * jx + 2];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) trEHt += E[q] * H[q];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        const double t1 = H[3 * i] * EtE[jx] + H[3 * i + 1] * EtE[3 + jx] + H[3 * i + 2] * EtE[6 + jx];     // H E^T E
+        const double t2 = HEt[i] * E[jx] + HEt[3 + i] * E[3 + jx] + HEt[6 + i] * E[6 + jx];                  // E H^T E
+        const double t3 = EEt[3 * i] * H[jx] + EEt[3 * i + 1] * H[3 + jx] + EEt[3 * i + 2] * H[6 + jx];     // E E^T H
+        J[k][3 * i + jx] = 2.0 * (t1 + t2 + t3) - 2.0 * trEHt * E[3 * i + jx] - tr * H[3 * i + jx];
+      }
+    double dd = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
+    J[k][9] = dd;
+  }
+  // (J^T J + u u^T) d = J^T r : 4x4 SPD, LDL^T without pivoting
+  double a[4][4], g[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    g[i] = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) g[i] += J[i][q] * r[q];
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+      double acc = u[i] * u[jx];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) acc += J[i][q] * J[jx][q];
+      a[i][jx] = acc;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double inv = 1.0 / a[c][c];
+#pragma unroll
+    for (int rr = c + 1; rr < 4; ++rr) {
+      const double f = a[rr][c] * inv;
+#pragma unroll
+      for (int k = c; k < 4; ++k) a[rr][k] -= f * a[c][k];
+      g[rr] -= f * g[c];
+    }
+  }
+  double d[4];
+#pragma unroll
+  for (int c = 3; c >= 0; --c) {
+    double acc = g[c];
+#pragma unroll
+    for (int k = c + 1; k < 4; ++k) acc -= a[c][k] * d[k];
+    d[c] = acc / a[c][c];
+  }
+  double nn = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { un[k] = u[k] - d[k]; nn += un[k] * un[k]; }
+  const double sc = 1.0 / sqrt(nn);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) un[k] *= sc;
+  double E2[9], r2[10], n1 = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) E2[q] = un[0] * nb[0][q] + un[1] * nb[1][q] + un[2] * nb[2][q] + un[3] * nb[3][q];
+  essential_residual(E2, r2);
+#pragma unroll
+  for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
+  n0_out = n0;
+  n1_out = n1;
+}
+
 __device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&u)[4], bool live, double tol2) {
   // one iteration for everybody, then only waves that still hold an unconverged sample go on (max 8)
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     if (it >= 1 && !__any(live)) break;
-    double E[9], r[10];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
-    essential_residual(E, r);
-    double n0 = 0;
-#pragma unroll
-    for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
-    double J[4][10];
-    double EEt[9], EtE[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int jx = 0; jx < 3; ++jx) {
-        EEt[3 * i + jx] = E[3 * i] * E[3 * jx] + E[3 * i + 1] * E[3 * jx + 1] + E[3 * i + 2] * E[3 * jx + 2];
-        EtE[3 * i + jx] = E[i] * E[jx] + E[3 + i] * E[3 + jx] + E[6 + i] * E[6 + jx];
-      }
-    const double tr = EEt[0] + EEt[4] + EEt[8];
-    const double cof[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
-                           E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
-                           E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double(&H)[9] = nb[k];
-      double HEt[9];
-      double trEHt = 0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int jx = 0; jx < 3; ++jx)
-          HEt[3 * i + jx] = H[3 * i] * E[3 * jx] + H[3 * i + 1] * E[3 * jx + 1] + H[3 * i + 2] * E[3 * jx + 2];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) trEHt += E[q] * H[q];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int jx = 0; jx < 3; ++jx) {
-          const double t1 = H[3 * i] * EtE[jx] + H[3 * i + 1] * EtE[3 + jx] + H[3 * i + 2] * EtE[6 + jx];     // H E^T E
-          const double t2 = HEt[i] * E[jx] + HEt[3 + i] * E[3 + jx] + HEt[6 + i] * E[6 + jx];                  // E H^T E
-          const double t3 = EEt[3 * i] * H[jx] + EEt[3 * i + 1] * H[3 + jx] + EEt[3 * i + 2] * H[6 + jx];     // E E^T H
-          J[k][3 * i + jx] = 2.0 * (t1 + t2 + t3) - 2.0 * trEHt * E[3 * i + jx] - tr * H[3 * i + jx];
-        }
-      double dd = 0;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
-      J[k][9] = dd;
-    }
-    // (J^T J + u u^T) d = J^T r : 4x4 SPD, LDL^T without pivoting
-    double a[4][4], g[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      g[i] = 0;
-#pragma unroll
-      for (int q = 0; q < 10; ++q) g[i] += J[i][q] * r[q];
-#pragma unroll
-      for (int jx = 0; jx < 4; ++jx) {
-        double acc = u[i] * u[jx];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) acc += J[i][q] * J[jx][q];
-        a[i][jx] = acc;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double inv = 1.0 / a[c][c];
-#pragma unroll
-      for (int rr = c + 1; rr < 4; ++rr) {
-        const double f = a[rr][c] * inv;
-#pragma unroll
-        for (int k = c; k < 4; ++k) a[rr][k] -= f * a[c][k];
-        g[rr] -= f * g[c];
-      }
-    }
-    double d[4];
-#pragma unroll
-    for (int c = 3; c >= 0; --c) {
-      double acc = g[c];
-#pragma unroll
-      for (int k = c + 1; k < 4; ++k) acc -= a[c][k] * d[k];
-      d[c] = acc / a[c][c];
-    }
-    double un[4], nn = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { un[k] = u[k] - d[k]; nn += un[k] * un[k]; }
-    const double sc = 1.0 / sqrt(nn);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) un[k] *= sc;
-    double E2[9], r2[10], n1 = 0;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) E2[q] = un[0] * nb[0][q] + un[1] * nb[1][q] + un[2] * nb[2][q] + un[3] * nb[3][q];
-    essential_residual(E2, r2);
-#pragma unroll
-    for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
+    double un[4], n0, n1;
+    polish_step(nb, u, un, n0, n1);
     const bool better = n1 <= n0 && is_finite(n1);
     if (better && (live || it < 1)) {
 #pragma unroll
@@ -271,10 +279,19 @@ struct FinishQueue {
   double *q;         // 3 x 320 doubles: x | y | z of the candidates
   uint16_t *meta;    // 320: source lane | candidate flag << 6
   int *cnt;          // 64: verified solutions so far of (sample, half) = source lane
-  static constexpr int kDoubles = 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2;
+  double *u;         // 4 x 320: the candidates' current coefficient vectors
+  uint16_t *live;    // 2 x 320: candidates that need another Gauss-Newton step (this round | next round)
+  static constexpr int kDoubles = 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2 + 4 * 320 + 2 * 320 / 4;
   __device__ __forceinline__ explicit FinishQueue(double *lds)
       : nb_lds(lds), q(lds + 36 * 32), meta(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 3 * 320)),
-        cnt(reinterpret_cast<int *>(lds + 36 * 32 + 3 * 320 + 320 / 4)) {}
+        cnt(reinterpret_cast<int *>(lds + 36 * 32 + 3 * 320 + 320 / 4)), u(lds + 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2),
+        live(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2 + 4 * 320)) {}
+  __device__ __forceinline__ void load_basis(int j, double (&nb)[4][9]) const {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int qq = 0; qq < 9; ++qq) nb[t][qq] = nb_lds[(9 * t + qq) * 32 + j];
+  }
 };
 
 __device__ __forceinline__ void park_basis(const FinishQueue &fq, const double (&nb)[4][9], int lane) {
@@ -288,6 +305,10 @@ __device__ __forceinline__ void park_basis(const FinishQueue &fq, const double (
 
 // xs/ys/zs[0..n-1]: this lane's candidates (dense), cand: bit i = candidate i is finite / solvable.  s0 = first sample of
 // the block.  Lanes of samples >= Bt pass n = 0.
+// Three phases, each 64 candidates at a time: (A) the first Gauss-Newton step of every candidate; (B) further steps for
+// the candidates that are not yet at the stopping tolerance -- they go through a second, much shorter queue, so a slow
+// candidate does not hold 63 finished ones (per candidate the sequence of steps is exactly polish_homog's); (C)
+// verification, rank, store.
 template <typename T>
 __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane, int n, const double (&xs)[10], const double (&ys)[10],
                                                 const double (&zs)[10], unsigned cand, size_t s0, bool active,
@@ -311,7 +332,13 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     }
   }
   fq.cnt[lane] = 0;
+  wave_lds_order();
   const double tol2 = (sizeof(T) == 4 && !models64) ? 1e-17 : 1e-28;
+  auto mbcnt = [](unsigned long long bm) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+  };
+  // ---- (A) first step
+  int nlive = 0;
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int e = base + lane;
@@ -319,16 +346,74 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     const int ec = has ? e : total - 1;
     const double x = fq.q[ec], y = fq.q[320 + ec], z = fq.q[640 + ec];
     const unsigned m = fq.meta[ec];
+    double nb[4][9];
+    fq.load_basis((m & 63) >> 1, nb);
+    const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+    double u[4] = {x * inv, y * inv, z * inv, inv};
+    const bool good = has && ((m >> 6) & 1u) && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
+    if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
+    double un[4], n0, n1;
+    polish_step(nb, u, un, n0, n1);
+    const bool better = n1 <= n0 && is_finite(n1);
+    const bool lv = good && better && (n1 > tol2) && (n1 < 0.25 * n0);
+    if (has) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fq.u[k * 320 + e] = better ? un[k] : u[k];
+      fq.meta[e] = (uint16_t)((m & 63) | (good ? 1u << 6 : 0u));   // bit 6 from here on: finite candidate
+    }
+    const unsigned long long bm = __ballot(lv);
+    if (lv) fq.live[nlive + mbcnt(bm)] = (uint16_t)e;
+    nlive += __popcll(bm);
+  }
+  wave_lds_order();
+  // ---- (B) steps 2..8 of the candidates that asked for them
+#pragma unroll 1
+  for (int it = 1; it < 8 && nlive > 0; ++it) {
+    const uint16_t *cur = fq.live + 320 * ((it - 1) & 1);
+    uint16_t *nxt = fq.live + 320 * (it & 1);
+    int nnext = 0;
+#pragma unroll 1
+    for (int base = 0; base < nlive; base += 64) {
+      const bool has = base + lane < nlive;
+      const int e = cur[has ? base + lane : base];
+      double nb[4][9], u[4], un[4], n0, n1;
+      fq.load_basis((fq.meta[e] & 63) >> 1, nb);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = fq.u[k * 320 + e];
+      polish_step(nb, u, un, n0, n1);
+      const bool better = n1 <= n0 && is_finite(n1);
+      if (has && better) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fq.u[k * 320 + e] = un[k];
+      }
+      const bool lv = has && better && (n1 > tol2) && (n1 < 0.25 * n0);
+      const unsigned long long bm = __ballot(lv);
+      if (lv) nxt[nnext + mbcnt(bm)] = (uint16_t)e;
+      nnext += __popcll(bm);
+    }
+    nlive = nnext;
+    wave_lds_order();
+  }
+  // ---- (C) verification of the ten constraints, rank among the verified candidates of the same source lane, store
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    const bool has = e < total;
+    const int ec = has ? e : total - 1;
+    const unsigned m = fq.meta[ec];
     const int src = m & 63;
     const int j = src >> 1;
-    double nb[4][9];
+    double nb[4][9], u[4], E[9], r[10];
+    fq.load_basis(j, nb);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int k = 0; k < 4; ++k) u[k] = fq.u[k * 320 + ec];
 #pragma unroll
-      for (int qq = 0; qq < 9; ++qq) nb[t][qq] = fq.nb_lds[(9 * t + qq) * 32 + j];
-    double E[9];
-    const bool good = finish_core(nb, x, y, z, has && ((m >> 6) & 1u), tol2, E);
-    // rank among the verified candidates of the same source lane
+    for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
+    essential_residual(E, r);
+    double rn = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) rn += r[q] * r[q];
+    const bool good = has && ((m >> 6) & 1u) && is_finite(rn) && rn <= 1e-14;
     const int gid = has ? src : 64 + lane;
     const int prev = __shfl_up(gid, 1, 64);
     const bool is_start = lane == 0 || prev != gid;
@@ -466,9 +551,9 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
 // LDS doubles per 32-sample block of the two-lanes-per-sample Nister kernel: basis (36 x 32) + B(z) (39 x 32; the
 // candidate queue overlays it later), then the root-search workspace
 constexpr int kPairFinishDoubles = (36 + 39) * 32;
-constexpr int kNisterPairDoubles = kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0) > 100 * 32
-                                       ? kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0)
-                                       : 100 * 32;
+constexpr int kmax(int a, int b) { return a > b ? a : b; }
+constexpr int kNisterPairDoubles =
+    kmax(100 * 32, kmax(FinishQueue::kDoubles, kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0)));
 
 // Two lanes per sample, balanced final stage (see balanced_finish).  LDS use after the constraint solve: the basis (36
 // doubles per sample) for the whole stage; B(z) (39 doubles per sample) only across the root search, where it would

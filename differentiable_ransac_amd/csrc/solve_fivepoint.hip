@@ -200,11 +200,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
 #endif
   if (!ok) nroots = 0;
 
+#if DR_K3_BALANCED
+  // eigenvector of every root per lane (cheap), then polish / verification dealt out over the wave (balanced_finish)
+  if (!active) nroots = 0;
+  const FinishQueue fq(lds);   // the root-search workspace is dead: basis, candidate queue and vectors take its place
+  park_basis(fq, nb, lane);
+  double xs[10], ys[10], zs[10];
+  unsigned cand = 0;
+#else
   T *mdl = models + (size_t)sc * 90;
   uint8_t *vld = valid + (size_t)sc * 10;
   int slot = 0;
+#endif
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
+#if DR_K3_BALANCED
+    xs[i] = 0; ys[i] = 0; zs[i] = 0;
+#endif
     if (!__any(i < nroots)) continue;
     const bool has = i < nroots;
     const double lam = roots[i];
@@ -262,6 +274,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
       u[c] = acc / K[c][c];
     }
     const double x = -lam, y = u[3], z = u[4];
+#if DR_K3_BALANCED
+    xs[i] = x; ys[i] = y; zs[i] = z;
+    if (has && solvable && is_finite(y) && is_finite(z)) cand |= 1u << i;
+  }
+  balanced_finish<T>(fq, lane, nroots, xs, ys, zs, cand, (size_t)blockIdx.x * 32, active, models, valid, nullptr);
+#else
     const int dst_slot = half ? 9 - slot : slot;
     const bool good = finish_solution<T>(nb, x, y, z, has && solvable && is_finite(y) && is_finite(z) && slot < 10,
                                          mdl + 9 * dst_slot, active);
@@ -276,6 +294,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
       vld[q] = 0;
     }
   }
+#endif
 }
 
 template <typename T>
@@ -306,7 +325,10 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
 
 template <typename T>
 int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st) {
-  const size_t smem = sizeof(double) * 100 * 32;   // the right 10x10 block of 32 samples
+  // the right 10x10 block of 32 samples, later the root-search workspace, then the candidate queue
+  constexpr int kDoubles = (DR_K3_BALANCED && FinishQueue::kDoubles > 100 * 32) ? FinishQueue::kDoubles : 100 * 32;
+  static_assert(!DR_K3_WAVE_ROOTS || RootWs<10>::kDoubles <= kDoubles, "root-search workspace");
+  const size_t smem = sizeof(double) * kDoubles;
   hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, Bt, models, valid);
   return check_launch("stewenius5_pair_kernel");
 }

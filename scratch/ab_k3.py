@@ -4,7 +4,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-variants = {'wave': [], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
+variants = {'wave': [], 'wave_v1': [], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
             'old': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVE_ROOTS=0'], 'old_w2': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVES=2'], 'bal': [], 'bal_w2': ['-DDR_K3_WAVES=2'],
             'old_prof': ['-DDR_K3_BALANCED=0', '-DDR_PROFILE_STAGES'], 'bal_prof': ['-DDR_PROFILE_STAGES'],
             'f32low': ['-DDR_ROOT_F32_LOW=1'], 'f32low_w2': ['-DDR_ROOT_F32_LOW=1', '-DDR_K3_WAVES=2'], 'f32low_prof': ['-DDR_ROOT_F32_LOW=1', '-DDR_PROFILE_STAGES']}
