@@ -162,11 +162,12 @@ __device__ __forceinline__ void polish_step(const double (&nb)[4][9], const doub
 #pragma unroll
     for (int q = 0; q < 10; ++q) g[i] += J[i][q] * r[q];
 #pragma unroll
-    for (int jx = 0; jx < 4; ++jx) {
+    for (int jx = i; jx < 4; ++jx) {   // symmetric, also in floating point (same products, same order)
       double acc = u[i] * u[jx];
 #pragma unroll
       for (int q = 0; q < 10; ++q) acc += J[i][q] * J[jx][q];
       a[i][jx] = acc;
+      a[jx][i] = acc;
     }
   }
 #pragma unroll

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
   double e[3][3][4];
   basis_to_entries(nb, e);
   double X[6][10];
-  const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
+  const bool ok = constraints_reduce<NisterOrder, 4, DR_K3_BALANCED != 0>(e, w, 1.0, X, lane & 1);
   DR_STAGE(2);
 #if DR_K3_BALANCED
   nister_finish_pair<T>(nb, X, ok, lds, lane, (size_t)blockIdx.x * 32, active, models, valid, models64);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
     double e[3][3][4];
     basis_to_entries(nb, e);
     double X[10][10];
-    ok = constraints_reduce<GrevlexOrder, 0>(e, w, 2.0, X);
+    ok = constraints_reduce<GrevlexOrder, 0, DR_K3_BALANCED != 0>(e, w, 2.0, X, half);
     const int src[6] = {0, 1, 2, 4, 5, 7};
 #pragma unroll
     for (int r = 0; r < 6; ++r)

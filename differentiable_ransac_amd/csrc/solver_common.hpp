@@ -18,6 +18,12 @@ struct LaneWs {
   __device__ __forceinline__ double &operator[](int e) const { return base[e * stride]; }
 };
 
+// orders the LDS traffic of a single-wave block (compiler-level: the hardware executes a wave's LDS instructions in order)
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double dsign(double a, double b) { return b >= 0 ? fabs(a) : -fabs(a); }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,21 +286,26 @@ __device__ __forceinline__ void real_roots_half(const double (&c)[D + 1], bool o
 // gathers its source lane's coefficients and bracket ends from LDS, runs the SAME bisection / Newton schedule on them as
 // roots_in_unit (so the results are bit-identical) and writes the root into the source lane's breakpoint list of the
 // next level (double-buffered: tasks of one level must all see the old breakpoints).
+// (Evaluating a task's polynomial as even + odd part in t^2 -- two chains of half the length -- is not faster, 73.4 vs
+// 72.6 us, and not bit-identical: dropped.  Measured f64 FMA on gfx950: 5.1 clk issue, 8.5 clk dependent issue.)
 // ------------------------------------------------------------------------------------------------
 template <int D>
 struct RootWs {
   double *pts[2];    // (D + 1) x 64 each: breakpoint i of lane l at [i * 64 + l]
   double *q;         // (D + 1) x 64: coefficient i of lane l's current polynomial
   uint16_t *queue;   // D x 64 tasks: source lane | bracket << 6 | (sign at the left end) << 10
+#ifdef DR_PROFILE_STAGES
+  unsigned long long *prof;   // 16 cycle accumulators of the block's (single) wave: [0] per-lane part, [d] level d
+  static constexpr int kDoubles = 3 * (D + 1) * 64 + (D * 64 + 3) / 4 + 16;
+  __device__ __forceinline__ explicit RootWs(double *ws)
+      : pts{ws, ws + (D + 1) * 64}, q(ws + 2 * (D + 1) * 64), queue(reinterpret_cast<uint16_t *>(ws + 3 * (D + 1) * 64)),
+        prof(reinterpret_cast<unsigned long long *>(ws + 3 * (D + 1) * 64 + (D * 64 + 3) / 4)) {}
+#else
   static constexpr int kDoubles = 3 * (D + 1) * 64 + (D * 64 + 3) / 4;
   __device__ __forceinline__ explicit RootWs(double *ws)
       : pts{ws, ws + (D + 1) * 64}, q(ws + 2 * (D + 1) * 64), queue(reinterpret_cast<uint16_t *>(ws + 3 * (D + 1) * 64)) {}
+#endif
 };
-
-__device__ __forceinline__ void wave_lds_order() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 template <int D, int d, int R>
 __device__ __forceinline__ void root_tasks(const RootWs<D> &ws, const double *__restrict__ cur, double *__restrict__ nxt, int total, int lane,
@@ -360,6 +371,9 @@ template <int D, int d, int kBisLast, int kNewtLast>
 __device__ __forceinline__ void root_levels_wave(const double (&c)[D + 1], const RootWs<D> &ws, int lane, unsigned &mask) {
   const double *cur = ws.pts[(d - 1) & 1];
   double *nxt = ws.pts[d & 1];
+#ifdef DR_PROFILE_STAGES
+  const unsigned long long _lvl_t0 = __builtin_readcyclecounter();
+#endif
   double q[d + 1];  // q = p^(D-d): degree d, ascending
 #pragma unroll
   for (int i = 0; i <= d; ++i) {
@@ -399,12 +413,18 @@ __device__ __forceinline__ void root_levels_wave(const double (&c)[D + 1], const
     fprev = fhi;
   }
   wave_lds_order();
+#ifdef DR_PROFILE_STAGES
+  if (lane == 0) ws.prof[0] += __builtin_readcyclecounter() - _lvl_t0;   // per-lane part, all levels
+#endif
   const int kBis = (d == D) ? kBisLast : DR_ROOT_BIS_LOW;
   const int kNewt = (d == D) ? kNewtLast : DR_ROOT_NEWT_LOW;
   if (offs <= 64) root_tasks<D, d, 1>(ws, cur, nxt, offs, lane, kBis, kNewt);
   else if (offs <= 128) root_tasks<D, d, 2>(ws, cur, nxt, offs, lane, kBis, kNewt);
   else root_tasks<D, d, 3>(ws, cur, nxt, offs, lane, kBis, kNewt);
   wave_lds_order();
+#ifdef DR_PROFILE_STAGES
+  if (lane == 0) ws.prof[d] += __builtin_readcyclecounter() - _lvl_t0;   // whole level d
+#endif
   if constexpr (d < D) root_levels_wave<D, d + 1, kBisLast, kNewtLast>(c, ws, lane, mask);
   else mask = has;
 }
@@ -432,7 +452,13 @@ __device__ __forceinline__ void real_roots_half_wave(const double (&c)[D + 1], b
     ws.pts[1][i * 64 + lane] = i == 0 ? -1.0 : 1.0;
   }
   unsigned mk;
+#ifdef DR_PROFILE_STAGES
+  if (lane < 16) ws.prof[lane] = 0;
+#endif
   root_levels_wave<D, 1, kBisLast, kNewtLast>(ch, ws, lane, mk);
+#ifdef DR_PROFILE_STAGES
+  if (D == 10 && lane <= 10) atomicAdd(&::dr::g_stage_cycles[lane == 0 ? 1 : 5 + lane], ws.prof[lane]);
+#endif
   if (!ok) mk = 0;
   const double *res = ws.pts[D & 1];
   count = 0;
@@ -880,9 +906,11 @@ __device__ __forceinline__ void pmul21_acc(const double (&a)[10], const double (
 // (51 KiB per 64-lane block => three blocks per CU instead of one), ~200 LDS accesses per sample instead of ~6000.
 // kFirstRow = smallest row index the caller needs (rows kFirstRow..9 of X are produced: X[r - kFirstRow][c]).
 // ------------------------------------------------------------------------------------------------
-template <class Ord, int kFirstRow>
+// kSplit: two lanes build and factor the same system (same LDS slot); each then solves five of the ten right-hand-side
+// columns (`half` = 0 / 1) and both read all results back -- block = one wave, so program order is enough.
+template <class Ord, int kFirstRow, bool kSplit = false>
 __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], const LaneWs &Bw, double s,
-                                   double (&X)[10 - kFirstRow][10]) {
+                                   double (&X)[10 - kFirstRow][10], int half = 0) {
   double A[10][10];
   // ---- the ten cubic constraints on E(x,y,z) = x B0 + y B1 + z B2 + B3: rows 0-8 = entries (row-major i,j) of
   //      s*(E E^T E - 1/2 tr(E E^T) E) (s = 2 for Stewenius' 2EE^TE - tr(EE^T)E), row 9 = det E;
@@ -979,8 +1007,10 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
 #pragma unroll
   for (int j = 0; j < 10; ++j) rinv[j] = ok ? 1.0 / rdiag[j] : 0.0;
   // ---- one right-hand-side column at a time
+  if (kSplit) wave_lds_order();
 #pragma unroll 1
-  for (int c = 0; c < 10; ++c) {
+  for (int c0 = 0; c0 < (kSplit ? 5 : 10); ++c0) {
+    const int c = kSplit ? c0 + 5 * half : c0;
     double b[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) b[i] = Bw[i * 10 + c];
@@ -1006,6 +1036,7 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
 #pragma unroll
     for (int r = kFirstRow; r < 10; ++r) Bw[r * 10 + c] = x[r];
   }
+  if (kSplit) wave_lds_order();
 #pragma unroll
   for (int r = kFirstRow; r < 10; ++r)
 #pragma unroll

@@ -4,7 +4,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-variants = {'wave': [], 'wave_v1': [], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
+variants = {'wave': [], 'wave_v1': [], 'wave_v2': [], 'wave_v3': [], 'nosplit': ['-DDR_ROOT_SPLIT=0'], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
             'old': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVE_ROOTS=0'], 'old_w2': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVES=2'], 'bal': [], 'bal_w2': ['-DDR_K3_WAVES=2'],
             'old_prof': ['-DDR_K3_BALANCED=0', '-DDR_PROFILE_STAGES'], 'bal_prof': ['-DDR_PROFILE_STAGES'],
             'f32low': ['-DDR_ROOT_F32_LOW=1'], 'f32low_w2': ['-DDR_ROOT_F32_LOW=1', '-DDR_K3_WAVES=2'], 'f32low_prof': ['-DDR_ROOT_F32_LOW=1', '-DDR_PROFILE_STAGES']}
@@ -46,7 +46,7 @@ for P in (32, 128):
             if name.endswith('_prof'):
                 buf = (ctypes.c_ulonglong * 16)()
                 lib.dr_debug_stage_read_fivepoint(buf); f(); torch.cuda.synchronize(); lib.dr_debug_stage_read_fivepoint(buf)
-                print('   cycles/wave by stage:', [int(x) // (Bt // 32) for x in buf[:6]], ' active brackets per wave by level 1..10:', [round(int(x) / (Bt // 32), 1) for x in buf[6:16]])
+                print('   cycles/wave by stage:', [int(x) // (Bt // 32) for x in buf[:6]], ' root-search cycles per wave by level 1..10:', [int(x) // (Bt // 32) for x in buf[6:16]])
             Eg = models[:512].reshape(512, 10, 3, 3).cpu().double(); vg = valid[:512].cpu().bool()
             found, total, worst = 0, 0, []
             for i in range(512):
