@@ -168,6 +168,18 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
     return step, dict(rn=rn, matches=matches, logits=logits, S=S, data=data, K=(K1, K2))
 
 
+def run_bounded(fn, n, window=32):
+    """fn(i) for i < n with at most `window` steps queued ahead of the device: step i is issued when step i - window has
+    finished (event recorded on the stream that is current when fn returns...  fn may switch streams itself: it then returns
+    the stream to record on)."""
+    ev = [torch.cuda.Event() for _ in range(window)]
+    for i in range(n):
+        if i >= window:
+            ev[i % window].synchronize()
+        st = fn(i)
+        ev[i % window].record(st if isinstance(st, torch.cuda.Stream) else torch.cuda.current_stream())
+
+
 class CallTimer:
     """HIP events around selected libdransac launches (the ctypes call), recorded on the stream the launch goes to."""
 
@@ -238,20 +250,25 @@ def config_record(key, dev, steps, warmup, pairs=None):
     if pairs is not None:
         w["pairs"] = pairs
     step, info = make_step(w, dev)
-    for _ in range(warmup):
+    for _ in range(max(warmup, 20)):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    # three equal segments, the median one is reported (a sub-record shares the process with everything measured before
+    # it -- allocator state, clocks -- and one slow segment should not stand for the config)
+    seg, seg_ms = max(1, steps // 3), []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run_bounded(lambda i: step() and None, seg)
+        torch.cuda.synchronize()
+        seg_ms.append((time.perf_counter() - t0) / seg * 1e3)
+    el, steps = sorted(seg_ms)[1] * 1e-3 * seg, seg
     calls = per_call_breakdown(step)
     dom = max(calls, key=calls.get)
     P, N, B = w["pairs"], w["points"], w["hyps"]
     M = B * info["S"]
     rec = {"baseline_config_index": w["baseline_config"], "workload": f"{w['text']}, {P} pair(s) per step",
-           "steps": steps, "ms_per_step": el / steps * 1e3, "hypotheses_per_s": P * B * steps / el,
+           "steps": steps, "segments_ms_per_step": [round(x, 5) for x in seg_ms], "ms_per_step": el / steps * 1e3,
+           "hypotheses_per_s": P * B * steps / el,
            "pairs_per_s": P * steps / el, "launch_ms": {k: round(v, 5) for k, v in sorted(calls.items(), key=lambda kv: -kv[1])},
            "dominant_launch": dom, "dominant_ms": calls[dom],
            "reference_import_hypotheses_per_s": REFERENCE_IMPORT.get(key)}
@@ -416,12 +433,29 @@ def main():
     outs = [None] * len(streams)
 
     def issue(i):
+        if len(streams) == 1:
+            # one batch in flight: the caller's current stream (a stream context costs the train step's autograd engine
+            # 0.2 ms of host time per step for cross-thread stream bookkeeping: scratch/host_overhead2.py)
+            outs[0] = step()
+            return
         st = streams[i % len(streams)]
         with torch.cuda.stream(st):
             outs[i % len(streams)] = step()
 
-    for i in range(args.warmup):
+    # bounded run-ahead: the host issues a step in ~0.1 ms and would otherwise queue hundreds of steps; the first time the
+    # runtime's queue fills it stalls the device for ~40 ms, once (scratch/stall_find.py, stall_find2.py).  Step i is issued
+    # when step i - kWindow has finished -- the device always has kWindow steps queued, so it never waits for the host.
+    kWindow = 32
+    done_ev = [torch.cuda.Event() for _ in range(kWindow)]
+
+    def issue_bounded(i, n_issued):
+        if n_issued >= kWindow:
+            done_ev[n_issued % kWindow].synchronize()
         issue(i)
+        done_ev[n_issued % kWindow].record(streams[i % len(streams)] if len(streams) > 1 else torch.cuda.current_stream())
+
+    for i in range(args.warmup):
+        issue_bounded(i, i)
     torch.cuda.synchronize()
     coll_ev.clear()
     if dist is not None:
@@ -430,7 +464,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         timer.i = i
-        issue(i)
+        issue_bounded(i, i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -483,10 +517,12 @@ def main():
             with torch.cuda.stream(s2[i % n2]):
                 keep[i % n2] = step()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
+        def issue2(i):
             with torch.cuda.stream(s2[i % n2]):
                 keep[i % n2] = step()
+            return s2[i % n2]
+        t1 = time.perf_counter()
+        run_bounded(issue2, args.steps)
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t1
         overlap = {"streams": n2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
@@ -588,8 +624,8 @@ def main():
                 fout = fstep()
             torch.cuda.synchronize()
             tf = time.perf_counter()
-            for _ in range(200):
-                fout = fstep()
+            run_bounded(lambda i: fstep() and None, 199)
+            fout = fstep()
             torch.cuda.synchronize()
             ef = time.perf_counter() - tf
             gi = finfo["data"]["inliers"].to(dev)
