@@ -89,6 +89,11 @@ def parse():
                     help="process-group backend.  nccl = RCCL over xGMI (the real thing).  gloo exists to run the N > 1 code paths "
                          "on a box with ONE GPU (RCCL refuses two ranks on one device): --gpus-shared lets the ranks share it")
     ap.add_argument("--gpus-shared", action="store_true", help="functional check only: every rank uses cuda:0")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="HIP-graph replay of the step (sampler seeds advance on the device, so every replay draws fresh "
+                         "hypotheses).  auto: the train step and the sub-records of the other configs are replayed; the "
+                         "headline test-mode region stays eager, because its roofline needs HIP events around the scoring "
+                         "launch of every step (it is device-bound either way)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the K timed steps are issued on round-robin.  Default 1: strictly one kernel at a "
                          "time, so that the HIP-event duration of the scoring kernel in the timed region is its own "
@@ -122,8 +127,9 @@ def load_logits_fixture(P):
             "inliers": t("geometric_inliers"), "gt_F": t("gt_E")}
 
 
-def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=False):
-    """Builds the resident inputs of a workload and returns (step callable, info dict)."""
+def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=False, device_seeds=False):
+    """Builds the resident inputs of a workload and returns (step callable, info dict).  device_seeds: the drivers advance
+    their sampler seed on the device, which makes the step capturable in a HIP graph (differentiable_ransac_amd.graphs)."""
     from differentiable_ransac_amd import synth
     from differentiable_ransac_amd.ransac import BatchedRANSAC, BatchedRANSAC3D
     P, N, B = w["pairs"], w["points"], w["hyps"]
@@ -133,6 +139,8 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
         logits = torch.stack([it["logits"] for it in items]).to(dev)
         rn = BatchedRANSAC3D(ransac_batch_size=B, train=False, threshold=0.03, max_iterations=B, seed=seed + rank, flag=False,
                              keep_masks=keep_masks)
+        if device_seeds:
+            rn.device_seeds(dev)
 
         def step():
             return rn(matches, logits)
@@ -145,6 +153,8 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
         from differentiable_ransac_amd.loss import MatchLoss
         gt = data["gt_E"].to(dev) if w["solver"] != "f8" else data["gt_F"].to(dev)
         tr = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=True, max_iterations=B, seed=99 + rank)
+        if device_seeds:
+            tr.device_seeds(dev)
         lg = logits.clone().requires_grad_(True)
         match_loss = MatchLoss()                     # the reference's default training loss (-w2 1, train.py:70-79)
         gt_mask = data["inliers"].to(dev)
@@ -162,6 +172,8 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
         return step, dict(rn=tr, matches=matches, logits=lg, S=S, data=data, K=(K1, K2))
     rn = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B, seed=seed + rank,
                        keep_masks=keep_masks, refit=False, sampling=w["sampler"])
+    if device_seeds:
+        rn.device_seeds(dev)
 
     def step():
         return rn(matches, logits, K1, K2)
@@ -244,7 +256,7 @@ def k4r_bytes(P, N, M):
     return P * (24 * N + 48 * M + 4 * M + 4 + M * N)     # rigid residuals with masks
 
 
-def config_record(key, dev, steps, warmup, pairs=None):
+def config_record(key, dev, steps, warmup, pairs=None, graph=True):
     """Sub-record of one BASELINE config: ms/step, hypotheses/s, the dominant libdransac launch and its roofline share."""
     w = dict(WORKLOADS[key])
     if pairs is not None:
@@ -255,20 +267,40 @@ def config_record(key, dev, steps, warmup, pairs=None):
     torch.cuda.synchronize()
     # three equal segments, the median one is reported (a sub-record shares the process with everything measured before
     # it -- allocator state, clocks -- and one slow segment should not stand for the config)
-    seg, seg_ms = max(1, steps // 3), []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        run_bounded(lambda i: step() and None, seg)
+    seg = max(1, steps // 3)
+
+    def segments(fn):
+        out = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run_bounded(lambda i: fn() and None, seg)
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / seg * 1e3)
+        return out
+    eager_ms = segments(step)
+    seg_ms, issue, graph_ms = eager_ms, "eager: one Python call per launch", None
+    if graph:
+        # the same step (same launches, fresh hypotheses per replay: the seed advances on the device) replayed as ONE HIP graph
+        from differentiable_ransac_amd.graphs import GraphedStep
+        gstep = GraphedStep(make_step(w, dev, device_seeds=True)[0])
+        for _ in range(5):
+            gstep()
         torch.cuda.synchronize()
-        seg_ms.append((time.perf_counter() - t0) / seg * 1e3)
+        graph_ms = segments(gstep)
+        del gstep
+        # launch-bound steps (config 1: 0.05 ms of device time in six launches) gain from the replay, device-bound ones lose a
+        # few per cent to the graph's inter-node barriers: the sub-record carries both and quotes the faster one
+        if sorted(graph_ms)[1] < sorted(eager_ms)[1]:
+            seg_ms, issue = graph_ms, "HIP graph replay of the whole step (differentiable_ransac_amd.graphs.GraphedStep)"
     el, steps = sorted(seg_ms)[1] * 1e-3 * seg, seg
     calls = per_call_breakdown(step)
     dom = max(calls, key=calls.get)
     P, N, B = w["pairs"], w["points"], w["hyps"]
     M = B * info["S"]
     rec = {"baseline_config_index": w["baseline_config"], "workload": f"{w['text']}, {P} pair(s) per step",
-           "steps": steps, "segments_ms_per_step": [round(x, 5) for x in seg_ms], "ms_per_step": el / steps * 1e3,
-           "hypotheses_per_s": P * B * steps / el,
+           "steps": steps, "issue": issue, "segments_ms_per_step": [round(x, 5) for x in seg_ms],
+           "ms_per_step": el / steps * 1e3, "hypotheses_per_s": P * B * steps / el,
+           "eager_ms_per_step": sorted(eager_ms)[1], "graph_replay_ms_per_step": sorted(graph_ms)[1] if graph else None,
            "pairs_per_s": P * steps / el, "launch_ms": {k: round(v, 5) for k, v in sorted(calls.items(), key=lambda kv: -kv[1])},
            "dominant_launch": dom, "dominant_ms": calls[dom],
            "reference_import_hypotheses_per_s": REFERENCE_IMPORT.get(key)}
@@ -400,8 +432,16 @@ def main():
     # hypothesis split: every rank holds the SAME pairs (rank 0's data) and its own sampler stream
     if args.logits_fixture and (w["solver"] in ("f8", "rigid") or N != 2000):
         raise SystemExit("--logits-fixture holds 2000-point essential-matrix pairs: use it with the c2 / c3 workloads")
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.mode == "train")
     step, info = make_step(w, dev, rank=0 if split_h else rank, mode=args.mode,
-                           seed=sharding.hypothesis_seed(1234, rank) if split_h else 1234, fixture=args.logits_fixture)
+                           seed=sharding.hypothesis_seed(1234, rank) if split_h else 1234, fixture=args.logits_fixture,
+                           device_seeds=use_graph)
+    eager_step = step
+    if use_graph:
+        # one graph launch per step instead of 6 (test) / ~25 (train, forward + backward) Python-issued launches; the
+        # collective of an N > 1 train step and the winner merge of --split hypotheses stay outside the graph
+        from differentiable_ransac_amd.graphs import GraphedStep
+        step = GraphedStep(step)
     rn, matches, logits, S = info["rn"], info["matches"], info["logits"], info["S"]
     K1, K2 = info["K"]
     M = w["hyps"] * S
@@ -496,6 +536,8 @@ def main():
                               "config": {"workload": f"{w['solver']} train step (sample, solve, best-of-10 vs GT, MatchLoss, "
                                                      f"backward), {N} pts x {B} hyps per pair, {P} pairs/GPU",
                                          "mode": "train",
+                                         "issue": ("HIP graph replay of forward + loss + backward (one launch per step)"
+                                                   if use_graph else "eager: one Python call per launch, autograd backward"),
                                          "parallelism": f"pairs sharded over {world} GPU(s); one flat RCCL all-reduce of "
                                                         f"{CLNET_PARAMS} + {P * N} f32 per step" if world > 1 else "single GPU"},
                               "collective_ms": collective_ms,
@@ -555,7 +597,16 @@ def main():
             e4 = time.perf_counter() - t3
             topdown = {"value": P * B * n_x / e4, "ms_per_step": e4 / n_x * 1e3, "streams": 1}
 
-    k4_ms = timer.mean_ms()
+    if use_graph:             # a replayed graph has no Python-level launches to put events around: time the scoring launch
+        n_ev = min(20, args.steps)   # in a few eager steps of the same driver instead
+        for i in range(n_ev):
+            timer.i = i
+            eager_step()
+        torch.cuda.synchronize()
+        timer.i = -1
+        k4_ms = timer.mean_ms(n_ev)
+    else:
+        k4_ms = timer.mean_ms()
     iso_ms = k4_ms
     if len(streams) > 1:      # with two batches in flight the kernel shares the CUs: also measure it alone
         n_iso = min(10, args.steps)
@@ -593,7 +644,8 @@ def main():
                    "parallelism": (f"hypotheses of the same {P} pair(s) split over {world} GPUs, per-pair winners merged by two "
                                    "all_gathers per step" if split_h else f"pairs sharded over {world} GPU(s), no collective"),
                    "streams": len(streams),
-                   "issue": f"{len(streams)} batch(es) in flight, round-robin over {len(streams)} HIP stream(s)"},
+                   "issue": f"{len(streams)} batch(es) in flight, round-robin over {len(streams)} HIP stream(s), "
+                            + ("HIP graph replay" if use_graph else "eager launches (HIP events around the scoring launch)")},
         "pairs_per_s": (1 if split_h else world) * P * args.steps / elapsed,
         "roofline": {"bound": "hbm", "kernel": kernel_name, "valid_slot_fraction": valid_frac, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -614,9 +666,10 @@ def main():
         result["kernel_breakdown_ms"] = kernel_breakdown(w, rn, matches, logits, ops)
     if rank == 0 and world == 1 and not args.no_configs:
         n_cfg = {"c1": 300, "c2": 200, "c3": 60, "c4": 150}
-        result["configs"] = {k: config_record(k, dev, n_cfg[k], 5) for k in sorted(WORKLOADS) if k != args.workload}
+        g_ = args.graph != "off"
+        result["configs"] = {k: config_record(k, dev, n_cfg[k], 5, graph=g_) for k in sorted(WORKLOADS) if k != args.workload}
         if args.workload == "c2" and P != 32:
-            result["configs"]["c2_p32"] = config_record("c2", dev, 300, 5, pairs=32)   # round 1's batch size
+            result["configs"]["c2_p32"] = config_record("c2", dev, 300, 5, pairs=32, graph=g_)   # round 1's batch size
         if not args.logits_fixture and os.path.exists(os.path.join(ROOT, "tests", "golden", "clnet_logits.npz")):
             # the c2 workload on reader-produced pairs with the reference network's scores instead of synthetic logits
             fstep, finfo = make_step(dict(WORKLOADS["c2"], pairs=32), dev, fixture=True)

@@ -35,6 +35,7 @@ struct GumbelArgs {
   uint64_t seed;
   T tau;
   int P, B, N, k;
+  const uint64_t *seed_ptr;   // optional: the seed lives in device memory (captured graphs: one word updated per replay)
 };
 
 template <typename T> __device__ __forceinline__ T gumbel_from_bits_t(uint32_t bits);
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
                                                                         T *__restrict__ gumbel_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ int s_win[kRowsPerBlock][kMaxK];
+  if (a.seed_ptr) a.seed = *a.seed_ptr;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
   const int groups = (a.N + 3) >> 2;
@@ -297,9 +299,11 @@ template <bool kSoft>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(const float *__restrict__ logits, uint64_t seed,
                                                                              int B, int N, int k, int32_t *__restrict__ idx,
                                                                              float *__restrict__ y_sel,
-                                                                             float *__restrict__ lse_out) {
+                                                                             float *__restrict__ lse_out,
+                                                                             const uint64_t *__restrict__ seed_ptr) {
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
+  if (seed_ptr) seed = *seed_ptr;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
   if (b >= B) return;   // whole wave exits together (no block-level barrier is used below)
@@ -434,8 +438,9 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 
 template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
-                      int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st) {
-  GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k};
+                      int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
+                      const uint64_t *seed_ptr = nullptr) {
+  GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
   const int groups = (N + 3) / 4;
   const size_t base = (size_t)kRowsPerBlock * kMaxCand * (sizeof(T) + sizeof(int));
   const size_t cache = (size_t)kRowsPerBlock * groups * 4 * sizeof(T);
@@ -446,10 +451,10 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
     if (DR_K1_FAST && logits && !gumbel && tau == T(1) && (N & 3) == 0 && N <= 4 * 64 * kFastGroups && !y_soft && !ret && !gumbel_out) {
       if (soft)
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse);
+                           (float *)y_sel, (float *)lse, seed_ptr);
       else
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse);
+                           (float *)y_sel, (float *)lse, seed_ptr);
       return check_launch("gumbel_topk_fast_kernel");
     }
   }
@@ -480,6 +485,7 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
   // `rows_per_block` hypothesis rows (their lse and <y,a> are staged in LDS) and adds its partial sums
   // into grad_logits with one atomicAdd per point: (groups/256) x P x (B/rows_per_block) blocks fill the chip, where a
   // single block per point group would leave 3/4 of the CUs idle at C2.
+  if (a.seed_ptr) a.seed = *a.seed_ptr;
   const int p = blockIdx.y;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -600,7 +606,8 @@ __global__ __launch_bounds__(1024) void softmax_cdf_kernel(const T *__restrict__
 // Step 2, one lane per (pair, hypothesis): k draws without replacement, ascending output.
 // Philox4x32-10(key = seed, counter = (draw pair, b, p, 2)): 64 random bits per draw.
 __global__ __launch_bounds__(256) void topdown_sample_kernel(const double *__restrict__ cdf, uint64_t seed, int B, int N, int k,
-                                                            int32_t *__restrict__ idx) {
+                                                            int32_t *__restrict__ idx, const uint64_t *__restrict__ seed_ptr) {
+  if (seed_ptr) seed = *seed_ptr;
   const int p = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const double *c = cdf + (size_t)p * N;
@@ -644,7 +651,9 @@ __global__ __launch_bounds__(256) void topdown_sample_kernel(const double *__res
 }
 
 // ---- K1u: uniform indices in [0, N-2]
-__global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_t *__restrict__ idx) {
+__global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_t *__restrict__ idx,
+                                      const uint64_t *__restrict__ seed_ptr) {
+  if (seed_ptr) seed = *seed_ptr;
   const int p = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // over B*k
   if (t >= B * k) return;
@@ -653,6 +662,15 @@ __global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_
   Philox::gen(seed, (uint32_t)j, (uint32_t)b, (uint32_t)p, 1u, r);
   const uint32_t span = (uint32_t)max(N - 1, 1);
   idx[((size_t)p * B + b) * k + j] = (int32_t)(((uint64_t)r[0] * span) >> 32);
+}
+
+// ---- seed of the next call, on the device: state = (base, calls) -> out = base * 0x9E3779B97F4A7C15 + calls ; calls += 1
+// (what the drivers compute on the host per call; here a captured graph advances it by itself at every replay)
+__global__ void seed_next_kernel(uint64_t *__restrict__ state, uint64_t *__restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *out = state[0] * 0x9E3779B97F4A7C15ull + state[1];
+    state[1] += 1;
+  }
 }
 
 // ---- K2 gather forward / backward
@@ -695,6 +713,45 @@ __global__ void gather_bwd_kernel(const T *__restrict__ matches, const int32_t *
 
 }  // namespace dr
 
+static int gumbel_bwd_f32_impl(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_ptr, float tau,
+                               int P, int B, int N, int k, const int32_t *idx, const float *lse, const float *a_sel,
+                               float *grad_logits, void *stream) {
+  DR_REQUIRE(idx && lse && a_sel && grad_logits, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
+  dr::GumbelArgs<float> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
+  const size_t smem = sizeof(float) * 256 * 2;
+  const int gx = ((N + 3) / 4 + 255) / 256;
+  // enough row chunks to put >= ~2048 blocks on the chip, at least 32 rows each
+  int chunks = (int)std::min<long>((B + 31) / 32, std::max<long>(1, 2048 / std::max<long>(1, (long)gx * P)));
+  const int rows_per_block = (B + chunks - 1) / chunks;
+  chunks = (B + rows_per_block - 1) / rows_per_block;
+  if (hipMemsetAsync(grad_logits, 0, sizeof(float) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
+    return dr::check_launch("memset");
+  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
+                     lse, a_sel, grad_logits, rows_per_block);
+  return dr::check_launch("gumbel_bwd_kernel");
+}
+
+template <typename T>
+static int topdown_impl(const T *logits, uint64_t seed, const uint64_t *seed_ptr, int P, int B, int N, int k, double *cdf_ws,
+                        int32_t *idx, void *stream) {
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && k > 0 && k <= dr::kMaxK && k <= N && P <= 65535, "bad sizes");
+  DR_REQUIRE(cdf_ws && idx, "null pointer");
+  hipLaunchKernelGGL((dr::softmax_cdf_kernel<T>), dim3(P), dim3(1024), 0, (hipStream_t)stream, logits, N, cdf_ws);
+  if (int rc = dr::check_launch("softmax_cdf_kernel")) return rc;
+  hipLaunchKernelGGL(dr::topdown_sample_kernel, dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, cdf_ws, seed, B,
+                     N, k, idx, seed_ptr);
+  return dr::check_launch("topdown_sample_kernel");
+}
+
+static int uniform_impl(uint64_t seed, const uint64_t *seed_ptr, int P, int B, int k, int N, int32_t *idx, void *stream) {
+  DR_REQUIRE(idx, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && k > 0 && N > 1 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL(dr::uniform_sample_kernel, dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, seed,
+                     B, k, N, idx, seed_ptr);
+  return dr::check_launch("uniform_sample_kernel");
+}
+
 extern "C" {
 
 #define DR_GUMBEL_CHECK()                                                          \
@@ -724,50 +781,64 @@ int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t 
 int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
                            int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
                            void *stream) {
-  DR_REQUIRE(idx && lse && a_sel && grad_logits, "null pointer");
-  DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
-  dr::GumbelArgs<float> a{logits, gumbel, seed, tau, P, B, N, k};
-  const size_t smem = sizeof(float) * 256 * 2;
-  const int gx = ((N + 3) / 4 + 255) / 256;
-  // enough row chunks to put >= ~2048 blocks on the chip, at least 32 rows each
-  int chunks = (int)std::min<long>((B + 31) / 32, std::max<long>(1, 2048 / std::max<long>(1, (long)gx * P)));
-  const int rows_per_block = (B + chunks - 1) / chunks;
-  chunks = (B + rows_per_block - 1) / rows_per_block;
-  if (hipMemsetAsync(grad_logits, 0, sizeof(float) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
-    return dr::check_launch("memset");
-  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
-                     lse, a_sel, grad_logits, rows_per_block);
-  return dr::check_launch("gumbel_bwd_kernel");
+  return gumbel_bwd_f32_impl(logits, gumbel, seed, nullptr, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
 }
 
 int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
                           void *stream) {
-  DR_REQUIRE(P > 0 && B > 0 && N > 0 && k > 0 && k <= dr::kMaxK && k <= N && P <= 65535, "bad sizes");
-  DR_REQUIRE(cdf_ws && idx, "null pointer");
-  hipLaunchKernelGGL((dr::softmax_cdf_kernel<float>), dim3(P), dim3(1024), 0, (hipStream_t)stream, logits, N, cdf_ws);
-  if (int rc = dr::check_launch("softmax_cdf_kernel")) return rc;
-  hipLaunchKernelGGL(dr::topdown_sample_kernel, dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, cdf_ws, seed, B,
-                     N, k, idx);
-  return dr::check_launch("topdown_sample_kernel");
+  return topdown_impl<float>(logits, seed, nullptr, P, B, N, k, cdf_ws, idx, stream);
 }
 
 int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
                           void *stream) {
-  DR_REQUIRE(P > 0 && B > 0 && N > 0 && k > 0 && k <= dr::kMaxK && k <= N && P <= 65535, "bad sizes");
-  DR_REQUIRE(cdf_ws && idx, "null pointer");
-  hipLaunchKernelGGL((dr::softmax_cdf_kernel<double>), dim3(P), dim3(1024), 0, (hipStream_t)stream, logits, N, cdf_ws);
-  if (int rc = dr::check_launch("softmax_cdf_kernel")) return rc;
-  hipLaunchKernelGGL(dr::topdown_sample_kernel, dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, cdf_ws, seed, B,
-                     N, k, idx);
-  return dr::check_launch("topdown_sample_kernel");
+  return topdown_impl<double>(logits, seed, nullptr, P, B, N, k, cdf_ws, idx, stream);
 }
 
 int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream) {
-  DR_REQUIRE(idx, "null pointer");
-  DR_REQUIRE(P > 0 && B > 0 && k > 0 && N > 1 && P <= 65535, "bad sizes");
-  hipLaunchKernelGGL(dr::uniform_sample_kernel, dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, seed,
-                     B, k, N, idx);
-  return dr::check_launch("uniform_sample_kernel");
+  return uniform_impl(seed, nullptr, P, B, k, N, idx, stream);
+}
+
+// ---- the same samplers with the Philox key read from device memory (*seed_dev) when the kernel starts: what a captured
+//      graph needs (a by-value seed would be frozen into the graph); dr_seed_next advances such a seed on the device
+int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream) {
+  DR_REQUIRE(state && seed_out, "null pointer");
+  hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seed_out);
+  return dr::check_launch("seed_next_kernel");
+}
+
+int dr_gumbel_topk_fwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
+                                 int32_t *idx, float *y_sel, float *lse, void *stream) {
+  const float *y_soft = nullptr, *ret = nullptr;
+  DR_REQUIRE(seed_dev, "null seed pointer");
+  DR_GUMBEL_CHECK();
+  return dr::gumbel_fwd_launch<float>(logits, nullptr, 0, tau, P, B, N, k, idx, y_sel, lse, nullptr, nullptr, nullptr,
+                                      (hipStream_t)stream, seed_dev);
+}
+
+int dr_gumbel_topk_fwd_f64_dseed(const double *logits, const uint64_t *seed_dev, double tau, int P, int B, int N, int k,
+                                 int32_t *idx, double *y_sel, double *lse, void *stream) {
+  const double *y_soft = nullptr, *ret = nullptr;
+  DR_REQUIRE(seed_dev, "null seed pointer");
+  DR_GUMBEL_CHECK();
+  return dr::gumbel_fwd_launch<double>(logits, nullptr, 0, tau, P, B, N, k, idx, y_sel, lse, nullptr, nullptr, nullptr,
+                                       (hipStream_t)stream, seed_dev);
+}
+
+int dr_gumbel_topk_bwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
+                                 const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits, void *stream) {
+  DR_REQUIRE(seed_dev, "null seed pointer");
+  return gumbel_bwd_f32_impl(logits, nullptr, 0, seed_dev, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
+}
+
+int dr_topdown_sample_f32_dseed(const float *logits, const uint64_t *seed_dev, int P, int B, int N, int k, double *cdf_ws,
+                                int32_t *idx, void *stream) {
+  DR_REQUIRE(seed_dev, "null seed pointer");
+  return topdown_impl<float>(logits, 0, seed_dev, P, B, N, k, cdf_ws, idx, stream);
+}
+
+int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream) {
+  DR_REQUIRE(seed_dev, "null seed pointer");
+  return uniform_impl(0, seed_dev, P, B, k, N, idx, stream);
 }
 
 int dr_gather_fwd_f32(const float *matches, const int32_t *idx, const float *y_sel, int P, int N, int B, int k,

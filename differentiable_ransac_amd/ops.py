@@ -116,6 +116,33 @@ def ransac_update(state: RansacState, matches, models, valid, scores, thr, B: in
 
 
 # ------------------------------------------------------------------------------------------ K1 / K1u / K2
+class DeviceSeed:
+    """The per-call sampler seed of the batched drivers, kept on the device: state = (base, calls) and `next()` launches
+    dr_seed_next -> a one-word tensor holding base * 0x9E3779B97F4A7C15 + calls (mod 2^64), calls += 1.  The samplers
+    accept such a tensor wherever they accept an int seed and read it when their kernel starts, so a step captured in a
+    HIP graph (torch.cuda.graph) draws fresh hypotheses at every replay -- the same ones an eager driver with the same
+    base seed draws at the same call number."""
+
+    def __init__(self, base: int, device, calls: int = 0):
+        def signed(v):
+            v &= 2 ** 64 - 1
+            return v - 2 ** 64 if v >= 2 ** 63 else v
+        self.state = torch.tensor([signed(base), signed(calls)], dtype=torch.int64, device=device)
+
+    def next(self) -> torch.Tensor:
+        out = torch.empty(1, dtype=torch.int64, device=self.state.device)
+        L.call("dr_seed_next", ptr(self.state), ptr(out), stream())
+        return out
+
+
+def _dev_seed(seed):
+    if torch.is_tensor(seed):
+        if seed.dtype != torch.int64 or seed.numel() != 1 or not seed.is_cuda:
+            raise L.DransacError("a device seed is a one-element int64 CUDA tensor (DeviceSeed.next())")
+        return True
+    return False
+
+
 def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0,
                 gumbel: Optional[torch.Tensor] = None, seed: int = 0, N: Optional[int] = None,
                 dense: bool = False, want_noise: bool = False, device=None, dtype=torch.float32, soft: bool = True):
@@ -143,6 +170,12 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
     y_soft = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
     ret = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
     noise = torch.empty((P, B, N), device=device, dtype=dtype) if want_noise else None
+    if _dev_seed(seed):
+        if gumbel is not None or dense or want_noise or logits is None:
+            raise L.DransacError("a device seed serves the in-kernel noise of given logits only (no explicit noise / dense outputs)")
+        L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}_dseed", ptr(logits), ptr(seed), L.scalar(dtype, tau), c_int(P), c_int(B),
+               c_int(N), c_int(k), ptr(idx), ptr(y_sel), ptr(lse), stream())
+        return dict(idx=idx, y_sel=y_sel, lse=lse)
     L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", ptr(logits), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
            L.scalar(dtype, tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(y_sel), ptr(lse), ptr(y_soft),
            ptr(ret), ptr(noise), stream())
@@ -159,6 +192,10 @@ def gumbel_topk_bwd(logits, gumbel, seed, tau, idx, lse, a_sel):
     P, B, k = idx.shape
     N = logits.shape[1]
     grad = torch.empty_like(logits)
+    if _dev_seed(seed):
+        L.call("dr_gumbel_topk_bwd_f32_dseed", ptr(logits.contiguous()), ptr(seed), L.c_float(tau), c_int(P), c_int(B), c_int(N),
+               c_int(k), ptr(idx), ptr(lse), ptr(a_sel.contiguous()), ptr(grad), stream())
+        return grad
     L.call("dr_gumbel_topk_bwd_f32", ptr(logits.contiguous()), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
            L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(lse), ptr(a_sel.contiguous()),
            ptr(grad), stream())
@@ -180,6 +217,12 @@ def topdown_sample(logits: Optional[torch.Tensor], B: int, k: int, seed: int = 0
         sfx = "f32"
     ws = torch.empty((P, N), device=device, dtype=torch.float64)
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
+    if _dev_seed(seed):
+        if sfx != "f32":
+            raise L.DransacError("device seeds: f32 logits")
+        L.call("dr_topdown_sample_f32_dseed", ptr(logits), ptr(seed), c_int(P), c_int(B), c_int(N), c_int(k), ptr(ws), ptr(idx),
+               stream())
+        return idx
     L.call(f"dr_topdown_sample_{sfx}", ptr(logits), c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(N), c_int(k),
            ptr(ws), ptr(idx), stream())
     return idx
@@ -188,6 +231,9 @@ def topdown_sample(logits: Optional[torch.Tensor], B: int, k: int, seed: int = 0
 def uniform_sample(P: int, B: int, k: int, N: int, seed: int, device) -> torch.Tensor:
     """K1u: idx [P,B,k] int32 ~ U{0..N-2} (uniform_sampler.py:15-19 semantics)."""
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
+    if _dev_seed(seed):
+        L.call("dr_uniform_sample_dseed", ptr(seed), c_int(P), c_int(B), c_int(k), c_int(N), ptr(idx), stream())
+        return idx
     L.call("dr_uniform_sample", c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(k), c_int(N), ptr(idx),
            stream())
     return idx

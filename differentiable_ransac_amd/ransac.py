@@ -323,11 +323,23 @@ class BatchedRANSAC(object):
         self.eps = eps
         self.fmat = solver in ("f8", "f7")
         self._side = None
+        self._dev_seed = None
 
     def _next_seed(self):
+        if self._dev_seed is not None:       # seeds advanced on the device (device_seeds(): graph-capturable steps)
+            self.calls += 1
+            return self._dev_seed.next()
         s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
         self.calls += 1
         return s
+
+    def device_seeds(self, device):
+        """From the next call on the per-call seed is computed on the device (ops.DeviceSeed) -- the same sequence of seeds,
+        hence the same hypotheses, but nothing about a call depends on a host-side counter any more, so a call with
+        max_iterations <= ransac_batch_size (one round, no read-back) can be captured in a HIP graph and replayed
+        (differentiable_ransac_amd.graphs.GraphedStep)."""
+        self._dev_seed = ops.DeviceSeed(self.seed, device, self.calls)
+        return self
 
     def hypotheses(self, matches, logits, gumbels=None):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
@@ -477,13 +489,22 @@ class BatchedRANSAC3D(object):
         self.tau = tau
         self.seed = seed
         self.calls = 0
+        self._dev_seed = None
         self.flag = flag
         self.keep_masks = keep_masks
 
     def _next_seed(self):
+        if self._dev_seed is not None:
+            self.calls += 1
+            return self._dev_seed.next()
         s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
         self.calls += 1
         return s
+
+    def device_seeds(self, device):
+        """See BatchedRANSAC.device_seeds."""
+        self._dev_seed = ops.DeviceSeed(self.seed, device, self.calls)
+        return self
 
     def __call__(self, matches, logits, gumbels=None):
         P, N, _ = matches.shape

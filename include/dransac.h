@@ -85,6 +85,23 @@ int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int
  * Philox4x32-10(key = seed, counter = (j, b, p, 1)). */
 int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream);
 
+/* The samplers with the Philox key in DEVICE memory (`*seed_dev`, read when the kernel starts) -- for steps captured in a
+ * HIP graph, where a by-value seed would be frozen at capture time.  Same kernels, same streams of random numbers as the
+ * by-value entry points for equal seeds; in-kernel noise only (no explicit-noise / dense-output modes).
+ * dr_seed_next: state[0] = base, state[1] = number of calls so far -> *seed_out = base * 0x9E3779B97F4A7C15 + calls
+ * (mod 2^64), calls += 1: the per-call seed of the batched drivers (ransac.py of this package: `_next_seed`), advanced on
+ * the device so that every replay of a captured step draws fresh hypotheses. */
+int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream);
+int dr_gumbel_topk_fwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
+                                 int32_t *idx, float *y_sel, float *lse, void *stream);
+int dr_gumbel_topk_fwd_f64_dseed(const double *logits, const uint64_t *seed_dev, double tau, int P, int B, int N, int k,
+                                 int32_t *idx, double *y_sel, double *lse, void *stream);
+int dr_gumbel_topk_bwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
+                                 const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits, void *stream);
+int dr_topdown_sample_f32_dseed(const float *logits, const uint64_t *seed_dev, int P, int B, int N, int k, double *cdf_ws,
+                                int32_t *idx, void *stream);
+int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  straight-through gather          RANSAC.__call__, ransac.py:58-65 (+ :73 weighted)
  *   samples[p,b,j,:] = matches[p, idx[p,b,j], :] * st[p,b,j],  st = (1 - y_sel) + y_sel  (f32 rounding
