@@ -2,7 +2,7 @@
   build (CPU box): python scratch/ab_k4nt.py --build      run (GPU box): python scratch/ab_k4nt.py"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
-VARIANTS = {'base': [], 'waves5': ['-DDR_K4_WAVES=5'], 'waves6': ['-DDR_K4_WAVES=6'], 'waves3': ['-DDR_K4_WAVES=3']}
+VARIANTS = {'base': [], 'nopre': ['-DDR_K4_PRECHECK=0']}
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
