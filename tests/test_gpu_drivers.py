@@ -160,6 +160,17 @@ def test_fivepoint_backward_finite_difference(dev):
     assert int(v2.sum()) == int(valid.sum())
     (E2 ** 2 * v2[..., None, None]).sum().backward()
     assert torch.isfinite(s32b.grad).all()
+    # ... and must give the Nister path's gradient for a loss that does not depend on the order or sign of the solutions
+    Wc = torch.tensor([[0.3, -1.2, 0.7], [1.1, 0.4, -0.6], [-0.9, 0.8, 1.5]], device=dev)
+    grads = {}
+    for solver in ("nister", "stewenius"):
+        s_ = smp.float().to(dev).clone().requires_grad_(True)
+        E_, v_ = ops.solve_essential(s_, None, solver)
+        ((E_ ** 2 * Wc) * v_[..., None, None]).sum().backward()
+        grads[solver] = s_.grad
+    scale = grads["nister"].abs().amax((-1, -2)).clamp(min=1e-6)
+    rel = (grads["nister"] - grads["stewenius"]).abs().amax((-1, -2)) / scale
+    assert rel.median() < 1e-4 and rel.max() < 5e-2, (rel.median(), rel.max())
 
 
 def test_batched_train_path_runs_and_is_finite(dev):
