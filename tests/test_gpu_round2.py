@@ -292,6 +292,7 @@ def test_batched_ransac3d(dev):
 # ---------------------------------------------------------------------------------------------------- harness
 @pytest.mark.parametrize("argv", ["-nf 2000 -bs 4 -rbs 256 -fmat 0 -sam 2 -tr 0 -t 0.75 --batches 1",
                                   "-nf 2000 -bs 4 -rbs 256 -fmat 0 -sam 2 -tr 1 -w2 1 -t 0.75 --batches 1",
+                                  "-nf 2000 -bs 4 -rbs 256 -fmat 0 -sam 2 -tr 1 -w2 1 -t 0.75 --batches 1 --per-pair-loss",
                                   "-nf 1000 -bs 2 -rbs 128 -fmat 1 -sam 3 -tr 0 -t 2 --batches 1",
                                   "-nf 2000 -bs 2 -rbs 128 -sam 2 -tr 1 --three-d --batches 1"])
 def test_flag_compatible_harness(dev, argv):

@@ -62,6 +62,9 @@ def create_parser():
     # additions of this harness
     add("--three-d", action="store_true", help="3-D registration path (train_point.py): RANSACLayer3D's solver on [N,6] pairs")
     add("--batches", type=int, default=3, help="timed batches of -bs pairs")
+    add("--per-pair-loss", action="store_true",
+        help="-tr 1, E branch: compute MatchLoss pair by pair on the NaN-filtered per-pair model lists the reference's forward "
+             "returns (train.py:70-79), instead of one batched MatchLoss over the driver's [P,B,3,3] output")
     add("--seed", type=int, default=0)
     return ap
 
@@ -117,9 +120,18 @@ def run(opt):
     rec = {"flags": {k: getattr(opt, k) for k in ("nfeatures", "batch_size", "ransac_batch_size", "fmat", "sampler", "tr",
                                                   "threshold", "weighted", "precision")},
            "ignored_arguments": opt.ignored, "input": b["source"]}
+    batched_loss = bool(opt.tr) and not opt.three_d and not opt.fmat and not opt.per_pair_loss and b.get("inliers") is not None
     if opt.three_d:
         drv = BatchedRANSAC3D(opt.ransac_batch_size, train=bool(opt.tr), max_iterations=1000 if opt.tr else opt.ransac_batch_size)
         call = lambda: drv(b["points"], weights)
+    elif batched_loss:
+        # the same driver batched_forward builds (model_cl.py:213-219: 100 iterations in train mode = one batch at -rbs >= 100)
+        from differentiable_ransac_amd.ransac import BatchedRANSAC
+        from differentiable_ransac_amd.loss import MatchLoss
+        drv = BatchedRANSAC("nister", ransac_batch_size=opt.ransac_batch_size, train=True, threshold=opt.threshold,
+                            max_iterations=100, weighted=opt.weighted)
+        ml = MatchLoss()
+        call = lambda: drv(b["points"], weights, b["K1"], b["K2"], gt_model=b["gt"])
     else:
         call = lambda: layers.batched_forward(opt, b["points"], weights, b["K1"], b["K2"], b.get("im1"), b.get("im2"),
                                               b["gt"] if opt.tr else None)
@@ -129,7 +141,9 @@ def run(opt):
     for _ in range(opt.batches):
         out = call()
         if opt.tr:
-            if opt.three_d:
+            if batched_loss:
+                loss = ml(out[0], b["points"], b["inliers"], out[1])     # -w2 1 over all pairs at once
+            elif opt.three_d:
                 loss = out["mean_residuals"].mean()       # train_point.py:28
             elif opt.fmat:
                 # sign-invariant distance to the ground-truth F of the kept models (the reference's F losses need OpenCV)
@@ -146,7 +160,10 @@ def run(opt):
     dt = time.perf_counter() - t0
     rec.update(pairs_per_s=P * opt.batches / dt, seconds_per_pair=dt / (P * opt.batches), pairs=P, points=N,
                hypotheses_per_pair_per_round=opt.ransac_batch_size)
-    if opt.three_d:
+    if batched_loss:
+        rec["returns"] = {"models [P,B,3,3]": list(out[0].shape), "keep [P,B]": list(out[1].shape),
+                          "loss": "one MatchLoss over the batch (--per-pair-loss: the reference's per-pair lists)"}
+    elif opt.three_d:
         rec["returns"] = {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}
     else:
         rec["returns"] = {"models_per_pair": [list(e.shape) for e in out[0][:4]], "seconds_per_pair_reported": out[1]}
