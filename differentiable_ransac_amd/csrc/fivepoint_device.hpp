@@ -276,22 +276,23 @@ __device__ __forceinline__ bool finish_solution(const double (&nb)[4][9], double
 // (sample, half) = verified ones before it in this round, by ballot, + the running count kept in LDS).
 // Block = ONE wave, so LDS traffic is ordered by program order and no barrier is needed.
 struct FinishQueue {
-  double *nb_lds;    // 36 x 32 doubles
-  double *q;         // 3 x 320 doubles: x | y | z of the candidates
-  uint16_t *meta;    // 320: source lane | candidate flag << 6
+  const double *nb_src;   // basis of sample j, element e = 9 t + q:  nb_src[e * 32 + j]  (LDS, element-major: conflict-free)
+  double *nb_lds;
+  double *u;         // 4 x 320: the candidates' coefficient vectors (unit 4-vectors; (0.5, 0.5, 0.5, 0.5) for non-finite ones)
+  uint16_t *meta;    // 320: source lane | finite-candidate flag << 6
   int *cnt;          // 64: verified solutions so far of (sample, half) = source lane
-  double *u;         // 4 x 320: the candidates' current coefficient vectors
   uint16_t *live;    // 2 x 320: candidates that need another Gauss-Newton step (this round | next round)
-  static constexpr int kDoubles = 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2 + 4 * 320 + 2 * 320 / 4;
+  static constexpr int kQueueDoubles = 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4;
+  static constexpr int kDoubles = 36 * 32 + kQueueDoubles;
   __device__ __forceinline__ explicit FinishQueue(double *lds)
-      : nb_lds(lds), q(lds + 36 * 32), meta(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 3 * 320)),
-        cnt(reinterpret_cast<int *>(lds + 36 * 32 + 3 * 320 + 320 / 4)), u(lds + 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2),
-        live(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 3 * 320 + 320 / 4 + 64 / 2 + 4 * 320)) {}
+      : nb_src(lds), nb_lds(lds), u(lds + 36 * 32), meta(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 4 * 320)),
+        cnt(reinterpret_cast<int *>(lds + 36 * 32 + 4 * 320 + 320 / 4)),
+        live(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 4 * 320 + 320 / 4 + 64 / 2)) {}
   __device__ __forceinline__ void load_basis(int j, double (&nb)[4][9]) const {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int qq = 0; qq < 9; ++qq) nb[t][qq] = nb_lds[(9 * t + qq) * 32 + j];
+      for (int qq = 0; qq < 9; ++qq) nb[t][qq] = nb_src[(9 * t + qq) * 32 + j];
   }
 };
 
@@ -325,11 +326,16 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
   const int off = incl - n;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
+    if (!__any(i < n)) continue;
+    // start vector (x, y, z, 1) / |.| ; a non-finite candidate keeps a harmless placeholder and never counts
+    const double x = xs[i], y = ys[i], z = zs[i];
+    const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+    double u0[4] = {x * inv, y * inv, z * inv, inv};
+    const bool good = ((cand >> i) & 1u) && is_finite(u0[0]) && is_finite(u0[1]) && is_finite(u0[2]) && is_finite(u0[3]);
     if (i < n) {
-      fq.q[off + i] = xs[i];
-      fq.q[320 + off + i] = ys[i];
-      fq.q[640 + off + i] = zs[i];
-      fq.meta[off + i] = (uint16_t)(lane | (((cand >> i) & 1u) << 6));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fq.u[k * 320 + off + i] = good ? u0[k] : 0.5;
+      fq.meta[off + i] = (uint16_t)(lane | (good ? 1u << 6 : 0u));
     }
   }
   fq.cnt[lane] = 0;
@@ -345,22 +351,19 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     const int e = base + lane;
     const bool has = e < total;
     const int ec = has ? e : total - 1;
-    const double x = fq.q[ec], y = fq.q[320 + ec], z = fq.q[640 + ec];
     const unsigned m = fq.meta[ec];
-    double nb[4][9];
+    double nb[4][9], u[4];
     fq.load_basis((m & 63) >> 1, nb);
-    const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
-    double u[4] = {x * inv, y * inv, z * inv, inv};
-    const bool good = has && ((m >> 6) & 1u) && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
-    if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = fq.u[k * 320 + ec];
+    const bool good = has && ((m >> 6) & 1u);
     double un[4], n0, n1;
     polish_step(nb, u, un, n0, n1);
     const bool better = n1 <= n0 && is_finite(n1);
     const bool lv = good && better && (n1 > tol2) && (n1 < 0.25 * n0);
-    if (has) {
+    if (has && better) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) fq.u[k * 320 + e] = better ? un[k] : u[k];
-      fq.meta[e] = (uint16_t)((m & 63) | (good ? 1u << 6 : 0u));   // bit 6 from here on: finite candidate
+      for (int k = 0; k < 4; ++k) fq.u[k * 320 + e] = un[k];
     }
     const unsigned long long bm = __ballot(lv);
     if (lv) fq.live[nlive + mbcnt(bm)] = (uint16_t)e;
@@ -556,6 +559,85 @@ constexpr int kmax(int a, int b) { return a > b ? a : b; }
 constexpr int kNisterPairDoubles =
     kmax(100 * 32, kmax(FinishQueue::kDoubles, kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0)));
 
+// B(z) (rows k = e - z f, l = g - z h, m = i - z j of the reduced system; columns x: degree 3, y: degree 3, 1: degree 4) as
+// 39 doubles bz[13 r + (0..3 | 4..7 | 8..12)] and its determinant's coefficients cs[0..10] (ascending)
+__device__ __forceinline__ void nister_bz_det(const double (&X)[6][10], double (&bz)[39], double (&cs)[11]) {
+  double bx[3][4], by[3][4], b1[3][5];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double(&hi)[10] = X[2 * r];
+    const double(&lo)[10] = X[2 * r + 1];
+    bx[r][0] = hi[2]; bx[r][1] = hi[1] - lo[2]; bx[r][2] = hi[0] - lo[1]; bx[r][3] = -lo[0];
+    by[r][0] = hi[5]; by[r][1] = hi[4] - lo[5]; by[r][2] = hi[3] - lo[4]; by[r][3] = -lo[3];
+    b1[r][0] = hi[9]; b1[r][1] = hi[8] - lo[9]; b1[r][2] = hi[7] - lo[8]; b1[r][3] = hi[6] - lo[7];
+    b1[r][4] = -lo[6];
+  }
+#pragma unroll
+  for (int i = 0; i < 11; ++i) cs[i] = 0;
+  auto minor_acc = [&](int a, int b, int r, double sgn) {
+    double mn[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) mn[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mn[i + j] += bx[a][i] * by[b][j] - bx[b][i] * by[a][j];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) cs[i + j] += sgn * mn[i] * b1[r][j];
+  };
+  minor_acc(1, 2, 0, 1.0);
+  minor_acc(0, 2, 1, -1.0);
+  minor_acc(0, 1, 2, 1.0);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bz[13 * r + i] = bx[r][i];
+      bz[13 * r + 4 + i] = by[r][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) bz[13 * r + 8 + i] = b1[r][i];
+  }
+}
+
+// (x, y) of every root z of this lane: null vector of B(z) by the best-conditioned cross product of two rows
+__device__ __forceinline__ void nister_xy_of_roots(const double (&bz)[39], const double (&roots)[10], int nroots, double (&xs)[10],
+                                                   double (&ys)[10], unsigned &cand) {
+  cand = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    xs[i] = 0;
+    ys[i] = 0;
+    if (!__any(i < nroots)) continue;
+    const double z = roots[i];
+    double rx[3], ry[3], r1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double *bx = bz + 13 * r, *by = bz + 13 * r + 4, *b1 = bz + 13 * r + 8;
+      rx[r] = ((bx[3] * z + bx[2]) * z + bx[1]) * z + bx[0];
+      ry[r] = ((by[3] * z + by[2]) * z + by[1]) * z + by[0];
+      r1[r] = (((b1[4] * z + b1[3]) * z + b1[2]) * z + b1[1]) * z + b1[0];
+    }
+    double bestn = -1, vx = 0, vy = 0, vw = 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 3; ++b) {
+        const double cx = ry[a] * r1[b] - r1[a] * ry[b];
+        const double cy = r1[a] * rx[b] - rx[a] * r1[b];
+        const double cw = rx[a] * ry[b] - ry[a] * rx[b];
+        const double nn = cw * cw;  // we divide by the w component: pick the largest
+        if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
+      }
+    const double x = vx / vw, y = vy / vw;
+    xs[i] = x;
+    ys[i] = y;
+    if (is_finite(x) && is_finite(y)) cand |= 1u << i;
+  }
+}
+
 // Two lanes per sample, balanced final stage (see balanced_finish).  LDS use after the constraint solve: the basis (36
 // doubles per sample) for the whole stage; B(z) (39 doubles per sample) only across the root search, where it would
 // otherwise occupy 78 registers -- the candidate queue reuses that space afterwards.
@@ -567,47 +649,13 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
   const int half = lane & 1;
   park_basis(fq, nb, lane);
   double cs[11];
-  double *bz = fq.q + (lane >> 1);   // B(z): element k of sample j at bz[k * 32]
+  double *bzl = fq.u + (lane >> 1);   // B(z): element k of sample j at bzl[k * 32] (the queue's space, later)
   {
-    double bx[3][4], by[3][4], b1[3][5];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const double(&hi)[10] = X[2 * r];
-      const double(&lo)[10] = X[2 * r + 1];
-      bx[r][0] = hi[2]; bx[r][1] = hi[1] - lo[2]; bx[r][2] = hi[0] - lo[1]; bx[r][3] = -lo[0];
-      by[r][0] = hi[5]; by[r][1] = hi[4] - lo[5]; by[r][2] = hi[3] - lo[4]; by[r][3] = -lo[3];
-      b1[r][0] = hi[9]; b1[r][1] = hi[8] - lo[9]; b1[r][2] = hi[7] - lo[8]; b1[r][3] = hi[6] - lo[7];
-      b1[r][4] = -lo[6];
-    }
-#pragma unroll
-    for (int i = 0; i < 11; ++i) cs[i] = 0;
-    auto minor_acc = [&](int a, int b, int r, double sgn) {
-      double mn[7];
-#pragma unroll
-      for (int i = 0; i < 7; ++i) mn[i] = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mn[i + j] += bx[a][i] * by[b][j] - bx[b][i] * by[a][j];
-#pragma unroll
-      for (int i = 0; i < 7; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) cs[i + j] += sgn * mn[i] * b1[r][j];
-    };
-    minor_acc(1, 2, 0, 1.0);
-    minor_acc(0, 2, 1, -1.0);
-    minor_acc(0, 1, 2, 1.0);
+    double bz[39];
+    nister_bz_det(X, bz, cs);
     if (half == 0) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          bz[(13 * r + i) * 32] = bx[r][i];
-          bz[(13 * r + 4 + i) * 32] = by[r][i];
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) bz[(13 * r + 8 + i) * 32] = b1[r][i];
-      }
+      for (int k = 0; k < 39; ++k) bzl[k * 32] = bz[k];
     }
   }
   double roots[10];
@@ -621,49 +669,12 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
   DR_STAGE(3);
   if (!ok || !active) nroots = 0;
   double xs[10], ys[10];
-  unsigned cand = 0;
+  unsigned cand;
   {
-    double bx[3][4], by[3][4], b1[3][5];
+    double bz[39];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bx[r][i] = bz[(13 * r + i) * 32];
-        by[r][i] = bz[(13 * r + 4 + i) * 32];
-      }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) b1[r][i] = bz[(13 * r + 8 + i) * 32];
-    }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      xs[i] = 0;
-      ys[i] = 0;
-      if (!__any(i < nroots)) continue;
-      const double z = roots[i];
-      // rows of B(z): (bx(z), by(z), b1(z)) . (x, y, 1) = 0 ; null vector = best-conditioned cross product
-      double rx[3], ry[3], r1[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        rx[r] = ((bx[r][3] * z + bx[r][2]) * z + bx[r][1]) * z + bx[r][0];
-        ry[r] = ((by[r][3] * z + by[r][2]) * z + by[r][1]) * z + by[r][0];
-        r1[r] = (((b1[r][4] * z + b1[r][3]) * z + b1[r][2]) * z + b1[r][1]) * z + b1[r][0];
-      }
-      double bestn = -1, vx = 0, vy = 0, vw = 1;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = a + 1; b < 3; ++b) {
-          const double cx = ry[a] * r1[b] - r1[a] * ry[b];
-          const double cy = r1[a] * rx[b] - rx[a] * r1[b];
-          const double cw = rx[a] * ry[b] - ry[a] * rx[b];
-          const double nn = cw * cw;  // we divide by the w component: pick the largest
-          if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
-        }
-      const double x = vx / vw, y = vy / vw;
-      xs[i] = x;
-      ys[i] = y;
-      if (is_finite(x) && is_finite(y)) cand |= 1u << i;
-    }
+    for (int k = 0; k < 39; ++k) bz[k] = bzl[k * 32];
+    nister_xy_of_roots(bz, roots, nroots, xs, ys, cand);
   }
   DR_STAGE(4);
   balanced_finish<T>(fq, lane, nroots, xs, ys, roots, cand, s0, active, models, valid, models64);

@@ -4,7 +4,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-variants = {'wave': [], 'wave_v1': [], 'wave_v2': [], 'wave_v3': [], 'nosplit': ['-DDR_ROOT_SPLIT=0'], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
+variants = {'wave': [], 'back1': ['-DDR_K3_BACK_WAVES=1'], 'wave_v1': [], 'wave_v2': [], 'wave_v3': [], 'wave_v4': [], 'nosplit': ['-DDR_ROOT_SPLIT=0'], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
             'old': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVE_ROOTS=0'], 'old_w2': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVES=2'], 'bal': [], 'bal_w2': ['-DDR_K3_WAVES=2'],
             'old_prof': ['-DDR_K3_BALANCED=0', '-DDR_PROFILE_STAGES'], 'bal_prof': ['-DDR_PROFILE_STAGES'],
             'f32low': ['-DDR_ROOT_F32_LOW=1'], 'f32low_w2': ['-DDR_ROOT_F32_LOW=1', '-DDR_K3_WAVES=2'], 'f32low_prof': ['-DDR_ROOT_F32_LOW=1', '-DDR_PROFILE_STAGES']}
@@ -19,7 +19,7 @@ import torch
 from differentiable_ransac_amd import ops, synth
 from oracle import cpu_ref as O
 dev = 'cuda'; N, B = 2000, 1024
-for P in (32, 128):
+for P in (32, 64, 128):
     d = synth.batch_two_view(P, N)
     m = d['matches'].to(dev)
     r = ops.gumbel_topk(d['logits'].to(dev), B, 5, 1.0, None, seed=1)
@@ -30,11 +30,15 @@ for P in (32, 128):
     ref = {}
     for name in names:
         lib = ctypes.CDLL(f'{ROOT}/scratch/libk3_{name}.so')
-        for solver in ('nister5', 'stewenius5'):
+        for solver in ('nister5', 'nister5_split', 'stewenius5'):
+            if solver == 'nister5_split' and not hasattr(lib, 'dr_solve_nister5_f32_split'): continue
             models = torch.empty(Bt, 10, 9, device=dev); valid = torch.empty(Bt, 10, device=dev, dtype=torch.uint8)
             cp = lambda t: ctypes.c_void_p(t.data_ptr())
             if solver == 'nister5':
                 f = lambda: lib.dr_solve_nister5_f32(cp(smp), None, Bt, 5, cp(models), cp(valid), None)
+            elif solver == 'nister5_split':
+                wsb = torch.empty(Bt * 88, device=dev, dtype=torch.float64)
+                f = lambda: lib.dr_solve_nister5_f32_split(cp(smp), None, Bt, cp(models), None, cp(valid), cp(wsb), None)
             else:
                 f = lambda: lib.dr_solve_stewenius5_f32(cp(smp), Bt, cp(models), cp(valid), None)
             assert f() == 0; torch.cuda.synchronize()
@@ -53,8 +57,9 @@ for P in (32, 128):
                 dist = O.match_solution_sets(Eo[i], oko[i], Eg[i], vg[i])
                 total += dist.numel(); found += int((dist < 1e-4).sum()); worst.append(dist)
             w = torch.cat(worst)
-            if solver not in ref: ref[solver] = (models.clone(), valid.clone())
-            rm, rv = ref[solver]
+            rkey = 'nister5' if solver == 'nister5_split' else solver
+            if rkey not in ref: ref[rkey] = (models.clone(), valid.clone())
+            rm, rv = ref[rkey]
             same = f'vs first: valid mismatches {(rv != valid).sum().item()}, models max|d| {(rm - models).abs().max().item():.2e}'
             print(f'P={P:4d} {name:16s} {solver:11s}: {us:7.1f} us   valid/sample {valid.float().sum().item()/Bt:.3f}   oracle solutions within 1e-4: '
                   f'{found}/{total}   p99 {w.kthvalue(int(0.99*w.numel())).values:.2e}   {same}', flush=True)
