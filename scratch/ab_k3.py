@@ -4,7 +4,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-variants = {'wave': [], 'back1': ['-DDR_K3_BACK_WAVES=1'], 'wave_v1': [], 'wave_v2': [], 'wave_v3': [], 'wave_v4': [], 'nosplit': ['-DDR_ROOT_SPLIT=0'], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
+variants = {'wave': [], 'f32hack_w1': [], 'f32hack_w2': [], 'back1': ['-DDR_K3_BACK_WAVES=1'], 'wave_v1': [], 'wave_v2': [], 'wave_v3': [], 'wave_v4': [], 'nosplit': ['-DDR_ROOT_SPLIT=0'], 'wave_prof': ['-DDR_PROFILE_STAGES'], 'bal_only': ['-DDR_K3_WAVE_ROOTS=0'], 'wave_w2': ['-DDR_K3_WAVES=2'],
             'old': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVE_ROOTS=0'], 'old_w2': ['-DDR_K3_BALANCED=0', '-DDR_K3_WAVES=2'], 'bal': [], 'bal_w2': ['-DDR_K3_WAVES=2'],
             'old_prof': ['-DDR_K3_BALANCED=0', '-DDR_PROFILE_STAGES'], 'bal_prof': ['-DDR_PROFILE_STAGES'],
             'f32low': ['-DDR_ROOT_F32_LOW=1'], 'f32low_w2': ['-DDR_ROOT_F32_LOW=1', '-DDR_K3_WAVES=2'], 'f32low_prof': ['-DDR_ROOT_F32_LOW=1', '-DDR_PROFILE_STAGES']}
@@ -19,7 +19,7 @@ import torch
 from differentiable_ransac_amd import ops, synth
 from oracle import cpu_ref as O
 dev = 'cuda'; N, B = 2000, 1024
-for P in (32, 64, 128):
+for P in (32, 128):
     d = synth.batch_two_view(P, N)
     m = d['matches'].to(dev)
     r = ops.gumbel_topk(d['logits'].to(dev), B, 5, 1.0, None, seed=1)
@@ -30,7 +30,7 @@ for P in (32, 64, 128):
     ref = {}
     for name in names:
         lib = ctypes.CDLL(f'{ROOT}/scratch/libk3_{name}.so')
-        for solver in ('nister5', 'nister5_split', 'stewenius5'):
+        for solver in ('nister5', 'stewenius5'):
             if solver == 'nister5_split' and not hasattr(lib, 'dr_solve_nister5_f32_split'): continue
             models = torch.empty(Bt, 10, 9, device=dev); valid = torch.empty(Bt, 10, device=dev, dtype=torch.uint8)
             cp = lambda t: ctypes.c_void_p(t.data_ptr())
