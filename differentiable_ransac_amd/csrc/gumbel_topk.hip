@@ -436,6 +436,114 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   if (kSoft && lane == 0) lse_out[row] = lse;
 }
 
+// ---- rows longer than the register kernel holds (N > 2048): ONE pass ----------------------------------------------------
+// The general kernel above makes two passes over a row that does not fit its LDS cache -- lane maxima first, then the
+// candidates above the k-th largest lane maximum -- and generates the Philox noise of every element twice.  Here a lane keeps
+// the K largest (value, index) pairs of the elements it has seen (sorted, in registers; the insertion code runs only in
+// iterations where some lane of the wave has a new entry: ~60 % of them at N = 50 000, K = 3) and the wave merges the 64
+// lists at the end by k rounds of arg-max over the lanes' heads.  Same Philox counters, same g, same order (value
+// descending, index ascending): the index sets are those of the general kernel (tests/test_gpu_round2.py).
+// f32, in-kernel noise, logits given, tau = 1, N % 4 == 0, no dense outputs.
+#ifndef DR_K1_STREAM
+#define DR_K1_STREAM 1   // 0: the general two-pass kernel (A/B builds)
+#endif
+template <int K, bool kSoft>
+__global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(const float *__restrict__ logits, uint64_t seed, int B,
+                                                                               int N, int k, int32_t *__restrict__ idx,
+                                                                               float *__restrict__ y_sel, float *__restrict__ lse_out,
+                                                                               const uint64_t *__restrict__ seed_ptr) {
+  if (seed_ptr) seed = *seed_ptr;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
+  if (b >= B) return;
+  const int groups = N >> 2;
+  const size_t row = (size_t)p * B + b;
+  const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
+  float tv[K];
+  int ti[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { tv[s] = -INFINITY; ti[s] = 0x7fffffff; }
+  float mx = -INFINITY, sm = 0.f;
+  for (int q = lane; q < groups; q += 64) {
+    uint32_t r[4];
+    Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+    const float4 l = lg[q];
+    const float g[4] = {l.x + gumbel_from_bits(r[0]), l.y + gumbel_from_bits(r[1]), l.z + gumbel_from_bits(r[2]),
+                        l.w + gumbel_from_bits(r[3])};
+    const float gm = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
+    if (kSoft) {
+      if (gm > mx) { sm *= exp_t<float>(mx - gm); mx = gm; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sm += exp_t<float>(g[j] - mx);
+    }
+    // a lane's elements arrive in ascending index order, so a new element displaces only strictly smaller values
+    if (!__ballot(gm > tv[K - 1])) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = g[j];
+      const int n = 4 * q + j;
+      bool prev = false;   // v > tv[s - 1]
+      float pv = 0.f;      // tv[s - 1] before the update
+      int pi = 0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        const bool c = v > tv[s];
+        const float ov = tv[s];
+        const int oi = ti[s];
+        tv[s] = c ? (prev ? pv : v) : ov;
+        ti[s] = c ? (prev ? pi : n) : oi;
+        prev = c; pv = ov; pi = oi;
+      }
+    }
+  }
+  float wmx = 0.f, lse = 0.f, inv_sm = 0.f;
+  if (kSoft) {
+    wmx = row_max(mx);
+    sm *= (mx == -INFINITY) ? 0.f : exp_t<float>(mx - wmx);
+    sm = row_sum(sm);
+    lse = wmx + log_t<float>(sm);
+    inv_sm = 1.0f / sm;
+  }
+  // merge: k rounds of (value desc, index asc) arg-max over the lanes' heads; the winning lane pops its head
+  int won[kMaxK];
+  float wong[kMaxK];
+  for (int r = 0; r < k; ++r) {
+    float bv = tv[0];
+    int bi = ti[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    won[r] = bi;
+    wong[r] = bv;
+    if (ti[0] == bi) {
+#pragma unroll
+      for (int s = 0; s + 1 < K; ++s) { tv[s] = tv[s + 1]; ti[s] = ti[s + 1]; }
+      tv[K - 1] = -INFINITY;
+      ti[K - 1] = 0x7fffffff;
+    }
+  }
+  if (lane < k) {
+    int me = 0;
+    float mg = 0.f;
+    for (int r = 0; r < k; ++r) if (r == lane) { me = won[r]; mg = wong[r]; }
+    int pos = 0;
+    for (int r = 0; r < k; ++r) pos += won[r] < me;
+    idx[row * k + pos] = me;
+    if (kSoft) y_sel[row * k + pos] = exp_t<float>(mg - wmx) * inv_sm;
+  }
+  if (kSoft && lane == 0) lse_out[row] = lse;
+}
+
+template <int K>
+static void stream_launch(bool soft, dim3 grid, dim3 block, hipStream_t st, const float *logits, uint64_t seed, int B, int N, int k,
+                          int32_t *idx, float *y_sel, float *lse, const uint64_t *seed_ptr) {
+  if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+}
+
 template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
@@ -456,6 +564,14 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
                            (float *)y_sel, (float *)lse, seed_ptr);
       return check_launch("gumbel_topk_fast_kernel");
+    }
+    // measured (scratch/ab_k1_stream.py): 50 000 x 2048 rows, k = 3: 226 -> 113 us; 4096 x 32 768 rows, k = 5: 196 -> 178 us;
+    // k = 8 lists cost what the second pass costs (256 vs 250 us at N = 20 000) -> the general kernel keeps k > 5
+    if (DR_K1_STREAM && logits && !gumbel && tau == T(1) && (N & 3) == 0 && N > 4 * 64 * kFastGroups && k <= 5 && !y_soft && !ret &&
+        !gumbel_out) {
+      if (k <= 3) stream_launch<3>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr);
+      else stream_launch<5>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr);
+      return check_launch("gumbel_topk_stream_kernel");
     }
   }
   if (base + cache <= 64 * 1024) {

@@ -219,6 +219,27 @@ def test_sampler_register_kernel_equals_general_kernel(dev, N, B, k):
     assert torch.equal(a["idx"], b_["idx"])
 
 
+@pytest.mark.parametrize("N,B,k", [(50000, 96, 3), (4096, 130, 5), (2052, 33, 8), (10000, 17, 1)])
+def test_sampler_single_pass_kernel_equals_general_kernel(dev, N, B, k):
+    """rows longer than the register kernel holds: the one-pass kernel (per-lane top-K lists, merged per wave) against the
+    general two-pass kernel (forced by asking for the noise) and, through that noise, against the oracle"""
+    from differentiable_ransac_amd import ops
+    P = 2
+    gen_ = torch.Generator().manual_seed(N + k)
+    logits = (torch.randn(P, N, generator=gen_) + 3.0 * (torch.rand(P, N, generator=gen_) > 0.5)).to(dev)
+    logits[0, :64] = 7.0                                                   # ties at the top: the index decides
+    for seed in (3, 2 ** 40 + 17):
+        one = ops.gumbel_topk(logits, B, k, 1.0, None, seed=seed)
+        gen = ops.gumbel_topk(logits, B, k, 1.0, None, seed=seed, want_noise=True)
+        assert torch.equal(one["idx"], gen["idx"])
+        assert torch.allclose(one["y_sel"], gen["y_sel"], rtol=5e-6, atol=1e-9) and torch.allclose(one["lse"], gen["lse"], rtol=2e-6, atol=2e-6)
+        assert torch.equal(ops.gumbel_topk(logits, B, k, 1.0, None, seed=seed, soft=False)["idx"], gen["idx"])
+        st = torch.tensor([seed], dtype=torch.int64, device=dev)           # device-resident seed: same kernel, same draws
+        assert torch.equal(ops.gumbel_topk(logits, B, k, 1.0, None, seed=st, soft=False)["idx"], gen["idx"])
+        oi, _, _ = O.gumbel_topk(logits[1].cpu(), gen["gumbel"][1].cpu(), 1.0, k)
+        assert torch.equal(oi.to(torch.int32), one["idx"][1].cpu())
+
+
 # ---------------------------------------------------------------------------------------------------- uniform sampler law
 def test_uniform_sampler_chi_square(dev):
     """dr_uniform_sample against the law of torch.randint(0, N - 1): uniform on 0 .. N - 2, the last point never drawn
