@@ -211,10 +211,106 @@ __global__ __launch_bounds__(kRThreads) void rigid_residual_kernel(const T *__re
   }
 }
 
+// f32, N % 16 == 0, masks wanted: a lane owns SIXTEEN consecutive points (96 VGPRs), 128-thread blocks, so that every mask
+// row segment is one 16-byte store per lane (1 KiB per wave instruction) and the per-model bookkeeping (reduction, model
+// fetch) is shared by twice as many points; DPP-only wave reduction, LDS atomic for the per-model partial.  Same arithmetic
+// per (model, point) as the kernel above, in the same order: identical masks, sums equal to rounding of the reduction order.
+// BASELINE config 4 (50 000 points x 2048 models): 80-86 -> see DESIGN.md section 6.
+#ifndef DR_K4R_16
+#define DR_K4R_16 1
+#endif
+constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts;
+typedef float v2r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2r rsplat(float a) { return (v2r){a, a}; }
+__global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(const float *__restrict__ pts, const float *__restrict__ models,
+                                                                           float threshold, int M, int N, float *__restrict__ res_sum,
+                                                                           uint8_t *__restrict__ masks, int chunks_per_block,
+                                                                           int use_atomic) {
+  __shared__ float part[kRModels];
+  const int p = blockIdx.z, m0 = blockIdx.x * kRModels;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int mcount = min(kRModels, M - m0);
+  const float *pt = pts + (size_t)p * N * 6;
+  const float *md = models + ((size_t)p * M + m0) * 16;
+  if (tid < kRModels) part[tid] = 0.f;
+  __syncthreads();
+  const int c_begin = blockIdx.y * chunks_per_block;
+  for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
+    if (c * kR16Chunk >= N) break;
+    const int n0 = c * kR16Chunk + tid * kR16Pts;
+    const bool have = n0 < N;   // N % 16 == 0: a lane's points are all inside or all outside
+    // points in PAIRS (component 0 / 1 = points 2 j / 2 j + 1 of the lane): the loop below is written in packed form, so the
+    // compiler has no operand pairs to assemble per model (its own vectoriser spent 178 v_mov per model doing that)
+    v2r xp[kR16Pts / 2][6];
+    {
+      float x[kR16Pts * 6];   // 16 points x 6 floats = 24 float4 per lane, contiguous
+      // lanes past the end read the row's first points instead (unconditional loads issue back to back; a predicated load
+      // each waited for the one before: 24 memory round trips per chunk) -- their results are never stored or summed
+      const float4 *src = reinterpret_cast<const float4 *>(pt + (size_t)(have ? n0 : 0) * 6);
+#pragma unroll
+      for (int v = 0; v < 24; ++v) {
+        const float4 w = src[v];
+        x[4 * v] = w.x; x[4 * v + 1] = w.y; x[4 * v + 2] = w.z; x[4 * v + 3] = w.w;
+      }
+#pragma unroll
+      for (int j = 0; j < kR16Pts / 2; ++j)
+#pragma unroll
+        for (int d = 0; d < 6; ++d) xp[j][d] = (v2r){x[12 * j + d], x[12 * j + 6 + d]};
+    }
+    for (int ml = 0; ml < mcount; ++ml) {
+      float m[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) m[q] = md[ml * 16 + q];
+      v2r acc2 = (v2r){0.f, 0.f};
+      uint32_t wq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < kR16Pts / 2; ++j) {
+        v2r d2 = (v2r){0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const v2r pred = xp[j][0] * rsplat(m[4 * i]) + (xp[j][1] * rsplat(m[4 * i + 1]) + (xp[j][2] * rsplat(m[4 * i + 2]) + rsplat(m[4 * i + 3])));
+          const v2r e = xp[j][3 + i] - pred;
+          d2 = e * e + d2;
+        }
+        acc2 = acc2 + d2;
+        wq[j >> 1] |= ((uint32_t)(d2[0] < threshold) | ((uint32_t)(d2[1] < threshold) << 8)) << (16 * (j & 1));
+      }
+      float acc = acc2[0] + acc2[1];
+      if (have) {
+        const uint4 q = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+        *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + ml) * N + n0) = q;
+      }
+      acc = wave_sum_lane63(have ? acc : 0.f);
+      if (lane == 63) atomicAdd(&part[ml], acc);
+    }
+  }
+  __syncthreads();
+  if (tid < mcount) {
+    float *dst = res_sum + (size_t)p * M + m0 + tid;
+    if (use_atomic) atomicAdd(dst, part[tid]);
+    else *dst = part[tid];
+  }
+}
+
 template <typename T>
 int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int M, int N, T *res_sum, uint8_t *masks,
                           hipStream_t st) {
   const int tiles = (M + kRModels - 1) / kRModels;
+  if constexpr (sizeof(T) == 4) {
+    if (DR_K4R_16 && masks && N % 16 == 0 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0) {
+      const int chunks = (N + kR16Chunk - 1) / kR16Chunk;
+      int ny = 1;
+      const long base = (long)P * tiles;
+      if (chunks > 1 && base < 4096) ny = (int)min((long)chunks, (4096 + base - 1) / base);
+      const int cpb = (chunks + ny - 1) / ny;
+      ny = (chunks + cpb - 1) / cpb;
+      const int use_atomic = ny > 1;
+      if (use_atomic && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
+      hipLaunchKernelGGL(rigid_residual_kernel_f32_16, dim3(tiles, ny, P), dim3(kR16Threads), 0, st, (const float *)pts,
+                         (const float *)models, (float)threshold, M, N, (float *)res_sum, masks, cpb, use_atomic);
+      return check_launch("rigid_residual_kernel_f32_16");
+    }
+  }
   const int chunks = (N + kRChunk - 1) / kRChunk;
   int ny = 1;
   const long base = (long)P * tiles;
