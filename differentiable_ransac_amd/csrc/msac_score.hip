@@ -439,7 +439,12 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 #ifndef DR_K4_TILE16
 #define DR_K4_TILE16 64   // model slots per block (multiple of 32)
 #endif
-constexpr int kT16 = 128, kP16 = 16, kChunk16 = kT16 * kP16;
+// DR_K4_HALVES = 2: a 256-thread block is two independent 128-thread halves, each with its own 64-slot model tile (nothing
+// shared but the workgroup slot): a CU holds at most 8 workgroups, i.e. 16 waves of 128-thread blocks = 4 waves per SIMD
+#ifndef DR_K4_HALVES
+#define DR_K4_HALVES 2
+#endif
+constexpr int kH16 = 128, kT16 = kH16 * DR_K4_HALVES, kP16 = 16, kChunk16 = kH16 * kP16;
 
 #ifndef DR_K4_WAVES
 #define DR_K4_WAVES 0   // A/B knob: > 0 pins the register budget to that many waves per SIMD (amdgpu_waves_per_eu)
@@ -459,14 +464,15 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
   constexpr int kTile = DR_K4_TILE16;
   __shared__ float part[kT16 / kWave][kTile];
   const int p = blockIdx.z;
-  const int m0 = blockIdx.x * kTile;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int mcount = min(kTile, M - m0);
+  const int half = threadIdx.x / kH16;                 // 0 unless DR_K4_HALVES = 2
+  const int m0 = (blockIdx.x * DR_K4_HALVES + half) * kTile;
+  const int tid = threadIdx.x % kH16, lane = tid & 63, wv = threadIdx.x >> 6;
+  const int mcount = max(0, min(kTile, M - m0));
   const float t = 1.5f * thr[p];
   const float inv_thr2 = 1.0f / (t * t);
   const float *mt = matches + (size_t)p * N * 4;
   const float *md = models + ((size_t)p * M + m0) * 9;
-  for (int i = tid; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
+  for (int i = threadIdx.x; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
   uint32_t vword[kTile / 32];
 #pragma unroll
   for (int w = 0; w < kTile / 32; ++w) {
@@ -544,8 +550,8 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
     }
   }
   __syncthreads();
-  for (int i = tid; i < mcount; i += kT16) {
-    const float v = part[0][i] + part[1][i];
+  for (int i = tid; i < mcount; i += kH16) {
+    const float v = part[2 * half][i] + part[2 * half + 1][i];
     float *dst = scores + (size_t)p * M + m0 + i;
     if (use_atomic) atomicAdd(dst, v);
     else *dst = v;
@@ -789,7 +795,7 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
                                 (float *)scores, masks, st);
   }
   const bool fast16 = kFast && DR_K4_FAST16 && (N % 16 == 0);
-  const int tile = fast16 ? DR_K4_TILE16 : (kFast ? kFastTile : kModelsPerBlock);
+  const int tile = fast16 ? DR_K4_TILE16 * DR_K4_HALVES : (kFast ? kFastTile : kModelsPerBlock);
   const int tiles = (M + tile - 1) / tile;
   const int chunks = (N + kChunk - 1) / kChunk;   // kChunk16 == kChunk
   // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip

@@ -2,7 +2,7 @@
   build (CPU box): python scratch/ab_k4nt.py --build      run (GPU box): python scratch/ab_k4nt.py"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
-VARIANTS = {'base': [], 'clamp': ['-DDR_K4_CLAMP=1']}
+VARIANTS = {'base': [], 'h1': ['-DDR_K4_HALVES=1']}
 if '--build' in sys.argv:
     for name, flags in VARIANTS.items():
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
