@@ -16,7 +16,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdransac.so")
+LIB_PATH = os.environ.get("DRANSAC_LIB") or os.path.join(_HERE, "libdransac.so")   # DRANSAC_LIB: A/B runs against another build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dransac.h")
 
 _lib: Optional[ctypes.CDLL] = None

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
   constexpr int kTile = DR_K4_TILE16;
   __shared__ float part[kT16 / kWave][kTile];
   const int p = blockIdx.z;
-  const int half = threadIdx.x / kH16;                 // 0 unless DR_K4_HALVES = 2
+  // wave-uniform BY CONSTRUCTION (a half is two whole waves) -- and it must look so to the compiler: with `half` in a VGPR the
+  // tile's model coefficients stop being scalar loads and the kernel is 40 % slower
+  const int half = DR_K4_HALVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kH16)) : 0;
   const int m0 = (blockIdx.x * DR_K4_HALVES + half) * kTile;
   const int tid = threadIdx.x % kH16, lane = tid & 63, wv = threadIdx.x >> 6;
   const int mcount = max(0, min(kTile, M - m0));
