@@ -187,6 +187,13 @@ __device__ __forceinline__ void mask_row_store(uint8_t *dst, uint32_t a, uint32_
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
+// 1: the soft-score term max(0, 1 - d2/thr2) comes out of ONE packed FMA with the clamp modifier (result clamped to [0, 1], NaN -> 0)
+// instead of fma + two v_min_i32: the same rounded values and the same inlier decisions (sign of the exact d2/thr2 - 1 either
+// way; masks and scores bit-identical on 164 M evaluations, scratch/k4_equal.py), scoring launch 0.644 -> 0.621 ms in the step.
+#ifndef DR_K4_CLAMP
+#define DR_K4_CLAMP 1
+#endif
+
 // A/B knobs (scratch/ab_k4.py builds one shared object per variant)
 #ifndef DR_K4_VARIANT
 #define DR_K4_VARIANT 6
@@ -414,6 +421,18 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
     v2f rc;
     rc[0] = __builtin_amdgcn_rcpf(jj[0]);
     rc[1] = __builtin_amdgcn_rcpf(jj[1]);
+#if DR_K4_CLAMP
+    // the soft-score term max(0, 1 - d2/thr2) itself, by the clamp modifier of the packed FMA ([0, 1]; NaN -> 0): the same
+    // rounded value as -min(d2/thr2 - 1, 0), one instruction per point pair instead of three; inlier <=> term > 0 <=> bit 5 of
+    // its top byte (biased exponent 64..127) is set.  nacc holds the NEGATED sum, as in the other form.
+    const v2f pq = rr * rc;
+    const v2f one = splat(1.0f), ith = splat(inv_thr2);
+    v2f c;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(c) : "v"(pq), "v"(ith), "v"(one));
+    sb[2 * j] = __float_as_uint(c[0]);
+    sb[2 * j + 1] = __float_as_uint(c[1]);
+    nacc = nacc - c;
+#else
     const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);
     sb[2 * j] = __float_as_uint(sv[0]);
     sb[2 * j + 1] = __float_as_uint(sv[1]);
@@ -421,13 +440,14 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
     mn[0] = __int_as_float(min((int)sb[2 * j], 0));
     mn[1] = __int_as_float(min((int)sb[2 * j + 1], 0));
     nacc = nacc + mn;
+#endif
   }
   uint32_t wq[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const uint32_t lo2 = __builtin_amdgcn_perm(sb[4 * g + 1], sb[4 * g], 0x0c0c0703u);
     const uint32_t hi2 = __builtin_amdgcn_perm(sb[4 * g + 3], sb[4 * g + 2], 0x07030c0cu);
-    wq[g] = finite ? (((lo2 | hi2) >> 7) & 0x01010101u) : 0u;
+    wq[g] = finite ? (((lo2 | hi2) >> (DR_K4_CLAMP ? 5 : 7)) & 0x01010101u) : 0u;
   }
   return make_uint4(wq[0], wq[1], wq[2], wq[3]);
 }
