@@ -466,6 +466,9 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 #endif
 constexpr int kH16 = 128, kT16 = kH16 * DR_K4_HALVES, kP16 = 16, kChunk16 = kH16 * kP16;
 
+#ifndef DR_K4_PRECHECK
+#define DR_K4_PRECHECK 1   // 16-point kernel: the finite / non-zero test of a tile's models once per block (prologue)
+#endif
 #ifndef DR_K4_WAVES
 #define DR_K4_WAVES 0   // A/B knob: > 0 pins the register budget to that many waves per SIMD (amdgpu_waves_per_eu)
 #endif
@@ -496,13 +499,40 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
   const float *md = models + ((size_t)p * M + m0) * 9;
   for (int i = threadIdx.x; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
   uint32_t vword[kTile / 32];
+#if DR_K4_PRECHECK
+  // non-finite / all-zero models of the tile are found here, once (lane l looks at slot l), instead of in every wave of
+  // every chunk: they leave the evaluated set (empty mask row like an invalid slot) and their score is NaN
+  uint32_t nanword[kTile / 32];
+#endif
 #pragma unroll
   for (int w = 0; w < kTile / 32; ++w) {
     const int ml = 32 * w + (lane & 31);
     const bool v = (ml < mcount) && (!valid || valid[(size_t)p * M + m0 + ml] != 0);
+#if DR_K4_PRECHECK
+    uint32_t ex = 0, anybit = 0;
+    if (v) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const uint32_t mb = __float_as_uint(md[ml * 9 + q]);
+        ex = max(ex, mb & 0x7f800000u);
+        anybit |= mb & 0x7fffffffu;
+      }
+    }
+    const bool bad = v && (ex == 0x7f800000u || anybit == 0u);
+    vword[w] = (uint32_t)(__ballot(v && !bad && lane < 32));
+    nanword[w] = (uint32_t)(__ballot(bad && lane < 32));
+#else
     vword[w] = (uint32_t)(__ballot(v && lane < 32));
+#endif
   }
   __syncthreads();
+#if DR_K4_PRECHECK
+  if ((wv & 1) == 0 && lane < 32) {
+#pragma unroll
+    for (int w = 0; w < kTile / 32; ++w)
+      if ((nanword[w] >> lane) & 1u) part[wv][32 * w + lane] = NAN;
+  }
+#endif
 
   const int c_begin = blockIdx.y * chunks_per_block;
   for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
@@ -538,6 +568,9 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
 #pragma unroll
           for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
         }
+#if DR_K4_PRECHECK
+        constexpr bool finite = true;   // the others never get here (prologue)
+#else
         uint32_t ex = 0, anybit = 0;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -548,6 +581,7 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
         // an all-zero model is treated like a non-finite one (score NaN, empty mask): the reference's 0/0 gives NaN
         // scores and `NaN < thr` = False masks (msac_score.py:42-48)
         const bool finite = ex != 0x7f800000u && anybit != 0u;
+#endif
         v2f nacc = splat(0.f);
         const uint4 q = msac_eval16(x1, y1, x2, y2, m, inv_thr2, finite, nacc);
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;
