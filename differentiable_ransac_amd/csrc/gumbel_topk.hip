@@ -300,7 +300,10 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
                                                                              int B, int N, int k, int32_t *__restrict__ idx,
                                                                              float *__restrict__ y_sel,
                                                                              float *__restrict__ lse_out,
-                                                                             const uint64_t *__restrict__ seed_ptr) {
+                                                                             const uint64_t *__restrict__ seed_ptr,
+                                                                             const float4 *__restrict__ gather_src = nullptr,
+                                                                             float4 *__restrict__ gather_dst = nullptr) {
+  // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
   if (seed_ptr) seed = *seed_ptr;
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
     if (win) {
       idx[row * k + pos] = ci;
       if (kSoft) y_sel[row * k + pos] = exp_t<float>(cv - wmx) * inv_sm;
+      if (!kSoft && gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + ci];
     }
   } else {
     // slow path (massive ties): k rounds of (value desc, index asc) arg-max with exclusion of earlier winners
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
       for (int r = 0; r < k; ++r) pos += won[r] < me;
       idx[row * k + pos] = me;
       if (kSoft) y_sel[row * k + pos] = exp_t<float>(mg - wmx) * inv_sm;
+      if (!kSoft && gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + me];
     }
   }
   if (kSoft && lane == 0) lse_out[row] = lse;
@@ -547,7 +552,9 @@ static void stream_launch(bool soft, dim3 grid, dim3 block, hipStream_t st, cons
 template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
-                      const uint64_t *seed_ptr = nullptr) {
+                      const uint64_t *seed_ptr = nullptr, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr,
+                      bool *gathered = nullptr) {
+  if (gathered) *gathered = false;
   GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
   const int groups = (N + 3) / 4;
   const size_t base = (size_t)kRowsPerBlock * kMaxCand * (sizeof(T) + sizeof(int));
@@ -561,8 +568,11 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
                            (float *)y_sel, (float *)lse, seed_ptr);
       else
+      {
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse, seed_ptr);
+                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst);
+        if (gathered) *gathered = gather_dst != nullptr;
+      }
       return check_launch("gumbel_topk_fast_kernel");
     }
     // measured (scratch/ab_k1_stream.py): 50 000 x 2048 rows, k = 3: 226 -> 113 us; 4096 x 32 768 rows, k = 5: 196 -> 178 us;
@@ -955,6 +965,25 @@ int dr_topdown_sample_f32_dseed(const float *logits, const uint64_t *seed_dev, i
 int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream) {
   DR_REQUIRE(seed_dev, "null seed pointer");
   return uniform_impl(0, seed_dev, P, B, k, N, idx, stream);
+}
+
+// K1 (index sets only) + K2 in one call: idx [P,B,k] and samples [P,B,k,4] = matches[p, idx] (test mode: the points themselves,
+// ransac.py:65).  One launch when the register kernel serves the shape, sampler + gather launches otherwise.
+int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
+                              int B, int N, int k, int32_t *idx, float *samples, void *stream) {
+  const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
+  DR_REQUIRE(logits && matches && samples, "null pointer");
+  DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
+  DR_GUMBEL_CHECK();
+  bool gathered = false;
+  if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                            (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
+                                            reinterpret_cast<float4 *>(samples), &gathered))
+    return rc;
+  if (gathered) return 0;
+  hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
+                     (const float *)nullptr, N, B * k, 4, samples);
+  return dr::check_launch("gather_fwd_kernel");
 }
 
 int dr_gather_fwd_f32(const float *matches, const int32_t *idx, const float *y_sel, int P, int N, int B, int k,

@@ -187,6 +187,22 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
     return out
 
 
+def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0):
+    """K1 (index sets only, in-kernel noise) + K2 in one call: matches [P,N,4] f32, logits [P,N] f32 ->
+    (idx [P,B,k] int32 ascending, samples [P,B,k,4] = matches[p, idx]).  What test mode asks of sampler + gather
+    (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor."""
+    if matches.dtype != torch.float32 or logits.dtype != torch.float32 or matches.shape[-1] != 4:
+        raise L.DransacError("gumbel_topk_gather: f32 two-view correspondences [P,N,4]")
+    matches, logits = matches.contiguous(), logits.contiguous()
+    P, N = logits.shape
+    idx = torch.empty((P, B, k), device=logits.device, dtype=torch.int32)
+    samples = torch.empty((P, B, k, 4), device=logits.device, dtype=torch.float32)
+    dev_seed = _dev_seed(seed)
+    L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
+           ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples), stream())
+    return idx, samples
+
+
 def gumbel_topk_bwd(logits, gumbel, seed, tau, idx, lse, a_sel):
     """grad_logits [P,N] from a_sel [P,B,k] (f32 only)."""
     P, B, k = idx.shape

@@ -352,8 +352,12 @@ class BatchedRANSAC(object):
         elif not self.train and not self.weighted:
             # test mode consumes the index sets only (`points[samples != 0]`, ransac.py:65): no soft-max statistics, and
             # the samples are the points themselves (not points x a straight-through value of 1 +- 1 ulp)
-            idx = ops.gumbel_topk(logits, self.B, self.k, self.tau, gumbels, self._next_seed(), soft=False)["idx"]
-            samples, w = ops.gather(matches, idx), None
+            if gumbels is None and matches.dtype == torch.float32 and logits.dtype == torch.float32 and matches.shape[-1] == 4:
+                idx, samples = ops.gumbel_topk_gather(matches, logits, self.B, self.k, self.tau, self._next_seed())   # one launch
+                w = None
+            else:
+                idx = ops.gumbel_topk(logits, self.B, self.k, self.tau, gumbels, self._next_seed(), soft=False)["idx"]
+                samples, w = ops.gather(matches, idx), None
         else:
             samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, self._next_seed())
         wts = w if self.weighted else None

@@ -102,6 +102,13 @@ int dr_topdown_sample_f32_dseed(const float *logits, const uint64_t *seed_dev, i
                                 int32_t *idx, void *stream);
 int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream);
 
+/* K1 in index-only mode + K2 in one call (test mode: `points[samples != 0]`, ransac.py:58-65, with in-kernel noise):
+ * idx [P,B,k] ascending and samples [P,B,k,4] = matches[p, idx] (c = 4; 16-byte aligned buffers).  seed_dev != NULL: the seed
+ * is read from device memory (see the *_dseed entry points), `seed` is ignored.  One launch when the register-resident
+ * sampler kernel serves the shape (N % 4 == 0, N <= 2048, tau == 1), sampler + gather launches otherwise. */
+int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
+                              int B, int N, int k, int32_t *idx, float *samples, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  straight-through gather          RANSAC.__call__, ransac.py:58-65 (+ :73 weighted)
  *   samples[p,b,j,:] = matches[p, idx[p,b,j], :] * st[p,b,j],  st = (1 - y_sel) + y_sel  (f32 rounding

@@ -240,6 +240,27 @@ def test_sampler_single_pass_kernel_equals_general_kernel(dev, N, B, k):
         assert torch.equal(oi.to(torch.int32), one["idx"][1].cpu())
 
 
+@pytest.mark.parametrize("N,B,k", [(2000, 300, 5), (128, 64, 8), (2050, 40, 5), (4096, 33, 3), (4096, 33, 8)])
+def test_sampler_with_fused_gather_equals_sampler_then_gather(dev, N, B, k):
+    """dr_gumbel_topk_gather: one launch where the register kernel serves the shape, two otherwise -- same index sets and
+    samples as gumbel_topk(soft=False) followed by gather; int and device-resident seeds"""
+    from differentiable_ransac_amd import ops
+    P = 3
+    g = torch.Generator().manual_seed(N + B)
+    lg = torch.randn(P, N, generator=g).to(dev)
+    m = torch.randn(P, N, 4, generator=g).to(dev)
+    for seed in (11, 2 ** 63 + 5):
+        idx0 = ops.gumbel_topk(lg, B, k, 1.0, None, seed, soft=False)["idx"]
+        smp0 = ops.gather(m, idx0)
+        idx1, smp1 = ops.gumbel_topk_gather(m, lg, B, k, 1.0, seed)
+        assert torch.equal(idx0, idx1) and torch.equal(smp0, smp1)
+        st = torch.tensor([seed - 2 ** 64 if seed >= 2 ** 63 else seed], dtype=torch.int64, device=dev)
+        idx2, smp2 = ops.gumbel_topk_gather(m, lg, B, k, 1.0, st)
+        assert torch.equal(idx0, idx2) and torch.equal(smp0, smp2)
+    with pytest.raises(Exception):
+        ops.gumbel_topk_gather(m.double(), lg.double(), B, k)
+
+
 # ---------------------------------------------------------------------------------------------------- uniform sampler law
 def test_uniform_sampler_chi_square(dev):
     """dr_uniform_sample against the law of torch.randint(0, N - 1): uniform on 0 .. N - 2, the last point never drawn
