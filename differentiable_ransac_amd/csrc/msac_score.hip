@@ -185,6 +185,17 @@ __device__ __forceinline__ void mask_row_store(uint8_t *dst, uint32_t a, uint32_
 #endif
 }
 
+// 16-byte store at (wave-uniform 64-bit base) + (per-lane unsigned 32-bit offset): the SGPR-base form of global_store, so that
+// the vector ALU computes no address (hipcc otherwise forms base + row * N + n0 per lane with a quarter-rate v_mad_u64_u32)
+__device__ __forceinline__ void mask_row_store_saddr(const uint8_t *base_uniform, uint32_t off, uint32_t a, uint32_t b, uint32_t c,
+                                                     uint32_t d) {
+  const uint64_t bb = reinterpret_cast<uint64_t>(base_uniform);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bb >> 32));
+  const uint64_t bs = ((uint64_t)hi << 32) | lo;
+  const u32x4 v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(v), "s"(bs) : "memory");
+}
+
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
 // 1: the soft-score term max(0, 1 - d2/thr2) comes out of ONE packed FMA with the clamp modifier (result clamped to [0, 1], NaN -> 0)
@@ -466,6 +477,9 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 #endif
 constexpr int kH16 = 128, kT16 = kH16 * DR_K4_HALVES, kP16 = 16, kChunk16 = kH16 * kP16;
 
+#ifndef DR_K4_SADDR
+#define DR_K4_SADDR 1   // mask rows stored through an SGPR base + 32-bit lane offset (in-step: scoring launch 0.610 -> 0.602 ms)
+#endif
 #ifndef DR_K4_PRECHECK
 #define DR_K4_PRECHECK 1   // 16-point kernel: the finite / non-zero test of a tile's models once per block (prologue)
 #endif
@@ -585,8 +599,15 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
         v2f nacc = splat(0.f);
         const uint4 q = msac_eval16(x1, y1, x2, y2, m, inv_thr2, finite, nacc);
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;
+#if DR_K4_SADDR
+        // row base = wave-uniform 64-bit address (scalar ALU), lane part = unsigned 32-bit offset: the store takes the SGPR-base form
+        // and the vector ALU computes no address at all (the 64-bit multiply-add per store was a quarter-rate instruction)
+        if (write_masks && have) mask_row_store_saddr(masks + ((size_t)p * M + m0 + cur) * N, (uint32_t)n0, q.x, q.y, q.z, q.w);
+#else
         if (write_masks && have) mask_row_store(masks + ((size_t)p * M + m0 + cur) * N + n0, q.x, q.y, q.z, q.w);
+#endif
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
+        // (row sums + four adding lanes instead of the two row_bcast steps: no gain in the step, 0.606 vs 0.609 ms)
         if (lane == 63) atomicAdd(&part[wv][cur], finite ? a : NAN);   // ds_add_f32, no return: nothing to wait for (-2 %)
         if (!more) break;
       }
@@ -600,7 +621,11 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
         while (inv) {
           const int ml = 32 * wd + __builtin_ctz(inv);
           inv &= inv - 1;
+#if DR_K4_SADDR
+          mask_row_store_saddr(masks + ((size_t)p * M + m0 + ml) * N, (uint32_t)n0, 0u, 0u, 0u, 0u);
+#else
           mask_row_store(masks + ((size_t)p * M + m0 + ml) * N + n0, 0u, 0u, 0u, 0u);
+#endif
         }
       }
     }
