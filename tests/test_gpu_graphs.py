@@ -104,3 +104,25 @@ def test_graph_replay_of_a_train_step_equals_the_eager_step(dev):
         assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-7), r
         # float atomics in the sampler backward: summation order differs between launches
         assert torch.allclose(g0, g1, rtol=1e-3, atol=1e-6 * float(g0.abs().max())), r
+
+
+def test_graph_replay_of_the_3d_driver_equals_the_eager_driver(dev):
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.graphs import GraphedStep
+    from differentiable_ransac_amd.ransac import BatchedRANSAC3D
+    P, N, B = 2, 4096, 128                     # 4096 points: the one-pass sampler kernel, 16-point residual kernel
+    items = [synth.rigid_pair(p, N) for p in range(P)]
+    m = torch.stack([i["matches"] for i in items]).to(dev)
+    lg = torch.stack([i["logits"] for i in items]).to(dev)
+    kw = dict(ransac_batch_size=B, train=False, threshold=0.03, max_iterations=B, seed=21, flag=False, keep_masks=True)
+    eager = BatchedRANSAC3D(**kw)
+    graphed = BatchedRANSAC3D(**kw).device_seeds(dev)
+    warm = 3
+    for _ in range(warm):
+        eager(m, lg)
+    step = GraphedStep(lambda: graphed(m, lg), warmup=warm)
+    for r in range(3):
+        want, got = eager(m, lg), step()
+        for key in want:
+            if torch.is_tensor(want[key]):
+                assert torch.equal(want[key], got[key]), (key, r)
