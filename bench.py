@@ -161,6 +161,7 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
         lg = logits.clone().requires_grad_(True)
         match_loss = MatchLoss()                     # the reference's default training loss (-w2 1, train.py:70-79)
         gt_mask = data["inliers"].to(dev)
+        no_inliers = torch.zeros(P, device=dev)      # the train step reports no inlier counts (allocated once, not per step)
 
         def step():
             lg.grad = None
@@ -171,7 +172,7 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
             else:
                 loss = match_loss(chosen, matches, gt_mask, keep)
             loss.backward()
-            return {"inliers": torch.zeros(P, device=dev), "grad": lg.grad}
+            return {"inliers": no_inliers, "grad": lg.grad}
         return step, dict(rn=tr, matches=matches, logits=lg, S=S, data=data, K=(K1, K2))
     rn = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B, seed=seed + rank,
                        keep_masks=keep_masks, refit=False, sampling=w["sampler"])
