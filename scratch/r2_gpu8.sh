@@ -15,9 +15,9 @@ prof() {  # name, title, bench args...
   python $R/tools/rocprof_summary.py $(find $O/prof_$name -name "*results.db" | head -1) $O/r2_kernel_stats_$name.md "$title" first 105
   rm -rf $O/prof_$name
 }
-prof c2 "python bench.py --steps 100 --warmup 5 --no-configs --no-cpu-baseline   (default workload: c2, 128 pairs per step)" --steps 100 --warmup 5 --no-configs --no-cpu-baseline --no-extras
+prof c2 "python bench.py --steps 100 --warmup 5 --no-configs --no-cpu-baseline --no-extras   (default workload: c2, 128 pairs per step)" --steps 100 --warmup 5 --no-configs --no-cpu-baseline --no-extras
 prof c2_p32 "python bench.py --workload c2 --pairs 32 --steps 100 --warmup 5 --no-configs --no-cpu-baseline" --workload c2 --pairs 32 --steps 100 --warmup 5 --no-configs --no-cpu-baseline
 prof c3 "python bench.py --workload c3 --steps 100 --warmup 5 --no-configs --no-cpu-baseline" --workload c3 --steps 100 --warmup 5 --no-configs --no-cpu-baseline
-prof c4 "python bench.py --workload c4 --steps 100 --warmup 5 --no-configs --no-cpu-baseline" --workload c4 --steps 100 --warmup 5 --no-configs --no-cpu-baseline --no-extras
+prof c4 "python bench.py --workload c4 --steps 100 --warmup 5 --no-configs --no-cpu-baseline --no-extras" --workload c4 --steps 100 --warmup 5 --no-configs --no-cpu-baseline --no-extras
 prof train "python bench.py --mode train --graph off --steps 100 --warmup 5   (32 pairs per step, eager so that the launches are visible one by one)" --mode train --graph off --steps 100 --warmup 5
 ls $O
