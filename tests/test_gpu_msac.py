@@ -42,7 +42,8 @@ def test_msac_golden(dev):
         _check_scores_masks(s, k, g[f"scores_{tag}"], g[f"masks_{tag}"], _margin(m, md, g["threshold"]))
 
 
-@pytest.mark.parametrize("N,M", [(2000, 1024), (2000, 37), (131, 5), (1, 1), (2049, 64), (5000, 40), (7, 33)])
+@pytest.mark.parametrize("N,M", [(2000, 1024), (2000, 37), (131, 5), (1, 1), (2049, 64), (5000, 40), (7, 33),
+                                 (4096, 40), (6144, 200), (2048, 129)])   # 16-point kernel with the point range split over blocks
 def test_msac_vs_oracle_shapes(dev, N, M):
     from differentiable_ransac_amd import ops, synth
     pair = synth.two_view_pair(100 + N, max(N, 8))
