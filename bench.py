@@ -97,6 +97,16 @@ def parse():
                          "hypotheses).  auto: the train step and the sub-records of the other configs are replayed; the "
                          "headline test-mode region stays eager, because its roofline needs HIP events around the scoring "
                          "launch of every step (it is device-bound either way)")
+    ap.add_argument("--segments", type=int, default=5,
+                    help="the timed region is repeated as this many segments of EXACTLY --steps steps, each bracketed by a "
+                         "barrier + synchronize on both sides; the line reports the median segment (value, ms_per_step, the "
+                         "scoring launch's HIP-event mean) and lists all of them")
+    ap.add_argument("--prewarm-s", type=float, default=0.6,
+                    help="time-based pre-conditioning before the counted warm-up: the same step is issued until this many "
+                         "seconds of wall time have passed (clocks, allocator pools, caches), reported as prewarm_s.  A "
+                         "20-step run is 24 ms of device time: without this it measures the power-state ramp, not the step")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check (no GPU needed): start the ranks, form the process group, count them, print the line")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the K timed steps are issued on round-robin.  Default 1: strictly one kernel at a "
                          "time, so that the HIP-event duration of the scoring kernel in the timed region is its own "
@@ -216,8 +226,8 @@ class CallTimer:
         else:
             self.orig(name, *a)
 
-    def mean_ms(self, n=None):
-        ev = self.ev if n is None else self.ev[:n]
+    def mean_ms(self, n=None, lo=0):
+        ev = self.ev[lo:] if n is None else self.ev[lo:lo + n]
         return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
 
     def close(self):
@@ -293,8 +303,10 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
         graph_ms = segments(gstep)
         del gstep
         # launch-bound steps (config 1: 0.05 ms of device time in six launches) gain from the replay, device-bound ones lose a
-        # few per cent to the graph's inter-node barriers: the sub-record carries both and quotes the faster one
-        if sorted(graph_ms)[1] < sorted(eager_ms)[1]:
+        # few per cent to the graph's inter-node barriers.  The sub-record always carries BOTH figures, labelled; which one
+        # `ms_per_step` quotes is fixed per config (not the minimum of the two): the replay for the launch-bound c1, the eager
+        # issue for the device-bound others
+        if key == "c1":
             seg_ms, issue = graph_ms, "HIP graph replay of the whole step (differentiable_ransac_amd.graphs.GraphedStep)"
     el, steps = sorted(seg_ms)[1] * 1e-3 * seg, seg
     calls = per_call_breakdown(step)
@@ -401,15 +413,57 @@ def pmc_traffic(kernel_key, shape):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` started plain (no RANK in the environment): start the N ranks here, one process per GPU,
+    under torch.distributed.run on the loopback address -- the command the driver would have used -- and hand its exit code
+    back.  Rank 0 of the child job prints the JSON line on this process's stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(args, world, rank):
+    """Launcher check: the ranks form the process group (gloo when there is no GPU) and count themselves."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    backend = args.backend if torch.cuda.is_available() and not args.gpus_shared else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    one = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(one)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "rendezvous only", "n_gpus": world, "n_ranks_seen": int(one.item()), "backend": backend,
+                          "requested_gpus": args.gpus}))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if args.gpus_shared:
         local = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: this node shows {torch.cuda.device_count()} GPU(s); one rank per GPU "
+                         "(--backend gloo --gpus-shared runs the N > 1 code paths on one device, functional check only)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -450,7 +504,8 @@ def main():
     K1, K2 = info["K"]
     M = w["hyps"] * S
     score_prefix = "dr_rigid_residual_f" if w["solver"] == "rigid" else "dr_msac_score_f"
-    timer = CallTimer((score_prefix,), args.steps)
+    n_seg = max(1, args.segments)
+    timer = CallTimer((score_prefix,), args.steps * n_seg)
 
     # the training step's collective: one flat bucket = the scores network's gradient (random stand-in of the reference
     # CLNet's size: the network itself is out of scope) + the logits gradient
@@ -463,7 +518,9 @@ def main():
             out = base_step()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            sharding.allreduce_mean_([net_grad, out["grad"]], dist)
+            # ranks own different pairs: the per-pair logits gradient continues into each rank's own backward through the
+            # scores network; what the ranks average is that network's parameter gradient (train.py:150-175), nothing else
+            sharding.allreduce_mean_([net_grad], dist)
             e1.record()
             coll_ev.append((e0, e1))
             return out
@@ -498,39 +555,63 @@ def main():
         issue(i)
         done_ev[n_issued % kWindow].record(streams[i % len(streams)] if len(streams) > 1 else torch.cuda.current_stream())
 
+    # time-based pre-conditioning (not counted in `warmup`): the same step until --prewarm-s of wall time has passed.  The
+    # driver's `--steps 20 --warmup 5` is 6 ms + 24 ms of device time: without this the region is the clock ramp of a cold box
+    # (round 2: 0.668 ms per scoring launch on the driver's run against 0.612 ms in the 1000-step runs).
+    n_issued, t_pre = 0, time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_s:
+        for _ in range(8):
+            issue_bounded(n_issued, n_issued)
+            n_issued += 1
+        done_ev[(n_issued - 1) % kWindow].synchronize()
+    torch.cuda.synchronize()
+    prewarm_s, prewarm_steps = time.perf_counter() - t_pre, n_issued
     for i in range(args.warmup):
-        issue_bounded(i, i)
+        issue_bounded(n_issued, n_issued)
+        n_issued += 1
     torch.cuda.synchronize()
-    coll_ev.clear()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timer.i = i
-        issue_bounded(i, i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    # the timed region: n_seg segments of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides; whole-job
+    # rate of a segment = sum of hypotheses over ranks / max elapsed over ranks; the line reports the MEDIAN segment
+    seg_elapsed, seg_rate, seg_k4, seg_coll = [], [], [], []
+    for sgi in range(n_seg):
+        coll_ev.clear()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            timer.i = sgi * args.steps + i
+            issue_bounded(i, n_issued)
+            n_issued += 1
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        timer.i = -1
+        rate, el = sharding.job_throughput(P * w["hyps"] * args.steps, el, dist, dev)
+        seg_elapsed.append(el)
+        seg_rate.append(rate)
+        if coll_ev:
+            seg_coll.append(sum(a.elapsed_time(b) for a, b in coll_ev) / len(coll_ev))
     out = outs[(args.steps - 1) % len(streams)]
-    elapsed = time.perf_counter() - t0
-    timer.i = -1
-    # whole-job rate = sum of hypotheses over ranks / max elapsed over ranks
-    job_hyps_per_s, elapsed = sharding.job_throughput(P * w["hyps"] * args.steps, elapsed, dist, dev)
+    med = sorted(range(n_seg), key=lambda i: seg_elapsed[i])[n_seg // 2]
+    elapsed, job_hyps_per_s = seg_elapsed[med], seg_rate[med]
     n_ranks_seen = 1
     if dist is not None:
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         n_ranks_seen = int(one.item())
-    collective_ms = None
-    if coll_ev:
-        collective_ms = sum(a.elapsed_time(b) for a, b in coll_ev) / len(coll_ev)
+    collective_ms = sorted(seg_coll)[len(seg_coll) // 2] if seg_coll else (0.0 if world > 1 else None)
 
     common = {"unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
               "scaling": "strong" if split_h else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-              "n_ranks_seen": n_ranks_seen}
+              "n_ranks_seen": n_ranks_seen, "collective_ms": collective_ms,
+              "prewarm_s": round(prewarm_s, 3), "prewarm_steps": prewarm_steps,
+              "segments": {"n": n_seg, "steps_each": args.steps, "reported": "median segment",
+                           "ms_per_step": [round(e / args.steps * 1e3, 5) for e in seg_elapsed],
+                           "hypotheses_per_s": [round(r, 1) for r in seg_rate]}}
 
     if args.mode == "train":
         if rank == 0:
@@ -543,10 +624,9 @@ def main():
                                          "issue": ("HIP graph replay of forward + loss + backward (one launch per step)"
                                                    if use_graph else "eager: one Python call per launch, autograd backward"),
                                          "parallelism": f"pairs sharded over {world} GPU(s); one flat RCCL all-reduce of "
-                                                        f"{CLNET_PARAMS} + {P * N} f32 per step" if world > 1 else "single GPU"},
-                              "collective_ms": collective_ms,
+                                                        f"{CLNET_PARAMS} f32 (the scores network's gradient) per step" if world > 1 else "single GPU"},
                               "collective_share_of_step": (collective_ms / (elapsed / args.steps * 1e3)) if collective_ms else None,
-                              "collective_bytes": 4 * (CLNET_PARAMS + P * N) if world > 1 else 0,
+                              "collective_bytes": 4 * CLNET_PARAMS if world > 1 else 0,
                               "grad_finite": bool(torch.isfinite(out["grad"]).all())}))
         timer.close()
         if dist is not None:
@@ -567,16 +647,17 @@ def main():
             with torch.cuda.stream(s2[i % n2]):
                 keep[i % n2] = step()
             return s2[i % n2]
+        n_ov = max(args.steps, 100)
         t1 = time.perf_counter()
-        run_bounded(issue2, args.steps)
+        run_bounded(issue2, n_ov)
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t1
-        overlap = {"streams": n2, "value": P * B * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3}
+        overlap = {"streams": n2, "steps": n_ov, "value": P * B * n_ov / e2, "ms_per_step": e2 / n_ov * 1e3}
         del keep
 
     with_refit, topdown = None, None
     if args.extras and world == 1 and w["solver"] != "rigid":
-        n_x = min(args.steps, 200)
+        n_x = 200
         rn_refit = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B,
                                  seed=4321, keep_masks=True, refit=True)
         for _ in range(3):
@@ -610,8 +691,11 @@ def main():
         torch.cuda.synchronize()
         timer.i = -1
         k4_ms = timer.mean_ms(n_ev)
+        seg_k4 = [k4_ms]
     else:
-        k4_ms = timer.mean_ms()
+        # HIP-event mean of the scoring launch per segment; the median of the segment means is the roofline's duration
+        seg_k4 = [timer.mean_ms(args.steps, sgi * args.steps) for sgi in range(n_seg)]
+        k4_ms = sorted(seg_k4)[n_seg // 2]
     iso_ms = k4_ms
     if len(streams) > 1:      # with two batches in flight the kernel shares the CUs: also measure it alone
         n_iso = min(10, args.steps)
@@ -655,7 +739,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel_name, "valid_slot_fraction": valid_frac, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
-                     "avg_launch_ms": k4_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "avg_launch_ms": k4_ms, "segments_avg_launch_ms": [round(x, 5) for x in seg_k4],
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
                      "isolated": {"avg_launch_ms": iso_ms, "achieved": bytes_per_launch / (iso_ms * 1e-3) / 1e9,
                                   "frac": bytes_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "note": "same launch, one stream, nothing else resident"},

@@ -23,7 +23,8 @@ __device__ __forceinline__ double block_sum(double v, double *red /* [4] */) {
 
 // accumulates sum_n w_n * row_n row_n^T (45 unique entries) over this thread's points into gram[81] in LDS
 template <bool kFundamental, typename T>
-__device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const uint8_t *__restrict__ mk, int N,
+__device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const uint8_t *__restrict__ mk,
+                                                const T *__restrict__ wt, int N,
                                                 const double (&mu)[4], double r1, double r2, double *gram, double *red) {
   double acc[45];
 #pragma unroll
@@ -33,7 +34,8 @@ __device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const 
     double row[9];
     if (kFundamental)
       epipolar_row_f(((double)mt[4 * n] - mu[0]) * r1, ((double)mt[4 * n + 1] - mu[1]) * r1,
-                     ((double)mt[4 * n + 2] - mu[2]) * r2, ((double)mt[4 * n + 3] - mu[3]) * r2, 1.0, row);
+                     ((double)mt[4 * n + 2] - mu[2]) * r2, ((double)mt[4 * n + 3] - mu[3]) * r2,
+                     wt ? (double)wt[n] : 1.0, row);   // weights scale the ROWS (fundamental_matrix_estimator.py:243-244)
     else
       epipolar_row_5pt((double)mt[4 * n], (double)mt[4 * n + 1], (double)mt[4 * n + 2], (double)mt[4 * n + 3], 1.0, row);
     int q = 0;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const T *mt = matches + (size_t)p * N * 4;
   const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
   const double mu[4] = {0, 0, 0, 0};
-  gram_accumulate<false, T>(mt, mk, N, mu, 1.0, 1.0, gram, red);
+  gram_accumulate<false, T>(mt, mk, static_cast<const T *>(nullptr), N, mu, 1.0, 1.0, gram, red);
 #if defined(DR_REFIT_STOP) && DR_REFIT_STOP == 1
   return;
 #endif
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 template <typename T>
 __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) void refit_fundamental_kernel(const T *__restrict__ matches,
-                                                                  const uint8_t *__restrict__ mask, int N,
+                                                                  const uint8_t *__restrict__ mask,
+                                                                  const T *__restrict__ weights, int N,
                                                                   T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];
   double *gram = lds + 192;   // [0,162): the one five-point workspace slot all lanes share (identical values)
@@ -123,6 +126,9 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   const int p = blockIdx.x;
   const T *mt = matches + (size_t)p * N * 4;
   const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
+  // per-point row weights [P,N] (ransac.py:151-153 hands the estimator `soft_weights[0, inlier_indices]`); the Hartley
+  // normalisation below stays unweighted, as in fundamental_matrix_estimator.py:177-228
+  const T *wt = weights ? weights + (size_t)p * N : nullptr;
   // pass 1: centroid of the selected points
   double s[4] = {0, 0, 0, 0}, cnt = 0;
   for (int n = threadIdx.x; n < N; n += kRefT) {
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   }
   const double r1 = M_SQRT2 * nsel / block_sum(d1, red), r2 = M_SQRT2 * nsel / block_sum(d2, red);
   // pass 3: Gram matrix of the normalised rows
-  gram_accumulate<true, T>(mt, mk, N, mu, r1, r2, gram, red);
+  gram_accumulate<true, T>(mt, mk, wt, N, mu, r1, r2, gram, red);
   if (threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
   double f[9];
@@ -183,8 +189,8 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 }
 
 template <typename T>
-int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, int P, int N, T *models, uint8_t *valid,
-                 hipStream_t st) {
+int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, const T *weights, int P, int N, T *models,
+                 uint8_t *valid, hipStream_t st) {
   // five-point workspace (one slot), gram[81] + red[4] (padded to 96), wave partials [4][45], Jacobi V[81] + (c, s, p, q)[4]:
   // 4.6 KB -- with a 162-double slot PER LANE (83 KB) a block left room for only two of the four solver blocks a CU hosts
   const size_t smem = sizeof(double) * (192 + 96 + 4 * 45 + 81 + 16);
@@ -195,7 +201,7 @@ int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, int P,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_f = true;
     }
-    hipLaunchKernelGGL((refit_fundamental_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, N, models, valid);
+    hipLaunchKernelGGL((refit_fundamental_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, weights, N, models, valid);
   } else {
     if (!attr_e) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_essential_kernel<T>),
@@ -215,25 +221,38 @@ int dr_refit_essential_f32(const float *matches, const uint8_t *mask, int P, int
                            void *stream) {
   DR_REQUIRE(matches && models && valid, "null pointer");
   DR_REQUIRE(P > 0 && N >= 5, "bad sizes");
-  return dr::refit_launch<float>(false, matches, mask, P, N, models, valid, (hipStream_t)stream);
+  return dr::refit_launch<float>(false, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
 }
 int dr_refit_essential_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
                            void *stream) {
   DR_REQUIRE(matches && models && valid, "null pointer");
   DR_REQUIRE(P > 0 && N >= 5, "bad sizes");
-  return dr::refit_launch<double>(false, matches, mask, P, N, models, valid, (hipStream_t)stream);
+  return dr::refit_launch<double>(false, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
 }
 int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
                              void *stream) {
   DR_REQUIRE(matches && models && valid, "null pointer");
   DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
-  return dr::refit_launch<float>(true, matches, mask, P, N, models, valid, (hipStream_t)stream);
+  return dr::refit_launch<float>(true, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
 }
 int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
                              void *stream) {
   DR_REQUIRE(matches && models && valid, "null pointer");
   DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
-  return dr::refit_launch<double>(true, matches, mask, P, N, models, valid, (hipStream_t)stream);
+  return dr::refit_launch<double>(true, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
+}
+
+int dr_refit_fundamental_w_f32(const float *matches, const uint8_t *mask, const float *weights, int P, int N,
+                               float *models, uint8_t *valid, void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
+  return dr::refit_launch<float>(true, matches, mask, weights, P, N, models, valid, (hipStream_t)stream);
+}
+int dr_refit_fundamental_w_f64(const double *matches, const uint8_t *mask, const double *weights, int P, int N,
+                               double *models, uint8_t *valid, void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
+  return dr::refit_launch<double>(true, matches, mask, weights, P, N, models, valid, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -435,15 +435,30 @@ def refit_accept(matches: torch.Tensor, cand: torch.Tensor, cand_valid: Optional
            c_int(P), c_int(S), c_int(N), ptr(best_score), ptr(best_model), stream())
 
 
-def refit_fundamental(matches: torch.Tensor, mask: Optional[torch.Tensor] = None):
-    """K7 (F): Hartley-normalised LSQ 8-point on the masked points of every pair.  -> F [P,3,3], valid [P]."""
+def refit_fundamental(matches: torch.Tensor, mask: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None):
+    """K7 (F): Hartley-normalised LSQ 8-point on the masked points of every pair.  -> F [P,3,3], valid [P].
+    weights [P,N] (optional): per-point row weights, the `soft_weights[0, inlier_indices[0]]` of ransac.py:151-153."""
     P, N, _ = matches.shape
     models = torch.empty((P, 3, 3), device=matches.device, dtype=matches.dtype)
     valid = torch.empty((P,), device=matches.device, dtype=torch.bool)
     mk = None if mask is None else mask.contiguous().view(torch.uint8)
+    if weights is not None:
+        if weights.shape != (P, N):
+            raise L.DransacError("refit weights are [P,N], one per point")
+        L.call(f"dr_refit_fundamental_w_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk),
+               ptr(weights.to(matches.dtype).contiguous()), c_int(P), c_int(N), ptr(models), ptr(valid), stream())
+        return models, valid
     L.call(f"dr_refit_fundamental_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk), c_int(P), c_int(N),
            ptr(models), ptr(valid), stream())
     return models, valid
+
+
+def soft_weights_row0(logits: torch.Tensor, k: int, tau: float, gumbel: Optional[torch.Tensor], seed: int) -> torch.Tensor:
+    """y_soft of hypothesis 0 of a sampler call, [P,N]: softmax((logits + noise[:, 0]) / tau) with the SAME noise row the call
+    with this seed (or this explicit noise) drew -- the in-kernel Philox counters are (element, hypothesis, pair), so row 0 does
+    not depend on the batch size.  What ransac.py:151-153 indexes as `soft_weights[0, ...]`."""
+    g = None if gumbel is None else gumbel[:, :1].contiguous()
+    return gumbel_topk(logits, 1, k, tau, g, seed, dense=True)["y_soft"][:, 0]
 
 
 # ------------------------------------------------------------------------------------------ autograd wrappers

@@ -33,6 +33,17 @@ def normalized_threshold(threshold, K1, K2, fmat):
     return threshold / ((K1[..., 0, 0] + K1[..., 1, 1] + K1[..., 0, 0] + K2[..., 1, 1]) / 4)
 
 
+def _takes_argument(fn) -> bool:
+    """True when `fn` (a bound method) accepts one positional argument."""
+    import inspect
+    try:
+        params = [p for p in inspect.signature(fn).parameters.values()
+                  if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD, p.VAR_POSITIONAL)]
+    except (TypeError, ValueError):
+        return False
+    return len(params) >= 1
+
+
 def _is_gumbel(sampler_id):
     # ids 2 and 3 in the reference; id 1 builds a Gumbel sampler there too but then crashes (Q16): treated as 2
     return sampler_id in (1, 2, 3)
@@ -58,6 +69,7 @@ class RANSAC(object):
         self.confidence = confidence
         self.max_iterations = max_iterations
         self.eps = eps
+        self._soft0 = None       # y_soft of hypothesis 0 of the last batch (weighted F refit, ransac.py:151-153)
         self.fused = True        # test mode with this package's own plugins: run on the device-resident batched driver
         self._fast = None
         self._fast_cfg = None
@@ -81,6 +93,8 @@ class RANSAC(object):
             else:
                 samples, w, _ = ops.SampleGather.apply(matches.unsqueeze(0), lg, B, k, self.sampler.tau, g, seed)
                 samples, w = samples[0], w[0]
+                if self.weighted and self.fmat and not self.train:      # the refit's `soft_weights[0, ...]` (ransac.py:151-153)
+                    self._soft0 = ops.soft_weights_row0(lg, k, self.sampler.tau, g, seed)[0]
         elif _is_gumbel(self.sampler_id):
             # a third-party sampler with the reference's duck-typed contract only (ransac.py:63-65,73):
             # sample(logits) -> (ret [B,N], y_soft [B,N]); the straight-through gather in plain torch ops
@@ -88,11 +102,11 @@ class RANSAC(object):
             pts = matches.repeat([ret.shape[0], 1, 1]) * ret.unsqueeze(-1)
             samples = pts[ret != 0].view(ret.shape[0], -1, matches.shape[-1])
             w = y_soft[ret != 0].view(ret.shape[0], -1)
+            self._soft0 = y_soft[0].detach()
         else:
-            try:
-                idx = self.sampler.sample(matches.shape[0])
-            except TypeError:                                   # the reference calls sampler.sample() (ransac.py:59)
-                idx = self.sampler.sample()
+            # the reference calls sampler.sample() (ransac.py:59); this package's UniformSampler takes the point count.  The call
+            # form is read off the signature -- catching TypeError would also swallow one raised INSIDE a plugin and call it twice
+            idx = self.sampler.sample(matches.shape[0]) if _takes_argument(self.sampler.sample) else self.sampler.sample()
             samples, w = matches[idx], None
         wts = w if self.weighted else None
         if hasattr(self.estimator, "estimate_model_slots"):
@@ -101,10 +115,16 @@ class RANSAC(object):
         # [S*B', 3, 3]; slots = consecutive groups per sample, every finite model valid
         models = self.estimator.estimate_model(samples, wts) if wts is not None else self.estimator.estimate_model(samples)
         nb = samples.shape[0]
-        if models is None or models.shape[0] == 0 or models.shape[0] % nb != 0:
-            raise ValueError("a plugin estimator must return S models per sample in sample order (got %s for %d samples)"
-                             % (None if models is None else tuple(models.shape), nb))
-        models = models.reshape(nb, models.shape[0] // nb, 3, 3)
+        # fixed slots: exactly S models per sample, in sample order.  S is the estimator's `solutions_per_sample` when it declares
+        # one; otherwise 1 / 10 / 4 for [B,3,3] / five-point / seven-point outputs of the reference's shapes (a ragged output that
+        # merely happens to divide evenly would be mis-grouped silently, so nothing is inferred from divisibility alone)
+        S = getattr(self.estimator, "solutions_per_sample", None)
+        if S is None and models is not None and models.shape[0] in (nb, 10 * nb, 4 * nb):
+            S = models.shape[0] // nb
+        if models is None or S is None or models.shape[0] != S * nb:
+            raise ValueError("a plugin estimator must return exactly S models per sample in sample order (declare "
+                             "`solutions_per_sample`): got %s for %d samples" % (None if models is None else tuple(models.shape), nb))
+        models = models.reshape(nb, S, 3, 3)
         return models, torch.isfinite(models).flatten(2).all(-1)
 
     def _fused_solver(self):
@@ -192,18 +212,21 @@ class RANSAC(object):
             inl = best_mask.nonzero(as_tuple=True)[0]
             slots = hasattr(self.estimator, "estimate_model_slots")
             cvalid = None
+            rw = None
             if self.fmat:
                 pts_ = matches[inl].unsqueeze(0) if inl.numel() >= 8 else None
+                if self.weighted and pts_ is not None and getattr(self, "_soft0", None) is not None:
+                    rw = self._soft0[inl].unsqueeze(0)      # ransac.py:151-153: soft_weights[0, inlier_indices[0]], last batch
             else:
                 # pymagsac absent: Nister on ALL points in f64 as one sample (ransac.py:157-165 -> nister.py:64-65)
                 pts_ = matches.unsqueeze(0).double()
             if pts_ is None:
                 cand = None
             elif slots:      # fixed-shape slots + validity: the eye(3) fillers of failed solves must not compete
-                cand, cvalid = self.estimator.estimate_model_slots(pts_)
+                cand, cvalid = self.estimator.estimate_model_slots(pts_, rw) if rw is not None else self.estimator.estimate_model_slots(pts_)
                 cand, cvalid = cand.reshape(-1, 3, 3), cvalid.reshape(-1)
             else:
-                cand = self.estimator.estimate_model(pts_)
+                cand = self.estimator.estimate_model(pts_, rw) if rw is not None else self.estimator.estimate_model(pts_)
             if cand is None or cand.shape[0] == 0:
                 if not isinstance(best_model, torch.Tensor):
                     best_model = torch.eye(3, device=matches.device, dtype=matches.dtype)
@@ -343,6 +366,14 @@ class BatchedRANSAC(object):
 
     def hypotheses(self, matches, logits, gumbels=None):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
+        if self.weighted and self.fmat and not self.train and self.refit:
+            # the weighted LSQ refit (ransac.py:151-153) needs y_soft of hypothesis 0 of the LAST batch a pair ran: take the seed
+            # here so that __call__ can re-draw that one row (ops.soft_weights_row0)
+            seed = self._next_seed()
+            samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, seed)
+            self._row0 = (seed, gumbels)
+            F, v = ops.solve_fundamental8(samples, w)
+            return F.unsqueeze(2), v.unsqueeze(2), idx
         if self.sampling == "uniform" and gumbels is None:
             idx = ops.uniform_sample(matches.shape[0], self.B, self.k, matches.shape[1], self._next_seed(), matches.device)
             samples, w = ops.gather(matches, idx), None
@@ -425,17 +456,24 @@ class BatchedRANSAC(object):
                 pre = issue_refit()
             ahead = None
             if have_round(0):
-                ahead = self.hypotheses(matches, logits, noise_of(0))[:2]
+                ahead = self.hypotheses(matches, logits, noise_of(0))[:2] + (getattr(self, "_row0", None),)
             r = 0
+            want_w = bool(self.weighted and self.fmat and self.refit)
+            last_w = torch.zeros((P, N), device=dev, dtype=dt) if want_w else None
             while ahead is not None:
-                models, valid = ahead
+                models, valid, row0 = ahead
                 ahead = None
                 if self.pipeline and have_round(r + 1):
                     if self._pipe is None:
                         self._pipe = torch.cuda.Stream(device=dev)
                     self._pipe.wait_stream(main)          # inputs (and, for explicit noise, the caller's tensors) are ready
                     with torch.cuda.stream(self._pipe):
-                        ahead = self.hypotheses(matches, logits, noise_of(r + 1))[:2]
+                        ahead = self.hypotheses(matches, logits, noise_of(r + 1))[:2] + (getattr(self, "_row0", None),)
+                if want_w:
+                    # pairs still iterating in this round take this round's row-0 soft weights; terminated pairs keep theirs
+                    # ("the last batch sampled", per pair)
+                    w0 = ops.soft_weights_row0(logits, self.k, self.tau, row0[1], row0[0])
+                    last_w = torch.where((st.iters.double() < st.max_iters)[:, None], w0, last_w)
                 flat = models.reshape(P, self.B * self.S, 3, 3)
                 scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks, valid=valid.reshape(P, -1))
                 if self.keep_masks:
@@ -452,10 +490,10 @@ class BatchedRANSAC(object):
                 if r % self.sync_every == 0 and not bool((st.iters.double() < st.max_iters).any()):
                     break
                 if ahead is None:
-                    ahead = self.hypotheses(matches, logits, noise_of(r))[:2]
+                    ahead = self.hypotheses(matches, logits, noise_of(r))[:2] + (getattr(self, "_row0", None),)
                 else:
                     main.wait_stream(self._pipe)
-                    for t_ in ahead:
+                    for t_ in ahead[:2]:
                         t_.record_stream(main)
             if ahead is not None and self._pipe is not None:
                 main.wait_stream(self._pipe)              # dropped speculative work: keep the allocator's stream order simple
@@ -463,7 +501,7 @@ class BatchedRANSAC(object):
                                                                   st.best_inliers, st.iters)
             if self.refit:
                 if self.fmat:
-                    F, fvalid = ops.refit_fundamental(matches, best_mask)   # LSQ on the inliers of the best mask
+                    F, fvalid = ops.refit_fundamental(matches, best_mask, last_w)   # (weighted) LSQ on the inliers of the best mask
                     cand, cvalid = F.unsqueeze(1), fvalid.unsqueeze(1)
                 else:
                     torch.cuda.current_stream().wait_stream(self._side)

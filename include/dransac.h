@@ -286,6 +286,14 @@ int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, i
                              void *stream);
 int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
                              void *stream);
+/*   dr_refit_fundamental_w  the same with per-point row weights [P,N] (NULL = unweighted): RANSAC.__call__ with
+ *                         `weighted=1`, ransac.py:151-153 -- `estimate_model(inlier_points, soft_weights[0, inlier_indices[0]])`,
+ *                         the weights multiply the epipolar rows (fundamental_matrix_estimator.py:243-244); the Hartley
+ *                         normalisation of the selected points stays unweighted (:177-228). */
+int dr_refit_fundamental_w_f32(const float *matches, const uint8_t *mask, const float *weights, int P, int N,
+                               float *models, uint8_t *valid, void *stream);
+int dr_refit_fundamental_w_f64(const double *matches, const uint8_t *mask, const double *weights, int P, int N,
+                               double *models, uint8_t *valid, void *stream);
 
 /* K7 acceptance (ransac.py:173-185): MSAC scores of the S refit candidates of every pair (cand [P,S,9], cand_valid [P,S]
  * or NULL); where the best candidate scores strictly higher than best_score[p], best_score[p] and best_model[p] ([P,9])

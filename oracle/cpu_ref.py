@@ -512,7 +512,8 @@ def ransac_train_batch(matches, logits, gumbels, gt, solver: str, tau: float = 1
 
 
 def ransac_test(matches, logits, gumbel_batches, K1, K2, solver: str, threshold: float = 0.75,
-                max_iterations: int = 5000, confidence: float = 0.999, tau: float = 1.0, refit: bool = True):
+                max_iterations: int = 5000, confidence: float = 0.999, tau: float = 1.0, refit: bool = True,
+                weighted: bool = False):
     """Test-mode RANSAC.__call__ (ransac.py:55-200, lo=0) with explicit noise per batch.
 
     gumbel_batches: list of [B,N] noise tensors, consumed one per iteration; the loop stops
@@ -528,10 +529,16 @@ def ransac_test(matches, logits, gumbel_batches, K1, K2, solver: str, threshold:
         if it >= max_iters:
             break
         B = g.shape[0]
-        idx, ret, _ = gumbel_topk(logits, g, tau, k)
-        samples = gather_samples(matches, ret)
+        idx, ret, y_soft = gumbel_topk(logits, g, tau, k)
+        if weighted:                          # ransac.py:70-74: the soft weights of the selected points scale the rows
+            samples, wts = gather_samples(matches, ret, y_soft)
+        else:
+            samples, wts = gather_samples(matches, ret), None
         if fmat:
-            models = fundamental_8pt(samples)
+            models = fundamental_8pt(samples, wts)
+        elif weighted:
+            E, ok, _ = nister_5pt(samples, wts)
+            models = compact_models(E, ok)
         else:
             E, ok, _ = nister_5pt(samples)
             models = compact_models(E, ok)
@@ -544,7 +551,10 @@ def ransac_test(matches, logits, gumbel_batches, K1, K2, solver: str, threshold:
         it += B
     if refit:
         inl = best_mask.nonzero(as_tuple=True)[0]
-        if fmat:
+        if fmat and weighted:
+            # ransac.py:151-153: `soft_weights[0, inlier_indices[0]]` -- hypothesis 0 of the LAST batch sampled
+            cand = fundamental_8pt(matches[inl].unsqueeze(0), y_soft[0, inl].unsqueeze(0))
+        elif fmat:
             cand = fundamental_8pt(matches[inl].unsqueeze(0))
         else:
             # pymagsac absent => Nister on ALL points in f64 as one sample (ransac.py:157-165, nister.py:64-65)

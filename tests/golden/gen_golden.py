@@ -201,6 +201,17 @@ def main():
     save("ransac_train_f8_weighted", matches=pairFp["matches"], logits=pairFp["logits"], gumbels=torch.stack(draws),
          chosen=chosen)
 
+    # weighted 8-pt TEST mode (`-fmat 1 -wei 1 -tr 0`): weighted minimal solves (ransac.py:70-74) and the weighted LSQ refit of
+    # the final model on the inliers with the soft weights of hypothesis 0 of the LAST batch (ransac.py:151-153)
+    pair_w = synth.two_view_pair(11, 128, inlier_ratio=0.7, pixel=True)
+    model, mask, score, iters, draws, _ = run_ransac("f8", False, 65, pair_w, 16, 5000, weighted=1)
+    y_soft0 = torch.softmax(pair_w["logits"] + draws[-1][0], dim=-1)      # tau = 1: gumbel_sampler.py:33-35, row 0
+    inl = mask.nonzero(as_tuple=True)[0]
+    cand = FundamentalMatrixEstimatorNew(device="cpu").estimate_model(pair_w["matches"][inl].unsqueeze(0), y_soft0[inl])
+    save("ransac_test_f8_weighted", matches=pair_w["matches"], logits=pair_w["logits"], K1=pair_w["K1"], K2=pair_w["K2"],
+         gumbels=torch.stack(draws), best_model=model, best_mask=mask, best_score=float(score), iterations=iters,
+         refit_weights=y_soft0, refit_candidate=cand[0])
+
     # ---------------------------------------------------------------- MatchLoss residual (batch_episym, cv_utils.py:680-695)
     pair = synth.two_view_pair(13, 200, dtype=torch.float64)
     gen = torch.Generator().manual_seed(14)

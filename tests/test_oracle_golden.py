@@ -202,6 +202,27 @@ def test_test_driver_matches_reference():
         _close(O.canonical(model), O.canonical(g["best_model"]), 1e-3)
 
 
+def test_weighted_fundamental_test_driver_matches_reference():
+    """`-fmat 1 -wei 1 -tr 0`: weighted minimal solves (ransac.py:70-74) + the weighted LSQ refit on the inliers with the soft
+    weights of hypothesis 0 of the last batch (ransac.py:151-153)."""
+    g = load_golden("ransac_test_f8_weighted")
+    model, mask, score, iters = O.ransac_test(g["matches"], g["logits"], list(g["gumbels"]), g["K1"], g["K2"], "f8",
+                                              weighted=True)
+    assert iters == g["iterations"]
+    assert torch.equal(mask, g["best_mask"])
+    assert abs(score - g["best_score"]) <= 1e-3 * max(1.0, abs(g["best_score"]))
+    _close(O.canonical(model), O.canonical(g["best_model"]), 1e-3)
+    # the refit candidate on its own: the reference estimator on (inliers of the best mask, soft weights of hypothesis 0)
+    inl = g["best_mask"].nonzero(as_tuple=True)[0]
+    y_soft = O.gumbel_topk(g["logits"], g["gumbels"][-1], 1.0, 8)[2]
+    assert torch.allclose(y_soft[0], g["refit_weights"], rtol=1e-5, atol=1e-9)
+    cand = O.fundamental_8pt(g["matches"][inl].unsqueeze(0), g["refit_weights"][inl].unsqueeze(0))[0]
+    _close(O.canonical(cand), O.canonical(g["refit_candidate"]), 1e-3)
+    # ... and it differs from the unweighted refit (the fixture exercises the weights)
+    plain = O.fundamental_8pt(g["matches"][inl].unsqueeze(0))[0]
+    assert (O.canonical(plain) - O.canonical(cand)).abs().max() > 3e-4
+
+
 def test_ransac3d_matches_reference():
     g = load_golden("ransac3d_train")
     models, residuals, means = [], [], []
