@@ -559,11 +559,19 @@ def main():
     # driver's `--steps 20 --warmup 5` is 6 ms + 24 ms of device time: without this the region is the clock ramp of a cold box
     # (round 2: 0.668 ms per scoring launch on the driver's run against 0.612 ms in the 1000-step runs).
     n_issued, t_pre = 0, time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_s:
+    while True:
         for _ in range(8):
             issue_bounded(n_issued, n_issued)
             n_issued += 1
         done_ev[(n_issued - 1) % kWindow].synchronize()
+        more = time.perf_counter() - t_pre < args.prewarm_s
+        if dist is not None:
+            # every rank must issue the SAME number of steps (a train step carries a collective): the ranks agree per chunk
+            flag = torch.tensor([1.0 if more else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item() > 0)
+        if not more:
+            break
     torch.cuda.synchronize()
     prewarm_s, prewarm_steps = time.perf_counter() - t_pre, n_issued
     for i in range(args.warmup):

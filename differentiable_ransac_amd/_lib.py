@@ -51,6 +51,11 @@ def check(status: int, what: str) -> None:
 _ctx = threading.local()
 
 
+def _reset() -> None:
+    _ctx.devs = set()
+    _ctx.keep = []
+
+
 def _devices() -> set:
     d = getattr(_ctx, "devs", None)
     if d is None:
@@ -65,10 +70,12 @@ def ptr(t: Optional[torch.Tensor]) -> c_void_p:
     the same argument list."""
     if t is None:
         return c_void_p(0)
-    if not t.is_cuda:
-        raise DransacError("libdransac operates on GPU tensors only (got a CPU tensor)")
-    if not t.is_contiguous():
-        raise DransacError("tensor must be contiguous")
+    if not t.is_cuda or not t.is_contiguous():
+        # the argument list this pointer belongs to will never reach call(): drop what its earlier ptr() calls recorded, or
+        # the next call on this thread would see stale devices ("tensors of one call live on different GPUs") and pin tensors
+        _reset()
+        raise DransacError("libdransac operates on GPU tensors only (got a CPU tensor)" if not t.is_cuda
+                           else "tensor must be contiguous")
     _devices().add(t.device.index)
     keep = getattr(_ctx, "keep", None)
     if keep is None:
@@ -80,7 +87,7 @@ def ptr(t: Optional[torch.Tensor]) -> c_void_p:
 def _launch_device() -> Optional[int]:
     devs = _devices()
     if len(devs) > 1:
-        _ctx.devs = set()
+        _reset()
         raise DransacError(f"tensors of one call live on different GPUs: {sorted(devs)}")
     return next(iter(devs)) if devs else None
 

@@ -322,7 +322,10 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     const int o = __shfl_up(incl, d, 64);
     incl += (lane >= d) ? o : 0;
   }
-  const int total = __shfl(incl, 63, 64);
+  // the queues hold 320 entries = 10 per sample: a degree-10 polynomial has at most 10 real roots, but each half of a sample's
+  // root search (|z| <= 1, |z| > 1) may report up to 10 on its own when rounding splits a multiple root into spurious sign
+  // changes.  Entries past the end are dropped (never written, never counted) instead of overrunning u / meta / cnt.
+  const int total = min(__shfl(incl, 63, 64), 320);
   const int off = incl - n;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -332,7 +335,7 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
     double u0[4] = {x * inv, y * inv, z * inv, inv};
     const bool good = ((cand >> i) & 1u) && is_finite(u0[0]) && is_finite(u0[1]) && is_finite(u0[2]) && is_finite(u0[3]);
-    if (i < n) {
+    if (i < n && off + i < 320) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) fq.u[k * 320 + off + i] = good ? u0[k] : 0.5;
       fq.meta[off + i] = (uint16_t)(lane | (good ? 1u << 6 : 0u));

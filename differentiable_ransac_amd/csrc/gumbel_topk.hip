@@ -6,7 +6,7 @@
 // Here one wave owns one (pair, hypothesis) row and never writes a [B,N] tensor unless the caller
 // asks for the API-faithful dense outputs:
 //   pass A  g = (logit + gumbel)/tau for the lane's 4-element groups (16-byte coalesced loads, or
-//           Philox4x32-10 in-kernel: one call = 4 elements), online soft-max (running max / sum)
+//           Philox4x32-7 in-kernel: one call = 4 elements), online soft-max (running max / sum)
 //           and the lane maximum; g is parked in LDS (4N bytes per wave) when it fits;
 //   select  T = k-th largest of the 64 lane maxima (k wave-max rounds) is a lower bound of the k-th
 //           largest element, so { g >= T } is a small superset of the top-k: it is compacted with
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(1024) void softmax_cdf_kernel(const T *__restrict__
 }
 
 // Step 2, one lane per (pair, hypothesis): k draws without replacement, ascending output.
-// Philox4x32-10(key = seed, counter = (draw pair, b, p, 2)): 64 random bits per draw.
+// Philox4x32-7(key = seed, counter = (draw pair, b, p, 2)): 64 random bits per draw.
 __global__ __launch_bounds__(256) void topdown_sample_kernel(const double *__restrict__ cdf, uint64_t seed, int B, int N, int k,
                                                             int32_t *__restrict__ idx, const uint64_t *__restrict__ seed_ptr) {
   if (seed_ptr) seed = *seed_ptr;

@@ -588,13 +588,9 @@ __global__ __launch_bounds__(kFT) void msac_filter_kernel(const float *__restric
 
 bool msac_filter_supported(int N) { return N % 16 == 0 && N >= 16 && N <= kFMaxN; }
 
-bool msac_filter_profitable(int P, int M, int N) {
-  return false;   // measured (profiles/r2_k4_filter_experiments.md): 262-269 us against 200-216 us for the general kernel at the
-                  // benchmark shape -- the filter kernel is reachable through path 2 only
-  if (N < 256) return false;
-  const long chunks = (long)P * ((M + kFSlots - 1) / kFSlots);
-  return chunks >= 1024;    // at least ~4 chunks per block of a chip-filling grid: the prologue has to amortise
-}
+// Never chosen automatically: measured 262-269 us against 200-216 us for the general kernel at the benchmark shape
+// (profiles/r2_k4_filter_experiments.md).  The filter kernel is opt-in through dr_msac_score_path_f32(path = 2) only.
+bool msac_filter_profitable(int, int, int) { return false; }
 
 int msac_filter_launch(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P, int M,
                        int N, float *scores, uint8_t *masks, hipStream_t st) {

@@ -467,6 +467,9 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 // Same algorithm with a lane owning 16 consecutive points (64 VGPRs), 128-thread blocks (two waves cover 2048 points):
 // every mask row segment is one 16-byte store per lane (1 KiB per wave instruction) -- the mask stream is store-ISSUE
 // bound with 8-byte stores.  Requires N % 16 == 0 (otherwise the 8-point kernel above is used).
+#ifndef DR_K4_SMALL
+#define DR_K4_SMALL 1   // 0: rows of <= 256 points take the general kernels too (A/B builds)
+#endif
 #ifndef DR_K4_TILE16
 #define DR_K4_TILE16 64   // model slots per block (multiple of 32)
 #endif
@@ -636,6 +639,76 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
     float *dst = scores + (size_t)p * M + m0 + i;
     if (use_atomic) atomicAdd(dst, v);
     else *dst = v;
+  }
+}
+
+// ---- f32, short rows (N <= 256): a WAVE per model ------------------------------------------------------------------------
+// The 16-points-per-lane mapping above gives a block's 128 lanes to 2048 points: at N = 128 (BASELINE configs[0]: 8-point F,
+// 128 correspondences, 64 hypotheses) eight lanes of a block hold all the points, the other 120 idle, and the tile's 64 models
+// run one after the other -- 47 us for 2.1 M evaluations, 40x below the kernel's own rate at N = 2000.  Here one wave covers
+// the whole row with kPts = 1, 2 or 4 CONSECUTIVE points per lane (smallest kPts with 64 kPts >= N), keeps them in VGPRs, and
+// the block's four waves take the tile's models in turn (model index wave-uniform -> coefficients through the scalar cache).
+// Every (pair, model) is owned by exactly one wave: the score is stored directly (deterministic, no LDS, no atomics) and the
+// mask row is one 1-, 2- or 4-byte store per lane.  Same arithmetic per (model, point) as the generic kernel (sampson_s).
+constexpr int kSmallMaxN = 256, kSmallWaves = 4, kSmallPerWave = 4, kSmallTile = kSmallWaves * kSmallPerWave;
+template <int kPtsS>
+__global__ __launch_bounds__(kSmallWaves * 64) void msac_score_kernel_f32_small(const float *__restrict__ matches,
+                                                                               const float *__restrict__ models,
+                                                                               const uint8_t *__restrict__ valid,
+                                                                               const float *__restrict__ thr, int M, int N,
+                                                                               float *__restrict__ scores,
+                                                                               uint8_t *__restrict__ masks) {
+  const int p = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const float t = 1.5f * thr[p];
+  const float inv_thr2 = 1.0f / (t * t);
+  const float4 *mt = reinterpret_cast<const float4 *>(matches) + (size_t)p * N;
+  const int n0 = lane * kPtsS;
+  const int nvalid = min(kPtsS, max(0, N - n0));
+  float x1[kPtsS], y1[kPtsS], x2[kPtsS], y2[kPtsS];
+#pragma unroll
+  for (int j = 0; j < kPtsS; ++j) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < nvalid) v = mt[n0 + j];
+    x1[j] = v.x; y1[j] = v.y; x2[j] = v.z; y2[j] = v.w;
+  }
+  const bool row_word = (N % kPtsS) == 0;   // every lane's segment is whole and its row offset naturally aligned
+#pragma unroll 1
+  for (int r = 0; r < kSmallPerWave; ++r) {
+    const int m = blockIdx.x * kSmallTile + r * kSmallWaves + wv;   // wave-uniform
+    if (m >= M) break;
+    const size_t slot = (size_t)p * M + m;
+    float mc[9];
+    uint32_t ex = 0, anybit = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      mc[q] = models[slot * 9 + q];
+      const uint32_t mb = __float_as_uint(mc[q]);
+      ex = max(ex, mb & 0x7f800000u);
+      anybit |= mb & 0x7fffffffu;
+    }
+    const bool live = !valid || valid[slot] != 0;                       // invalid slot: score 0, empty mask row
+    const bool finite = ex != 0x7f800000u && anybit != 0u;              // non-finite / all-zero model: score NaN, empty row
+    float acc = 0.f;
+    uint32_t bits = 0;
+    if (live && finite) {
+#pragma unroll
+      for (int j = 0; j < kPtsS; ++j) {
+        const float sv = sampson_s<float>(mc, x1[j], y1[j], x2[j], y2[j], inv_thr2);
+        const bool in = (j < nvalid) && (sv < 0.f);                     // a 0/0 point (NaN) is no inlier and contributes 0
+        acc += in ? -sv : 0.f;
+        bits |= (uint32_t)in << (8 * j);
+      }
+    }
+    if (masks && nvalid > 0) {
+      uint8_t *row = masks + slot * N + n0;
+      if (row_word && kPtsS == 4) *reinterpret_cast<uint32_t *>(row) = bits;
+      else if (row_word && kPtsS == 2) *reinterpret_cast<uint16_t *>(row) = (uint16_t)bits;
+      else
+        for (int j = 0; j < nvalid; ++j) row[j] = (uint8_t)((bits >> (8 * j)) & 1u);
+    }
+    acc = wave_sum_lane63(acc);
+    if (lane == 63) scores[slot] = live ? (finite ? acc : NAN) : 0.f;
   }
 }
 
@@ -874,6 +947,16 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
     if (path == 2 || (path == 0 && msac_filter_supported(N) && msac_filter_profitable(P, M, N)))
       return msac_filter_launch((const float *)matches, (const float *)models, valid, (const float *)thr, P, M, N,
                                 (float *)scores, masks, st);
+  }
+  if constexpr (kFast) {
+    if (DR_K4_SMALL && N <= kSmallMaxN) {   // short rows: a wave per model (BASELINE configs[0])
+      const dim3 g((M + kSmallTile - 1) / kSmallTile, 1, P), b(kSmallWaves * 64);
+      const float *mt = (const float *)matches, *md = (const float *)models, *th = (const float *)thr;
+      if (N <= 64) hipLaunchKernelGGL(msac_score_kernel_f32_small<1>, g, b, 0, st, mt, md, valid, th, M, N, (float *)scores, masks);
+      else if (N <= 128) hipLaunchKernelGGL(msac_score_kernel_f32_small<2>, g, b, 0, st, mt, md, valid, th, M, N, (float *)scores, masks);
+      else hipLaunchKernelGGL(msac_score_kernel_f32_small<4>, g, b, 0, st, mt, md, valid, th, M, N, (float *)scores, masks);
+      return check_launch("msac_score_kernel_f32_small");
+    }
   }
   const bool fast16 = kFast && DR_K4_FAST16 && (N % 16 == 0);
   const int tile = fast16 ? DR_K4_TILE16 * DR_K4_HALVES : (kFast ? kFastTile : kModelsPerBlock);

@@ -213,27 +213,39 @@ __global__ __launch_bounds__(kRThreads) void rigid_residual_kernel(const T *__re
 
 // f32, N % 16 == 0, masks wanted: a lane owns SIXTEEN consecutive points (96 VGPRs), 128-thread blocks, so that every mask
 // row segment is one 16-byte store per lane (1 KiB per wave instruction) and the per-model bookkeeping (reduction, model
-// fetch) is shared by twice as many points; DPP-only wave reduction, LDS atomic for the per-model partial.  Same arithmetic
-// per (model, point) as the kernel above, in the same order: identical masks, sums equal to rounding of the reduction order.
-// BASELINE config 4 (50 000 points x 2048 models): 80-86 -> see DESIGN.md section 6.
+// fetch) is shared by twice as many points; DPP-only wave reduction.  Same arithmetic per (model, point) as the kernel
+// above, in the same order: identical masks, sums equal to rounding of the reduction order.
+// Round 3 (BASELINE config 4, 50 000 points x 2048 models, one pair; 63 us = 0.20 of the HBM roofline before): the ISA
+// of the round-2 loop showed (i) the twelve model coefficients fetched by s_load at the top of every iteration with an
+// immediate s_waitcnt -- a scalar-cache round trip per model, exposed at three waves per SIMD; (ii) sixteen v_cmp + v_cndmask
+// pairs with s_nop bubbles + twelve v_or for the mask bytes; (iii) the lane-63 LDS atomicAdd expanded by the compiler into a
+// readlane loop.  Now: the next model is prefetched into a second SGPR set while the current one is evaluated (as in the MSAC
+// kernel), the inlier test is the clamped packed difference max(0, min(1, thr - d2)) whose exponent bit 6 says "> 0"
+// (NaN -> 0 = outlier), packed with v_perm_b32 like the MSAC masks (1.25 instructions per point instead of 3.5), plain
+// LDS read-modify-write of a wave-private partial, and 16-model tiles (twice as many, half as long blocks: the 3 200 waves
+// of a 32-model grid were 3.1 per SIMD -- SIMDs with four waves set the time, the others idled a quarter of it).
 #ifndef DR_K4R_16
 #define DR_K4R_16 1
 #endif
-constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts;
+#ifndef DR_K4R_TILE
+#define DR_K4R_TILE 16
+#endif
+constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts, kR16Models = DR_K4R_TILE;
 typedef float v2r __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2r rsplat(float a) { return (v2r){a, a}; }
 __global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(const float *__restrict__ pts, const float *__restrict__ models,
                                                                            float threshold, int M, int N, float *__restrict__ res_sum,
                                                                            uint8_t *__restrict__ masks, int chunks_per_block,
                                                                            int use_atomic) {
-  __shared__ float part[kRModels];
-  const int p = blockIdx.z, m0 = blockIdx.x * kRModels;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int mcount = min(kRModels, M - m0);
+  __shared__ float part[kR16Threads / 64][kR16Models];
+  const int p = blockIdx.z, m0 = blockIdx.x * kR16Models;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mcount = min(kR16Models, M - m0);
   const float *pt = pts + (size_t)p * N * 6;
   const float *md = models + ((size_t)p * M + m0) * 16;
-  if (tid < kRModels) part[tid] = 0.f;
+  if (tid < (kR16Threads / 64) * kR16Models) (&part[0][0])[tid] = 0.f;
   __syncthreads();
+  const v2r thr2 = rsplat(threshold);
   const int c_begin = blockIdx.y * chunks_per_block;
   for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
     if (c * kR16Chunk >= N) break;
@@ -257,47 +269,82 @@ __global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(cons
 #pragma unroll
         for (int d = 0; d < 6; ++d) xp[j][d] = (v2r){x[12 * j + d], x[12 * j + 6 + d]};
     }
-    for (int ml = 0; ml < mcount; ++ml) {
-      float m[12];
+    uint8_t *mrow = masks + ((size_t)p * M + m0) * N;   // wave-uniform row base; the lane part is the 32-bit offset n0
+    // models in groups of kGroup: the 12 coefficients of all of them are requested from the scalar cache together (one
+    // round trip per group instead of one per model: the compiler puts `s_waitcnt lgkmcnt(0)` right behind any s_load whose
+    // destination shares an SGPR pair with a live splat operand, so a hand-written "prefetch the next model" is not one)
+    constexpr int kGroup = 4;
+#pragma unroll 1
+    for (int mg = 0; mg < mcount; mg += kGroup) {
+      float mm[kGroup][12];
 #pragma unroll
-      for (int q = 0; q < 12; ++q) m[q] = md[ml * 16 + q];
-      v2r acc2 = (v2r){0.f, 0.f};
-      uint32_t wq[4] = {0u, 0u, 0u, 0u};
+      for (int u = 0; u < kGroup; ++u) {
+        const int mu = min(mg + u, mcount - 1);
 #pragma unroll
-      for (int j = 0; j < kR16Pts / 2; ++j) {
-        v2r d2 = (v2r){0.f, 0.f};
+        for (int q = 0; q < 12; ++q) mm[u][q] = md[mu * 16 + q];
+      }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const v2r pred = xp[j][0] * rsplat(m[4 * i]) + (xp[j][1] * rsplat(m[4 * i + 1]) + (xp[j][2] * rsplat(m[4 * i + 2]) + rsplat(m[4 * i + 3])));
-          const v2r e = xp[j][3 + i] - pred;
-          d2 = e * e + d2;
+      for (int u = 0; u < kGroup; ++u) {
+        const int ml = mg + u;
+        const bool live = ml < mcount;    // wave-uniform; a tail slot re-evaluates the tile's last model and drops the result
+        const float (&m)[12] = mm[u];
+        v2r acc2 = (v2r){0.f, 0.f};
+        uint32_t wq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint32_t sb[4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int j = 2 * g + h;
+            v2r d2 = (v2r){0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              // e = (q_i - t_i) - R_i . p, every step with ONE scalar (SGPR) coefficient operand: no model coefficient has to
+              // be copied into a VGPR pair to serve as an FMA addend (three v_mov_b64 and six registers per model otherwise)
+              v2r e = xp[j][3 + i] - rsplat(m[4 * i + 3]);
+              e = e - xp[j][2] * rsplat(m[4 * i + 2]);
+              e = e - xp[j][1] * rsplat(m[4 * i + 1]);
+              e = e - xp[j][0] * rsplat(m[4 * i]);
+              d2 = e * e + d2;
+            }
+            acc2 = acc2 + d2;
+            // inlier <=> d2 < thr <=> fl(thr - d2) > 0 (a difference of two floats is zero only if they are equal); clamped
+            // to [0, 1], NaN -> 0: "positive" = biased exponent >= 64 = bit 6 of the top byte (values below 2^-63 cannot
+            // occur as a difference of f32 numbers of the sizes thresholds and squared distances have)
+            v2r cl;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(cl) : "v"(thr2), "v"(d2));
+            sb[2 * h] = __float_as_uint(cl[0]);
+            sb[2 * h + 1] = __float_as_uint(cl[1]);
+          }
+          const uint32_t lo2 = __builtin_amdgcn_perm(sb[1], sb[0], 0x0c0c0703u);      // [s0.b3, s1.b3, 0, 0]
+          const uint32_t hi2 = __builtin_amdgcn_perm(sb[3], sb[2], 0x07030c0cu);      // [0, 0, s2.b3, s3.b3]
+          wq[g] = ((lo2 | hi2) >> 6) & 0x01010101u;
         }
-        acc2 = acc2 + d2;
-        wq[j >> 1] |= ((uint32_t)(d2[0] < threshold) | ((uint32_t)(d2[1] < threshold) << 8)) << (16 * (j & 1));
+        float acc = acc2[0] + acc2[1];
+        if (have && live) *reinterpret_cast<uint4 *>(mrow + (size_t)ml * N + (uint32_t)n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+        acc = wave_sum_lane63(have ? acc : 0.f);
+        if (lane == 63 && live) part[wv][ml] += acc;     // wave-private slot: plain read-modify-write
       }
-      float acc = acc2[0] + acc2[1];
-      if (have) {
-        const uint4 q = make_uint4(wq[0], wq[1], wq[2], wq[3]);
-        *reinterpret_cast<uint4 *>(masks + ((size_t)p * M + m0 + ml) * N + n0) = q;
-      }
-      acc = wave_sum_lane63(have ? acc : 0.f);
-      if (lane == 63) atomicAdd(&part[ml], acc);
     }
   }
   __syncthreads();
   if (tid < mcount) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kR16Threads / 64; ++w) v += part[w][tid];
     float *dst = res_sum + (size_t)p * M + m0 + tid;
-    if (use_atomic) atomicAdd(dst, part[tid]);
-    else *dst = part[tid];
+    if (use_atomic) atomicAdd(dst, v);
+    else *dst = v;
   }
 }
 
 template <typename T>
 int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int M, int N, T *res_sum, uint8_t *masks,
                           hipStream_t st) {
-  const int tiles = (M + kRModels - 1) / kRModels;
   if constexpr (sizeof(T) == 4) {
-    if (DR_K4R_16 && masks && N % 16 == 0 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0) {
+    // (thresholds below 1e-12 would put `thr - d2` near the bit-6 exponent test's blind spot: general kernel)
+    if (DR_K4R_16 && masks && N % 16 == 0 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0 && threshold > T(1e-12)) {
+      const int tiles = (M + kR16Models - 1) / kR16Models;
       const int chunks = (N + kR16Chunk - 1) / kR16Chunk;
       int ny = 1;
       const long base = (long)P * tiles;
@@ -311,6 +358,7 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
       return check_launch("rigid_residual_kernel_f32_16");
     }
   }
+  const int tiles = (M + kRModels - 1) / kRModels;
   const int chunks = (N + kRChunk - 1) / kRChunk;
   int ny = 1;
   const long base = (long)P * tiles;
@@ -328,6 +376,84 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
     hipLaunchKernelGGL((rigid_residual_kernel<T, false>), grid, dim3(kRThreads), 0, st, pts, models, threshold, M, N,
                        res_sum, masks, cpb, use_atomic);
   return check_launch("rigid_residual_kernel");
+}
+
+// ---- K6 of the 3-D path: per-pair arg-min of the residual sums, "is it better", best model and best mask on the device ----
+// (RANSAC3D's test branch, ransac.py:383-406, is dead code upstream -- SURVEY Q4 -- so the selection rule is the documented
+// stand-in: keep the valid model with the smallest residual sum.)  grid = (point slices, pairs): every block repeats the
+// arg-min over the M sums (8 KB at C4) and recomputes the winner's mask for ITS slice of the points, so one pair of 50 000
+// points is served by many CUs; the state is ping-ponged (best_*_in -> best_*_out) because block 0 cannot overwrite the
+// value the other blocks of the pair still compare against.  Replaces ~10 torch launches per round (where / min / gather).
+constexpr int kU3Threads = 256;
+template <typename T>
+__global__ __launch_bounds__(kU3Threads) void ransac3d_update_kernel(
+    const T *__restrict__ pts, const T *__restrict__ models, const uint8_t *__restrict__ valid, const T *__restrict__ res,
+    T threshold, int M, int N, int pts_per_block, const T *__restrict__ best_res_in, const T *__restrict__ best_model_in,
+    T *__restrict__ best_res_out, T *__restrict__ best_model_out, uint8_t *__restrict__ best_mask,
+    int32_t *__restrict__ best_idx) {
+  __shared__ T s_val[kU3Threads / 64];
+  __shared__ int s_idx[kU3Threads / 64];
+  const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const T *rs = res + (size_t)p * M;
+  const uint8_t *vd = valid ? valid + (size_t)p * M : nullptr;
+  T bv = INFINITY;
+  int bi = 0x7fffffff;
+  for (int m = tid; m < M; m += kU3Threads) {
+    const T v = rs[m];
+    const bool ok = (!vd || vd[m]) && v == v;
+    if (ok && (v < bv || (v == bv && m < bi))) { bv = v; bi = m; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const T ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
+  __syncthreads();
+  bv = s_val[0]; bi = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < kU3Threads / 64; ++w)
+    if (s_val[w] < bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+  const T old = best_res_in[p];
+  const bool better = bi != 0x7fffffff && bv < old;            // strict: an equal later round does not replace the model
+  if (blockIdx.x == 0) {
+    if (tid < 16) best_model_out[(size_t)p * 16 + tid] = better ? models[((size_t)p * M + bi) * 16 + tid]
+                                                                : best_model_in[(size_t)p * 16 + tid];
+    if (tid == 0) {
+      best_res_out[p] = better ? bv : old;
+      if (best_idx) best_idx[p] = better ? bi : -1;            // winner of THIS round, -1 when the state was kept
+    }
+  }
+  if (!better || !best_mask) return;
+  T m[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) m[q] = models[((size_t)p * M + bi) * 16 + q];
+  const int n_begin = blockIdx.x * pts_per_block, n_end = min(N, n_begin + pts_per_block);
+  for (int n = n_begin + tid; n < n_end; n += kU3Threads) {
+    const T *x = pts + ((size_t)p * N + n) * 6;
+    T d2 = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {     // the operation order of rigid_residual_kernel: the mask equals the winner's row of K4r
+      const T pred = fma(m[4 * i], x[0], fma(m[4 * i + 1], x[1], fma(m[4 * i + 2], x[2], m[4 * i + 3])));
+      const T e = x[3 + i] - pred;
+      d2 = fma(e, e, d2);
+    }
+    best_mask[(size_t)p * N + n] = d2 < threshold;
+  }
+}
+
+template <typename T>
+int ransac3d_update_launch(const T *pts, const T *models, const uint8_t *valid, const T *res, T threshold, int P, int M, int N,
+                           const T *best_res_in, const T *best_model_in, T *best_res_out, T *best_model_out,
+                           uint8_t *best_mask, int32_t *best_idx, hipStream_t st) {
+  // enough blocks per pair to spread a long point row over the chip, at least 2048 points each
+  int nblk = 1;
+  if (best_mask) nblk = max(1, min((N + 2047) / 2048, max(1, 512 / P)));
+  const int ppb = (N + nblk - 1) / nblk;
+  hipLaunchKernelGGL((ransac3d_update_kernel<T>), dim3(nblk, P), dim3(kU3Threads), 0, st, pts, models, valid, res, threshold, M,
+                     N, ppb, best_res_in, best_model_in, best_res_out, best_model_out, best_mask, best_idx);
+  return check_launch("ransac3d_update_kernel");
 }
 
 // ---- K5: chosen[p,b] = the valid slot closest (Frobenius) to gt[p] -----------------------------------------
@@ -406,6 +532,25 @@ int dr_rigid_residual_f64(const double *pts, const double *models, double thresh
   DR_REQUIRE(pts && models && res_sum, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   return dr::rigid_residual_launch<double>(pts, models, threshold, P, M, N, res_sum, masks, (hipStream_t)stream);
+}
+
+int dr_ransac3d_update_f32(const float *pts, const float *models, const uint8_t *valid, const float *res, float threshold,
+                           int P, int M, int N, const float *best_res_in, const float *best_model_in, float *best_res_out,
+                           float *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream) {
+  DR_REQUIRE(pts && models && res && best_res_in && best_model_in && best_res_out && best_model_out, "null pointer");
+  DR_REQUIRE(best_res_in != best_res_out && best_model_in != best_model_out, "the state is ping-ponged: in and out must differ");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  return dr::ransac3d_update_launch<float>(pts, models, valid, res, threshold, P, M, N, best_res_in, best_model_in,
+                                           best_res_out, best_model_out, best_mask, best_idx, (hipStream_t)stream);
+}
+int dr_ransac3d_update_f64(const double *pts, const double *models, const uint8_t *valid, const double *res, double threshold,
+                           int P, int M, int N, const double *best_res_in, const double *best_model_in, double *best_res_out,
+                           double *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream) {
+  DR_REQUIRE(pts && models && res && best_res_in && best_model_in && best_res_out && best_model_out, "null pointer");
+  DR_REQUIRE(best_res_in != best_res_out && best_model_in != best_model_out, "the state is ping-ponged: in and out must differ");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  return dr::ransac3d_update_launch<double>(pts, models, valid, res, threshold, P, M, N, best_res_in, best_model_in,
+                                            best_res_out, best_model_out, best_mask, best_idx, (hipStream_t)stream);
 }
 
 int dr_select_closest_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,

@@ -26,8 +26,8 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
                valid: Optional[torch.Tensor] = None, path: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None.
     valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row).
-    path (f32 only): 0 = kernel family chosen by shape, 1 = general kernels, 2 = matrix-core filter kernel
-    (include/dransac.h: dr_msac_score_path_f32)."""
+    path (f32 only): 0 = 1 = the general kernels (the default never picks the filter kernel: it is slower),
+    2 = matrix-core candidate filter kernel, opt-in only (include/dransac.h: dr_msac_score_path_f32)."""
     P, N, _ = matches.shape
     M = models.shape[1]
     matches = matches.contiguous()
@@ -399,6 +399,25 @@ def rigid_residual(pts: torch.Tensor, models: torch.Tensor, threshold: float = 0
     L.call(f"dr_rigid_residual_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()),
            L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(res), ptr(masks), stream())
     return res, masks
+
+
+def ransac3d_update(pts: torch.Tensor, models: torch.Tensor, valid: Optional[torch.Tensor], res: torch.Tensor,
+                    threshold: float, best_res: torch.Tensor, best_model: torch.Tensor,
+                    best_mask: Optional[torch.Tensor] = None):
+    """K6 of the 3-D path (dr_ransac3d_update): per pair the valid model with the smallest residual sum replaces the state
+    where it is strictly better.  pts [P,N,6], models [P,M,4,4], valid [P,M] | None, res [P,M]; state best_res [P],
+    best_model [P,4,4] -> NEW (best_res, best_model) tensors (the small state is ping-ponged), best_mask [P,N] updated in
+    place, idx [P] int32 = the round's winner or -1."""
+    P, N, _ = pts.shape
+    M = models.shape[1]
+    out_res, out_model = torch.empty_like(best_res), torch.empty_like(best_model)
+    idx = torch.empty((P,), device=pts.device, dtype=torch.int32)
+    v = None if valid is None else valid.contiguous().view(torch.uint8)
+    mk = None if best_mask is None else best_mask.view(torch.uint8)
+    L.call(f"dr_ransac3d_update_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()), ptr(v),
+           ptr(res.contiguous()), L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(best_res.contiguous()),
+           ptr(best_model.contiguous()), ptr(out_res), ptr(out_model), ptr(mk), ptr(idx), stream())
+    return out_res, out_model, idx
 
 
 def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torch.Tensor):

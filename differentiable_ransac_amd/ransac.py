@@ -565,10 +565,11 @@ class BatchedRANSAC3D(object):
             return dict(models=torch.cat([o[0] for o in out], 1), keep=torch.cat([o[1] for o in out], 1),
                         residuals=torch.cat([o[2] for o in out], 1), mean_residuals=torch.stack([o[3] for o in out], 1))
         with torch.no_grad():
+            matches = matches.contiguous()
             best = torch.full((P,), float("inf"), device=matches.device, dtype=matches.dtype)
             best_model = torch.eye(4, device=matches.device, dtype=matches.dtype).repeat(P, 1, 1)
-            best_mask, masks = None, None
-            ar = torch.arange(P, device=matches.device)
+            best_mask = torch.zeros((P, N), device=matches.device, dtype=torch.bool) if self.keep_masks else None
+            masks = None
             for r in range(rounds):
                 g = None if gumbels is None else gumbels[r]
                 idx = ops.gumbel_topk(logits, self.B, 3, self.tau, g, self._next_seed(), soft=False)["idx"]
@@ -576,13 +577,8 @@ class BatchedRANSAC3D(object):
                 model, R, t, scale, valid = ops.solve_rigid(samples.reshape(P * self.B, 3, 6), None, self.flag)
                 model = model.reshape(P, self.B, 4, 4)
                 res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks)
-                res = torch.where(valid.reshape(P, self.B), res, torch.full_like(res, float("inf")))
-                val, b = res.min(1)
-                better = val < best
-                best = torch.where(better, val, best)
-                best_model = torch.where(better[:, None, None], model[ar, b], best_model)
-                if self.keep_masks:
-                    pick = masks[ar, b]
-                    best_mask = pick if best_mask is None else torch.where(better[:, None], pick, best_mask)
+                # K6 of the 3-D path on the device: arg-min over the valid models, strict "better" test, best model and mask
+                # (one launch; was where / min / gather / where x3: ten torch kernels per round)
+                best, best_model, _ = ops.ransac3d_update(matches, model, valid.reshape(P, self.B), res, self.threshold, best,
+                                                          best_model, best_mask)
             return dict(model=best_model, residual=best, mask=best_mask, masks=masks)
-

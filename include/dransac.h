@@ -44,7 +44,7 @@ const char *dr_last_error(void);
  * K1  Gumbel-softmax top-k sampler     GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42
  *
  *   g[p,b,n] = (logits[p,n] + gumbel[p,b,n]) / tau ; y = softmax_n(g) ; idx = top-k_n(g).
- *   gumbel == NULL  -> noise generated in-kernel: Philox4x32-10(key = seed, counter = (n/4, b, p, 0)),
+ *   gumbel == NULL  -> noise generated in-kernel: Philox4x32-7(key = seed, counter = (n/4, b, p, 0)),
  *                      lane n%4, u = tiny + u24*(1-eps-tiny), gumbel = -log(-log u);
  *   gumbel != NULL  -> explicit noise [P,B,N] (parity mode: index sets are bit-exact w.r.t. the reference).
  *   Outputs: idx [P,B,k] int32, ASCENDING point index (= the order `points[samples != 0]` yields,
@@ -75,14 +75,14 @@ int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t se
  * (any tau > 0).  For callers that only consume `samples != 0` (RANSAC test mode, ransac.py:65); y_sel / lse need the
  * whole noise row and come from dr_gumbel_topk_fwd.  logits [P,N] or NULL (uniform); cdf_ws [P,N] f64 workspace (the
  * per-pair cumulative soft-max weights, overwritten); idx [P,B,k] ascending.
- * Philox4x32-10(key = seed, counter = (draw / 2, b, p, 2)). */
+ * Philox4x32-7(key = seed, counter = (draw / 2, b, p, 2)). */
 int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
                           void *stream);
 int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
                           void *stream);
 
 /* K1u  UniformSampler.batch_generate, samplers/uniform_sampler.py:15-19: idx ~ U{0..N-2}, with replacement.
- * Philox4x32-10(key = seed, counter = (j, b, p, 1)). */
+ * Philox4x32-7(key = seed, counter = (j, b, p, 1)). */
 int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream);
 
 /* The samplers with the Philox key in DEVICE memory (`*seed_dev`, read when the kernel starts) -- for steps captured in a
@@ -190,8 +190,10 @@ int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,
                       int M, int N, double *scores, uint8_t *masks, void *stream);
 /* The same operation with the kernel family named explicitly (dr_msac_score_f32 = path 0):
- *   path 0  choose by shape;
- *   path 1  general kernels: every (model, point) through the f32 fma chain on the vector units (any N);
+ *   path 0  what dr_msac_score_f32 runs: the general kernels (path 1) for every shape -- the filter kernel is never chosen
+ *           automatically (measured slower), it is opt-in through path 2;
+ *   path 1  general kernels: every (model, point) through the f32 fma chain on the vector units (any N; rows of <= 256
+ *           points: a wave per model with 1 / 2 / 4 points per lane, longer rows: a lane owns 8 / 16 points);
  *   path 2  matrix-core candidate filter + the same f32 chain for the candidates + LDS-assembled, line-aligned
  *           mask stream; needs N % 16 == 0 and 16 <= N <= 2048, else DR_EINVAL.  Masks are bit-identical to path 1;
  *           scores are accumulated in 64-bit fixed point (order-independent) and agree with path 1 to f32 rounding. */
@@ -211,6 +213,19 @@ int dr_rigid_residual_f64(const double *pts, const double *models, double thresh
                           double *res_sum, uint8_t *masks, void *stream);
 int dr_rigid_residual_bwd_f32(const float *pts, const float *models, const float *grad_res, int P, int M, int N,
                               float *grad_models, void *stream);
+
+/* K6 of the 3-D path (RANSAC3D.__call__ test branch, ransac.py:383-406 -- dead code upstream; selection rule =
+ * the valid model with the smallest residual sum, as BatchedRANSAC3D documents): per pair the arg-min of res [P,M] over the
+ * valid slots (valid [P,M] or NULL; NaN sums never win; ties -> lowest index), compared STRICTLY with best_res_in [P].
+ * Where it is better: best_res_out / best_model_out [P,16] take the winner and best_mask [P,N] (or NULL) is rewritten with
+ * `d2 < threshold` of the winner; elsewhere the state is copied through and the mask left alone.  The small state is
+ * ping-ponged (in != out) because several blocks serve one pair.  best_idx [P] (or NULL): the round's winner, -1 if kept. */
+int dr_ransac3d_update_f32(const float *pts, const float *models, const uint8_t *valid, const float *res, float threshold,
+                           int P, int M, int N, const float *best_res_in, const float *best_model_in, float *best_res_out,
+                           float *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream);
+int dr_ransac3d_update_f64(const double *pts, const double *models, const uint8_t *valid, const double *res, double threshold,
+                           int P, int M, int N, const double *best_res_in, const double *best_model_in, double *best_res_out,
+                           double *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K5  train-mode best-of-S selection      RANSAC.__call__, ransac.py:87-96

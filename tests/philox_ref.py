@@ -1,17 +1,21 @@
-"""numpy restatement of the counter-based RNG used in-kernel (Philox4x32-10, Salmon et al. SC'11) --
-test infrastructure, mirrors dr::Philox in differentiable_ransac_amd/csrc/dr_common.hpp."""
+"""numpy restatement of the counter-based RNG used in-kernel (Philox4x32-7, Salmon et al. SC'11: seven rounds, the smallest
+Crush-resistant Philox4x32; ten until round 2) -- test infrastructure, mirrors dr::Philox in
+differentiable_ransac_amd/csrc/dr_common.hpp."""
 import numpy as np
 
 M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
 
 
-def philox4x32_10(seed: int, c0, c1, c2, c3):
+ROUNDS = 7
+
+
+def philox4x32(seed: int, c0, c1, c2, c3, rounds: int = ROUNDS):
     c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint32) for c in np.broadcast_arrays(c0, c1, c2, c3)]
     k0 = np.uint32(seed & 0xFFFFFFFF)
     k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = M0 * c0.astype(np.uint64)
             p1 = M1 * c2.astype(np.uint64)
             h0, l0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
@@ -22,12 +26,17 @@ def philox4x32_10(seed: int, c0, c1, c2, c3):
     return c0, c1, c2, c3
 
 
+def philox4x32_10(seed: int, c0, c1, c2, c3):
+    """The ten-round generator (known-answer test against the Random123 vectors only)."""
+    return philox4x32(seed, c0, c1, c2, c3, rounds=10)
+
+
 def gumbel_noise_f32(seed: int, P: int, B: int, N: int):
     """noise [P,B,N] as the f32 kernel generates it: counter (n/4, b, p, 0), word n%4."""
     q = np.arange((N + 3) // 4, dtype=np.uint32)[None, None, :]
     b = np.arange(B, dtype=np.uint32)[None, :, None]
     p = np.arange(P, dtype=np.uint32)[:, None, None]
-    w = np.stack(philox4x32_10(seed, q, b, p, np.uint32(0)), axis=-1).reshape(P, B, -1)[:, :, :N]
+    w = np.stack(philox4x32(seed, q, b, p, np.uint32(0)), axis=-1).reshape(P, B, -1)[:, :, :N]
     r = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
     tiny, eps = np.float32(1.17549435e-38), np.float32(1.1920928955078125e-07)
     u = r * (np.float32(1.0) - eps - tiny) + tiny
@@ -38,5 +47,5 @@ def uniform_indices(seed: int, P: int, B: int, k: int, N: int):
     j = np.arange(k, dtype=np.uint32)[None, None, :]
     b = np.arange(B, dtype=np.uint32)[None, :, None]
     p = np.arange(P, dtype=np.uint32)[:, None, None]
-    w0 = philox4x32_10(seed, j, b, p, np.uint32(1))[0]
+    w0 = philox4x32(seed, j, b, p, np.uint32(1))[0]
     return ((w0.astype(np.uint64) * np.uint64(max(N - 1, 1))) >> np.uint64(32)).astype(np.int64)

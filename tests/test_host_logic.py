@@ -108,3 +108,25 @@ def test_ransac_layers_wire_the_plugins_like_the_reference():
     # cv_utils.denormalize_pts: pts * max(im_size) + (w/2, h/2), im_size = (h, w)
     out = denormalize_pts(torch.tensor([[0.0, 0.0], [0.5, -0.25]]), torch.tensor([480.0, 640.0]))
     assert torch.equal(out, torch.tensor([[320.0, 240.0], [640.0, 80.0]]))
+
+
+def test_philox_restatement_known_answers():
+    """tests/philox_ref.py (the numpy restatement the in-kernel stream is pinned by) against the Random123 known-answer
+    vectors of philox4x32-10; the kernels run the same round function seven times (philox_ref.ROUNDS)."""
+    import numpy as np
+    from tests import philox_ref as R
+    kat = [(0, (0, 0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           (0xffffffffffffffff, (0xffffffff,) * 4, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x299f31d0 << 32) | 0xa4093822, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for key, ctr, out in kat:
+        got = R.philox4x32_10(key, *[np.uint32(c) for c in ctr])
+        assert tuple(int(x) for x in got) == out
+    assert R.ROUNDS == 7
+    a = R.philox4x32(5, np.arange(4, dtype=np.uint32), 1, 2, 0)
+    b = R.philox4x32(5, np.arange(4, dtype=np.uint32), 1, 2, 0, rounds=10)
+    assert not np.array_equal(a[0], b[0])
+    # words are uniform enough for a smoke check: mean of 2^16 draws of the top 24 bits
+    w = R.philox4x32(77, np.arange(1 << 14, dtype=np.uint32), 3, 1, 0)
+    u = np.concatenate([(x >> np.uint32(8)).astype(np.float64) for x in w]) / 2.0 ** 24
+    assert abs(u.mean() - 0.5) < 0.005 and abs(u.var() - 1 / 12) < 0.002
