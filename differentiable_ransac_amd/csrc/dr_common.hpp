@@ -150,12 +150,15 @@ struct Philox {
   }
 };
 
-// u32 -> Gumbel(0,1) sample, mirroring torch.distributions.Gumbel: u = tiny + r*(1-eps-tiny), r = u24 * 2^-24
+// u32 -> Gumbel(0,1) sample, mirroring torch.distributions.Gumbel: u = tiny + r*(1-eps-tiny), r uniform on a 2^-24 grid of
+// [0, 1].  r = RNE-to-24-bits(bits) * 2^-32 (one v_cvt_f32_u32: no shift) and u = fma(cvt, 2^-32 * (1-eps-tiny), tiny): the
+// scale factor is folded exactly (a power of two times the constant), so u equals fl(r * c + tiny) bit for bit and costs two
+// instructions instead of four (shift, convert, multiply, fma).
 __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
-  float r = (float)(bits >> 8) * 5.9604644775390625e-08f;  // [0,1)
-  float u = r * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f) + 1.17549435e-38f;
-  // u in [2^-126, 1) and -ln u in [6e-8, 87.4]: both log arguments are normal numbers, so the raw v_log_f32
-  // (no denormal fix-up sequence) is exact to its 1-ulp spec
+  constexpr float kScale = 2.3283064365386963e-10f * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f);   // 2^-32 * c
+  float u = __builtin_fmaf((float)bits, kScale, 1.17549435e-38f);   // in [2^-126, 1 - eps]
+  // -ln u in [1.2e-7, 87.4]: both log arguments are normal numbers, so the raw v_log_f32 (no denormal fix-up sequence) is
+  // exact to its 1-ulp spec
   const float kLn2 = 0.69314718055994530942f;
 #if defined(DR_K1_NOISE_EXPERIMENT) && DR_K1_NOISE_EXPERIMENT == 1   // timing experiment: no logarithm at all
   return u;
@@ -163,7 +166,13 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
   return -kLn2 * __builtin_amdgcn_logf(u);
 #endif
   const float a = -kLn2 * __builtin_amdgcn_logf(u);
-  return -kLn2 * __builtin_amdgcn_logf(a);
+  float g = -kLn2 * __builtin_amdgcn_logf(a);
+  // the sample is an f32 VALUE: rounded here, then added to the logit by the caller with a second rounding -- exactly what the
+  // oracle does with the noise tensor the general kernel reports.  The empty asm hides the multiply from -ffp-contract=fast,
+  // which otherwise fuses it into the caller's `logit + noise` (one rounding): a top-k decided by the last bit then differs
+  // from the oracle's on the reported noise (seen as soon as the generator changed: tests/test_gpu_round2.py, 2000 x 1024 x 5)
+  asm("" : "+v"(g));
+  return g;
 }
 
 // ---- optional per-stage cycle accounting (profiling builds only: -DDR_PROFILE_STAGES) --------------------

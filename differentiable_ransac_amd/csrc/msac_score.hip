@@ -416,16 +416,48 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
 //   sv = d2/thr2 - 1 (inlier <=> sv < 0); the soft score max(-sv, 0) is accumulated as min(sv, 0) with ONE integer
 //   instruction per point: for IEEE bit patterns min_i32(bits(sv), 0) is sv when the sign bit is set and +0 otherwise
 //   (fmaxf costs two -- the compiler has to canonicalise its operand first); a 0/0 point (sv = +NaN) contributes 0.
+// DR_K4_SPAIR = 1: a model coefficient reaches the packed FMAs as a REAL SGPR pair (c, c) instead of one SGPR broadcast through
+// op_sel.  With the op_sel form the upper half of the aligned pair a `v_pk_fma_f32 ..., s[16:17] op_sel_hi:[1,0,0]` names is
+// undefined, the register allocator parks something else there -- in the shipped round-2 build the destination of the NEXT
+// model's `s_load_dword` -- and the wait-count pass, which sees a read of s17 with a scalar load to s17 in flight, puts
+// `s_waitcnt lgkmcnt(0)` right behind the prefetch: the "prefetch one model ahead" was a scalar-cache round trip per model,
+// in full, at the top of every iteration (ISA: profiles/r3_k4_isa_budget.md).  The empty asm makes both halves live.
+// Both measured in the step on one box, alternating libraries (scratch/r3_gpu_d.sh, r3_gpu_e.sh), and both OFF: pairs alone 0.602 /
+// 0.610 ms against 0.601 / 0.605 ms (nothing: the wait stays where it was, the SALU copies de-interleaving the loaded registers
+// follow the load at once); pairs + the hand-placed request below 0.623 / 0.628 ms against 0.601 / 0.602 ms -- a real prefetch
+// is 4 % SLOWER than the exposed round trip.  At four waves per SIMD the other three waves cover a parked one, and what the
+// prefetch costs (nine more scalar copies per model, a pinned scheduling region, 16 more live SGPRs) is not free.  The scalar
+// fetch is not what the kernel waits for.
+#ifndef DR_K4_SPAIR
+#define DR_K4_SPAIR 0
+#endif
+#ifndef DR_K4_ASMPREF
+#define DR_K4_ASMPREF 0   // the next model's scalar loads as inline asm, awaited at the end of the iteration (see the model loop)
+#endif
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v2f sgpr_pair(float c) {
+#if DR_K4_SPAIR
+  const uint32_t b = __builtin_amdgcn_readfirstlane(__float_as_uint(c));
+  unsigned long long pr = ((unsigned long long)b << 32) | b;
+  asm("" : "+s"(pr));
+  v2f r;
+  __builtin_memcpy(&r, &pr, 8);
+  return r;
+#else
+  return splat(c);
+#endif
+}
+
 __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)[8], const v2f (&x2)[8], const v2f (&y2)[8],
-                                            const float (&m)[9], float inv_thr2, bool finite, v2f &nacc) {
+                                            const v2f (&ms)[9], float inv_thr2, bool finite, v2f &nacc) {
   uint32_t sb[16];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const v2f a0 = x2[j] * splat(m[0]) + (y2[j] * splat(m[3]) + splat(m[6]));
-    const v2f a1 = x2[j] * splat(m[1]) + (y2[j] * splat(m[4]) + splat(m[7]));
-    const v2f a2 = x2[j] * splat(m[2]) + (y2[j] * splat(m[5]) + splat(m[8]));
-    const v2f b0 = x1[j] * splat(m[0]) + (y1[j] * splat(m[1]) + splat(m[2]));
-    const v2f b1 = x1[j] * splat(m[3]) + (y1[j] * splat(m[4]) + splat(m[5]));
+    const v2f a0 = x2[j] * ms[0] + (y2[j] * ms[3] + ms[6]);
+    const v2f a1 = x2[j] * ms[1] + (y2[j] * ms[4] + ms[7]);
+    const v2f a2 = x2[j] * ms[2] + (y2[j] * ms[5] + ms[8]);
+    const v2f b0 = x1[j] * ms[0] + (y1[j] * ms[1] + ms[2]);
+    const v2f b1 = x1[j] * ms[3] + (y1[j] * ms[4] + ms[5]);
     const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
     const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
     const v2f rr = r * r;
@@ -467,6 +499,12 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 // Same algorithm with a lane owning 16 consecutive points (64 VGPRs), 128-thread blocks (two waves cover 2048 points):
 // every mask row segment is one 16-byte store per lane (1 KiB per wave instruction) -- the mask stream is store-ISSUE
 // bound with 8-byte stores.  Requires N % 16 == 0 (otherwise the 8-point kernel above is used).
+#ifndef DR_K4_ZERO_RUNS
+#define DR_K4_ZERO_RUNS 0   // 1: runs of invalid slots zero-filled as contiguous byte ranges.  Measured in the step, same box,
+                            // alternating libraries (scratch/r3_gpu_c.sh): scoring launch 0.621 / 0.627 ms against 0.606 / 0.606 ms
+                            // for the row pieces -- SLOWER (the sweep is a store-only phase at the end of the block; the row
+                            // pieces of an invalid slot cost no more than a valid row's store): kept as a knob, off
+#endif
 #ifndef DR_K4_SMALL
 #define DR_K4_SMALL 1   // 0: rows of <= 256 points take the general kernels too (A/B builds)
 #endif
@@ -571,20 +609,53 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
       int ml = 32 * wd + __builtin_ctz(live);
       live &= live - 1;
       float mc[9];
+#if DR_K4_ASMPREF
+      {   // the first model of the word through the same path as the others (one kind of value in the loop-carried registers)
+        u32x8 f8;
+        uint32_t f1;
+        const float *src = md + ml * 9;
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(f8), "=&s"(f1) : "s"(src));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mc[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(f8[q]));
+        mc[8] = __uint_as_float(__builtin_amdgcn_readfirstlane(f1));
+      }
+#else
 #pragma unroll
       for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
+#endif
       while (true) {
         float m[9];
+        v2f ms[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) m[q] = mc[q];
+        for (int q = 0; q < 9; ++q) { m[q] = mc[q]; ms[q] = sgpr_pair(mc[q]); }
         const int cur = ml;
         const bool more = live != 0;
+#if DR_K4_ASMPREF
+        // The next model's nine coefficients, requested NOW and awaited at the END of this iteration.  Written as the two
+        // scalar loads themselves: the compiler's own loads are followed at once by the SALU copies that de-interleave them
+        // (and so by `s_waitcnt lgkmcnt(0)`), whatever the source order.  The matching wait below takes the results as
+        // in/out operands, so nothing that reads them can move above it.  Issued in EVERY iteration (the last one re-reads
+        // its own model): a conditional request makes the results a phi of inline-asm values, which the compiler treats
+        // as divergent and keeps in VGPRs.
+        if (more) {
+          ml = 32 * wd + __builtin_ctz(live);
+          live &= live - 1;
+        }
+        u32x8 nx8;
+        uint32_t nx1;
+        {
+          const float *src = md + ml * 9;
+          asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(nx8), "=&s"(nx1) : "s"(src));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the request stays HERE, ahead of the evaluation
+#else
         if (more) {
           ml = 32 * wd + __builtin_ctz(live);
           live &= live - 1;
 #pragma unroll
           for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
         }
+#endif
 #if DR_K4_PRECHECK
         constexpr bool finite = true;   // the others never get here (prologue)
 #else
@@ -600,7 +671,7 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
         const bool finite = ex != 0x7f800000u && anybit != 0u;
 #endif
         v2f nacc = splat(0.f);
-        const uint4 q = msac_eval16(x1, y1, x2, y2, m, inv_thr2, finite, nacc);
+        const uint4 q = msac_eval16(x1, y1, x2, y2, ms, inv_thr2, finite, nacc);
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;
 #if DR_K4_SADDR
         // row base = wave-uniform 64-bit address (scalar ALU), lane part = unsigned 32-bit offset: the store takes the SGPR-base form
@@ -612,10 +683,44 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
         // (row sums + four adding lanes instead of the two row_bcast steps: no gain in the step, 0.606 vs 0.609 ms)
         if (lane == 63) atomicAdd(&part[wv][cur], finite ? a : NAN);   // ds_add_f32, no return: nothing to wait for (-2 %)
+#if DR_K4_ASMPREF
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nx8), "+s"(nx1));   // (also before leaving: the request must not outlive its registers)
+#endif
         if (!more) break;
+#if DR_K4_ASMPREF
+#pragma unroll
+        // (readfirstlane: inline-asm results count as divergent -- without it the whole loop-carried model moves to VGPRs,
+        //  the first fetch becomes a vector load and every iteration starts with `s_waitcnt vmcnt(0)`, i.e. waits for the
+        //  previous mask store: 0.69 instead of 0.60 ms per launch.  On an SGPR the intrinsic is a plain copy.)
+        for (int q = 0; q < 8; ++q) mc[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(nx8[q]));
+        mc[8] = __uint_as_float(__builtin_amdgcn_readfirstlane(nx1));
+#endif
       }
     }
     // empty mask rows of the invalid slots (store-only)
+#if DR_K4_ZERO_RUNS
+    // The five-point solvers fill a sample's ten slots from both ends (|z| <= 1 roots upwards from slot 0, |z| > 1 roots
+    // downwards from slot 9), so the invalid slots of a sample are ONE run in the middle: 5.5 rows = 11 KB on average at the
+    // benchmark shape.  With the whole row inside this block's chunk (N <= 2048) a run of R rows is the contiguous byte range
+    // [r0 N, (r0 + R) N) of the output: the half-block's 128 lanes sweep it 2 KiB per step (whole 128-byte lines except at the
+    // two ends) instead of writing R row pieces of 1024 + 976 bytes per wave.
+    if (write_masks && gridDim.y == 1 && N <= kChunk16) {
+      static_assert(kTile == 64, "the run walk below reads the tile's validity as one 64-bit word");
+      unsigned long long inv = ~(((unsigned long long)vword[1] << 32) | vword[0]);
+      if (mcount < 64) inv &= (mcount > 0) ? ((1ull << mcount) - 1ull) : 0ull;
+      uint8_t *tile_base = masks + ((size_t)p * M + m0) * N;
+      while (inv) {
+        const int r0 = __builtin_ctzll(inv);
+        const unsigned long long rest = ~(inv >> r0);
+        const int len = rest ? __builtin_ctzll(rest) : 64 - r0;
+        inv &= ~((((len < 64) ? (1ull << len) : 0ull) - 1ull) << r0);
+        const uint32_t nbytes = (uint32_t)len * (uint32_t)N;
+        const uint8_t *run = tile_base + (size_t)r0 * N;      // wave-uniform
+        for (uint32_t off = (uint32_t)tid * 16u; off < nbytes; off += (uint32_t)kH16 * 16u)
+          mask_row_store_saddr(run, off, 0u, 0u, 0u, 0u);
+      }
+    } else
+#endif
     if (write_masks && have) {
 #pragma unroll
       for (int wd = 0; wd < kTile / 32; ++wd) {

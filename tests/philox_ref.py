@@ -37,9 +37,10 @@ def gumbel_noise_f32(seed: int, P: int, B: int, N: int):
     b = np.arange(B, dtype=np.uint32)[None, :, None]
     p = np.arange(P, dtype=np.uint32)[:, None, None]
     w = np.stack(philox4x32(seed, q, b, p, np.uint32(0)), axis=-1).reshape(P, B, -1)[:, :, :N]
-    r = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    # r = the word rounded to 24 significant bits (what v_cvt_f32_u32 does) * 2^-32, u = fl(r * (1 - eps - tiny) + tiny)
     tiny, eps = np.float32(1.17549435e-38), np.float32(1.1920928955078125e-07)
-    u = r * (np.float32(1.0) - eps - tiny) + tiny
+    r = w.astype(np.float32).astype(np.float64) * 2.0 ** -32
+    u = (r * np.float64(np.float32(1.0) - eps - tiny) + np.float64(tiny)).astype(np.float32)
     return -np.log(-np.log(u.astype(np.float64))).astype(np.float32)
 
 
