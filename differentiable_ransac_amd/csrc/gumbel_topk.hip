@@ -452,15 +452,27 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 #ifndef DR_K1_STREAM
 #define DR_K1_STREAM 1   // 0: the general two-pass kernel (A/B builds)
 #endif
-template <int K, bool kSoft>
+#ifndef DR_K1_STREAM_SPLIT
+#define DR_K1_STREAM_SPLIT 1   // 0: always one wave per row
+#endif
+// kW = waves per row (1 or kRowsPerBlock).  With few rows (BASELINE configs[3]: 2048 hypotheses of ONE pair) a wave per row is
+// two waves per SIMD on this chip: the kernel's 32 registers would allow eight, and its dependent Philox rounds and logarithms
+// want them.  kW = 4: the block's four waves take interleaved 64-group slices of ONE row, each keeps the top k of its slice,
+// and wave 0 merges the 4 k candidates through LDS -- same total order (value descending, index ascending), so the same
+// index set; the soft-max statistics are combined the same way (per-wave running max / sum, then across the four waves).
+template <int K, bool kSoft, int kW>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(const float *__restrict__ logits, uint64_t seed, int B,
                                                                                int N, int k, int32_t *__restrict__ idx,
                                                                                float *__restrict__ y_sel, float *__restrict__ lse_out,
                                                                                const uint64_t *__restrict__ seed_ptr) {
+  __shared__ float s_cv[kW > 1 ? kRowsPerBlock * kMaxK : 1];
+  __shared__ int s_ci[kW > 1 ? kRowsPerBlock * kMaxK : 1];
+  __shared__ float s_mx[kRowsPerBlock], s_sm[kRowsPerBlock];
   if (seed_ptr) seed = *seed_ptr;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
-  if (b >= B) return;
+  const int part = kW > 1 ? wv : 0;
+  const int p = blockIdx.y, b = kW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * kRowsPerBlock + wv);
+  if (b >= B) return;   // kW > 1: block-uniform (one row per block), so the barrier below is reached by all or none
   const int groups = N >> 2;
   const size_t row = (size_t)p * B + b;
   const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
 #pragma unroll
   for (int s = 0; s < K; ++s) { tv[s] = -INFINITY; ti[s] = 0x7fffffff; }
   float mx = -INFINITY, sm = 0.f;
-  for (int q = lane; q < groups; q += 64) {
+  for (int q = lane + 64 * part; q < groups; q += 64 * kW) {
     uint32_t r[4];
     Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
     const float4 l = lg[q];
@@ -506,8 +518,12 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
     wmx = row_max(mx);
     sm *= (mx == -INFINITY) ? 0.f : exp_t<float>(mx - wmx);
     sm = row_sum(sm);
-    lse = wmx + log_t<float>(sm);
-    inv_sm = 1.0f / sm;
+    if (kW > 1) {   // this wave's (max, sum) -> the row's
+      if (lane == 0) { s_mx[wv] = wmx; s_sm[wv] = sm; }
+    } else {
+      lse = wmx + log_t<float>(sm);
+      inv_sm = 1.0f / sm;
+    }
   }
   // merge: k rounds of (value desc, index asc) arg-max over the lanes' heads; the winning lane pops its head
   int won[kMaxK];
@@ -530,6 +546,50 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
       ti[K - 1] = 0x7fffffff;
     }
   }
+  if (kW > 1) {
+    // the four waves' top-k lists -> LDS -> wave 0 ranks the 4 k candidates (value descending, index ascending)
+    if (lane < k) {
+      int me = 0x7fffffff;
+      float mg = -INFINITY;
+      for (int r = 0; r < k; ++r) if (r == lane) { me = won[r]; mg = wong[r]; }
+      s_cv[wv * kMaxK + lane] = mg;
+      s_ci[wv * kMaxK + lane] = me;
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    if (kSoft) {
+      wmx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+      sm = 0.f;
+#pragma unroll
+      for (int w = 0; w < kW; ++w) sm += (s_mx[w] == -INFINITY) ? 0.f : s_sm[w] * exp_t<float>(s_mx[w] - wmx);
+      lse = wmx + log_t<float>(sm);
+      inv_sm = 1.0f / sm;
+    }
+    const int nc = kW * k;                     // <= 32 candidates; slice w, entry r at lane w * k + r
+    const bool have = lane < nc;
+    const int cw = have ? lane / k : 0, cr = have ? lane % k : 0;
+    const float cv = have ? s_cv[cw * kMaxK + cr] : -INFINITY;
+    const int ci = have ? s_ci[cw * kMaxK + cr] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < nc; ++j) {
+      const float ov = __shfl(cv, j, 64);
+      const int oi = __shfl(ci, j, 64);
+      rank += (ov > cv) || (ov == cv && oi < ci);
+    }
+    const bool win = have && rank < k && ci != 0x7fffffff;
+    const unsigned long long wb = __ballot(win);
+    int pos = 0;
+    for (int j = 0; j < nc; ++j) {
+      const int oi = __shfl(ci, j, 64);
+      if ((wb >> j) & 1ull) pos += oi < ci;
+    }
+    if (win) {
+      idx[row * k + pos] = ci;
+      if (kSoft) y_sel[row * k + pos] = exp_t<float>(cv - wmx) * inv_sm;
+    }
+    if (kSoft && lane == 0) lse_out[row] = lse;
+    return;
+  }
   if (lane < k) {
     int me = 0;
     float mg = 0.f;
@@ -545,8 +605,16 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
 template <int K>
 static void stream_launch(bool soft, dim3 grid, dim3 block, hipStream_t st, const float *logits, uint64_t seed, int B, int N, int k,
                           int32_t *idx, float *y_sel, float *lse, const uint64_t *seed_ptr) {
-  if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
-  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+  // few rows: four waves per row (one row per block) -- the wave-per-row grid would leave the SIMDs at <= 4 waves each
+  const long rows = (long)grid.y * B;
+  if (DR_K1_STREAM_SPLIT && rows <= 4096 && N >= 4 * 64 * 4 * 4) {
+    const dim3 g2(B, grid.y);
+    if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+    else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+    return;
+  }
+  if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
 }
 
 template <typename T>

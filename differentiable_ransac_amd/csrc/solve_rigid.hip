@@ -228,22 +228,22 @@ __global__ __launch_bounds__(kRThreads) void rigid_residual_kernel(const T *__re
 #define DR_K4R_16 1
 #endif
 #ifndef DR_K4R_TILE
-#define DR_K4R_TILE 16
+#define DR_K4R_TILE 0    // > 0: fixed models per block (A/B builds); 0: chosen per launch so that the grid is whole rounds of blocks
 #endif
-constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts, kR16Models = DR_K4R_TILE;
+constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts, kR16MaxTile = 64;
 typedef float v2r __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2r rsplat(float a) { return (v2r){a, a}; }
 __global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(const float *__restrict__ pts, const float *__restrict__ models,
                                                                            float threshold, int M, int N, float *__restrict__ res_sum,
                                                                            uint8_t *__restrict__ masks, int chunks_per_block,
-                                                                           int use_atomic) {
-  __shared__ float part[kR16Threads / 64][kR16Models];
-  const int p = blockIdx.z, m0 = blockIdx.x * kR16Models;
+                                                                           int use_atomic, int tile) {
+  __shared__ float part[kR16Threads / 64][kR16MaxTile];
+  const int p = blockIdx.z, m0 = blockIdx.x * tile;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int mcount = min(kR16Models, M - m0);
+  const int mcount = min(tile, M - m0);
   const float *pt = pts + (size_t)p * N * 6;
   const float *md = models + ((size_t)p * M + m0) * 16;
-  if (tid < (kR16Threads / 64) * kR16Models) (&part[0][0])[tid] = 0.f;
+  if (tid < (kR16Threads / 64) * kR16MaxTile) (&part[0][0])[tid] = 0.f;
   __syncthreads();
   const v2r thr2 = rsplat(threshold);
   const int c_begin = blockIdx.y * chunks_per_block;
@@ -344,17 +344,34 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
   if constexpr (sizeof(T) == 4) {
     // (thresholds below 1e-12 would put `thr - d2` near the bit-6 exponent test's blind spot: general kernel)
     if (DR_K4R_16 && masks && N % 16 == 0 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0 && threshold > T(1e-12)) {
-      const int tiles = (M + kR16Models - 1) / kR16Models;
+      // One block = (pair, model tile, 2048-point chunk); every block of a launch takes the same time (tile x chunk
+      // evaluations), so the launch takes ceil(blocks / resident blocks) block times: 3 200 blocks on 1 536 resident ones
+      // (138 registers: three waves per SIMD, six 2-wave blocks per CU) are THREE rounds for 2.08 rounds of work.  The tile is
+      // therefore chosen per launch: the largest grid that is a whole number of rounds -- at C4 (one pair, 25 chunks) 61
+      // tiles of 34 models = 1 525 blocks, one round.
+      static int resident = 0;
+      if (!resident) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = 6 * max(cus, 1);
+      }
       const int chunks = (N + kR16Chunk - 1) / kR16Chunk;
-      int ny = 1;
-      const long base = (long)P * tiles;
-      if (chunks > 1 && base < 4096) ny = (int)min((long)chunks, (4096 + base - 1) / base);
-      const int cpb = (chunks + ny - 1) / ny;
-      ny = (chunks + cpb - 1) / cpb;
+      int ny = chunks;                      // one chunk per block whenever the row is longer than a chunk (atomics across them)
+      int tile = DR_K4R_TILE;
+      if (tile <= 0) {
+        const long per_tile = (long)P * ny;                       // blocks added by one more tile
+        const long min_tiles = (M + kR16MaxTile - 1) / kR16MaxTile;
+        long rounds = max(1L, (per_tile * min_tiles + resident - 1) / resident);
+        long tiles_t = max(min_tiles, rounds * resident / per_tile);      // as many tiles as fit in `rounds` whole rounds
+        tile = (int)((M + tiles_t - 1) / tiles_t);
+        tile = min(kR16MaxTile, max(4, (tile + 1) & ~1));
+      }
+      const int tiles = (M + tile - 1) / tile;
+      const int cpb = 1;
       const int use_atomic = ny > 1;
       if (use_atomic && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
       hipLaunchKernelGGL(rigid_residual_kernel_f32_16, dim3(tiles, ny, P), dim3(kR16Threads), 0, st, (const float *)pts,
-                         (const float *)models, (float)threshold, M, N, (float *)res_sum, masks, cpb, use_atomic);
+                         (const float *)models, (float)threshold, M, N, (float *)res_sum, masks, cpb, use_atomic, tile);
       return check_launch("rigid_residual_kernel_f32_16");
     }
   }
