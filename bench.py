@@ -79,8 +79,8 @@ def parse():
                     help="pairs: every rank owns its own pairs (weak scaling); hypotheses: every rank draws hyps/N hypotheses "
                          "for the SAME pairs and the winners are merged with two tiny all_gathers (strong scaling, P < G)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
-                    help="skip the two informational regions after the timed one (the step followed by the final refit; the "
-                         "step with the top-down sampler)")
+                    help="skip the informational regions after the timed one (two batches in flight on two streams; the step "
+                         "followed by the final refit; the step with the top-down sampler)")
     ap.add_argument("--extras", dest="extras", action="store_true", help="(default) kept for older command lines")
     ap.set_defaults(extras=True)
     ap.add_argument("--sampler", default=None, choices=["gumbel", "topdown", "uniform"])
@@ -392,7 +392,7 @@ def cpu_baseline(args, w, pairs_data):
 def pmc_traffic(kernel_key, shape):
     """HBM bytes per launch of the scoring kernel from the committed rocprofv3 PMC passes, valid only for the kernel
     source they were collected on: the JSON carries the sha256 of the source files, compared with the tree's."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_fetch_write.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc_fetch_write.json")
     if not os.path.exists(path):
         return None, "no PMC capture committed for this round"
     rec = json.load(open(path))
@@ -400,16 +400,16 @@ def pmc_traffic(kernel_key, shape):
     for rel, sha in srcs.items():
         p = os.path.join(ROOT, rel)
         if not os.path.exists(p) or hashlib.sha256(open(p, "rb").read()).hexdigest() != sha:
-            return None, f"{rel} changed since profiles/r2_pmc_fetch_write.json was collected: traffic not attributable"
+            return None, f"{rel} changed since profiles/r3_pmc_fetch_write.json was collected: traffic not attributable"
     if rec.get("workload") != shape:
-        return None, f"profiles/r2_pmc_fetch_write.json was collected on {rec.get('workload')}, this run is {shape}"
+        return None, f"profiles/r3_pmc_fetch_write.json was collected on {rec.get('workload')}, this run is {shape}"
     pmc = rec.get("kernels", {}).get(kernel_key, {})
     if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
-        return None, f"no counters for {kernel_key} in profiles/r2_pmc_fetch_write.json"
+        return None, f"no counters for {kernel_key} in profiles/r3_pmc_fetch_write.json"
     # gfx950: FETCH_SIZE shows half the bytes of 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled (upper bound:
     # most of this kernel's reads are scalar-cache model loads); WRITE_SIZE taken as is (matches the mask bytes to 0.2 %)
     return ((2.0 * pmc["FETCH_SIZE"]["avg"] + pmc["WRITE_SIZE"]["avg"]) * 1024.0,
-            "profiles/r2_pmc_fetch_write.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, source hashes match")
+            "profiles/r3_pmc_fetch_write.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, source hashes match")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -643,7 +643,7 @@ def main():
 
     # informational second region: the same K steps with two batches in flight on two streams
     overlap = None
-    if world == 1:
+    if world == 1 and args.extras:
         n2 = 1 if len(streams) > 1 else 2
         s2 = [torch.cuda.Stream(device=dev) for _ in range(n2)]
         keep = [None] * n2

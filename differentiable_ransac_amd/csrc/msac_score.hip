@@ -428,6 +428,16 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
 // is 4 % SLOWER than the exposed round trip.  At four waves per SIMD the other three waves cover a parked one, and what the
 // prefetch costs (nine more scalar copies per model, a pinned scheduling region, 16 more live SGPRs) is not free.  The scalar
 // fetch is not what the kernel waits for.
+// Round 3, measured in the step on one box, alternating libraries (scratch/r3_gpu_i.sh; scoring launch, two rounds):
+//   base 0.5977 / 0.5988 ms;  + v_bitop3 mask op 0.5962 / 0.5912 ms (kept);  + LDS quad-sum reduction 0.642 / 0.633 ms (7 % SLOWER:
+//   eleven fewer vector instructions per model, but 16 KB of LDS per workgroup, a masked ds_write per model in front of the next
+//   model's scalar-load wait, and the dense pass at the end of the tile; off).
+#ifndef DR_K4_BITOP3
+#define DR_K4_BITOP3 1
+#endif
+#ifndef DR_K4_LDSRED
+#define DR_K4_LDSRED 0   // 1: per-model score partials as quad sums in LDS, one dense reduction per tile (0: six DPP steps per model)
+#endif
 #ifndef DR_K4_SPAIR
 #define DR_K4_SPAIR 0
 #endif
@@ -490,7 +500,14 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
   for (int g = 0; g < 4; ++g) {
     const uint32_t lo2 = __builtin_amdgcn_perm(sb[4 * g + 1], sb[4 * g], 0x0c0c0703u);
     const uint32_t hi2 = __builtin_amdgcn_perm(sb[4 * g + 3], sb[4 * g + 2], 0x07030c0cu);
+#if DR_K4_BITOP3
+    // (lo2 | hi2) & 0x20202020 (0x80808080) as ONE three-input boolean op (v_bitop3_b32, truth table 0xA8), then the shift
+    uint32_t bits;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8" : "=v"(bits) : "v"(lo2), "v"(hi2), "s"(DR_K4_CLAMP ? 0x20202020u : 0x80808080u));
+    wq[g] = finite ? (bits >> (DR_K4_CLAMP ? 5 : 7)) : 0u;
+#else
     wq[g] = finite ? (((lo2 | hi2) >> (DR_K4_CLAMP ? 5 : 7)) & 0x01010101u) : 0u;
+#endif
   }
   return make_uint4(wq[0], wq[1], wq[2], wq[3]);
 }
@@ -541,6 +558,13 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
                                                                      int chunks_per_block, int use_atomic) {
   constexpr int kTile = DR_K4_TILE16;
   __shared__ float part[kT16 / kWave][kTile];
+#if DR_K4_LDSRED
+  // [wave][slot][quad]: the sixteen quad sums of a wave's (model, 1024 points) evaluation, written once per model (two DPP steps
+  // + one ds_write_b32 from every fourth lane) and reduced densely after the tile's last model: lane l adds the sixteen
+  // partials of slot l.  16 KB per workgroup; replaces four more DPP steps, two moves and an LDS atomic per model.
+  __shared__ __align__(16) float part16[kT16 / kWave][kTile][16];
+  static_assert(kTile == 64, "the dense reduction maps lane l to slot l of the tile");
+#endif
   const int p = blockIdx.z;
   // wave-uniform BY CONSTRUCTION (a half is two whole waves) -- and it must look so to the compiler: with `half` in a VGPR the
   // tile's model coefficients stop being scalar loads and the kernel is 40 % slower
@@ -680,9 +704,15 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
 #else
         if (write_masks && have) mask_row_store(masks + ((size_t)p * M + m0 + cur) * N + n0, q.x, q.y, q.z, q.w);
 #endif
+#if DR_K4_LDSRED
+        a += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        a += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        if ((lane & 3) == 0) part16[wv][cur][lane >> 2] = a;
+#else
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
         // (row sums + four adding lanes instead of the two row_bcast steps: no gain in the step, 0.606 vs 0.609 ms)
         if (lane == 63) atomicAdd(&part[wv][cur], finite ? a : NAN);   // ds_add_f32, no return: nothing to wait for (-2 %)
+#endif
 #if DR_K4_ASMPREF
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nx8), "+s"(nx1));   // (also before leaving: the request must not outlive its registers)
 #endif
@@ -697,6 +727,19 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
 #endif
       }
     }
+#if DR_K4_LDSRED
+    {   // dense reduction of this chunk's quad sums: lane l <-> slot l of the tile (evaluated slots only: the others hold stale data)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const bool mine = (vword[lane >> 5] >> (lane & 31)) & 1u;
+      if (mine) {
+        const float4 *src = reinterpret_cast<const float4 *>(&part16[wv][lane][0]);
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        part[wv][lane] += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#endif
     // empty mask rows of the invalid slots (store-only)
 #if DR_K4_ZERO_RUNS
     // The five-point solvers fill a sample's ten slots from both ends (|z| <= 1 roots upwards from slot 0, |z| > 1 roots

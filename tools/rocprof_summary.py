@@ -4,8 +4,9 @@
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py ...
     python tools/rocprof_summary.py gpurun_out/prof/bench_results.db profiles/rNN_bench_kernel_stats.md "command line" [first N | skip N]
 
-`first N` / `skip N`: statistics over the first N dispatches of every kernel only (or over everything after them) --
-bench.py runs its warm-up + timed region first and an informational two-streams region afterwards.
+`first N` / `skip N` / `last N`: statistics over the first N dispatches of every kernel only (over everything after them /
+over the last N) -- bench.py runs a time-based pre-conditioning and its warm-up before the timed segments; `last N` with
+N = segments x steps is the timed region.
 """
 import sqlite3
 import sys
@@ -23,7 +24,7 @@ def main():
         per.setdefault(name, []).append((dur, vg, sg, lds, gx, gy, gz, wx))
     rows = []
     for name, lst in per.items():
-        sel = lst[:n] if mode == "first" else (lst[n:] if mode == "skip" else lst)
+        sel = lst[:n] if mode == "first" else (lst[n:] if mode == "skip" else (lst[-n:] if mode == "last" else lst))
         if not sel:
             continue
         durs = [x[0] for x in sel]
@@ -33,7 +34,10 @@ def main():
     with open(out, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
         if mode != "all":
-            f.write(f"dispatches: {'the first' if mode == 'first' else 'all after the first'} {n} of every kernel\n\n")
+            which = {"first": "the first", "skip": "all after the first", "last": "the last"}[mode]
+            f.write(f"dispatches: {which} {n} of every kernel"
+                    + (" (the timed segments: the time-based pre-conditioning and the warm-up come before them)\n\n"
+                       if mode == "last" else "\n\n"))
         f.write("| kernel | calls | total (us) | avg (us) | min (us) | max (us) | % | VGPR | SGPR | LDS (B) | grid | block |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for name, calls, tot, avg, lo, hi, (vg, sg, lds, gx, gy, gz, wx) in rows:
