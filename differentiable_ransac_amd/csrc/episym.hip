@@ -8,48 +8,38 @@
 
 namespace dr {
 
-constexpr int kET = 256, kEP = 8, kEChunk = kET * kEP, kEM = 8;   // 8 models per block = 2 per wave
-constexpr int kEPw = 16, kEPass = 64 * kEPw;                          // a wave holds 16 points per lane per pass
+constexpr int kET = 256, kEP = 8, kEChunk = kET * kEP;
+constexpr int kEMW = 2;                          // models a wave evaluates together (their accumulators live in registers)
+constexpr int kEMperGroup = (kET / 64) * kEMW;   // 8 models per block and group; a block takes `groups` of them (chosen per launch)
+constexpr int kEPw = 16, kEPass = 64 * kEPw;     // a wave holds 16 points per lane per pass
 typedef float ev2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ev2 esplat(float a) { return (ev2){a, a}; }
 
-// v3 (v2 = mask compaction + packed f32 + v_rcp_f32).  The points selected by the mask (the GT inliers: half of the points
-// at C2) are compacted per block, so no lane evaluates a point whose weight is 0.  Each WAVE then takes its own two models
-// of the block's tile over ALL compacted points (16 per lane per pass of 1024): the nine gradient accumulators of a
-// model are reduced once per wave (DPP) instead of once per 256-lane slice of the points -- with ~1000 selected points a
-// lane used to hold 4 of them per model and the reductions were 37 % of the instructions.  No LDS partials, no
-// cross-wave reduction.
+// v4 (v2 = mask compaction + packed f32 + v_rcp_f32; v3 = a wave takes its models over ALL compacted points, one DPP
+// reduction per accumulator and wave).  The points selected by the mask (the GT inliers: half of the points at C2) are
+// compacted per block, so no lane evaluates a point whose weight is 0.  v3 ran the compaction (mask bytes, wave scans, three
+// barriers, the gathered point loads) once per EIGHT models -- 4096 blocks at the train shape, each with ~2 k cycles of
+// arithmetic behind ~2 us of prologue: 36 us forward + 59 us backward for 33 M (model, point) evaluations.  Now a block owns
+// 8 x `groups` models: every wave takes `groups` groups of two, and when the selected points fit one pass (<= 1024 of <= 2048:
+// the training shape) they are loaded ONCE and stay in VGPRs for all groups.  `groups` is chosen per launch so that the grid
+// is one round of resident waves where the shape allows it (episym_groups below).
 template <bool kBackward>
 __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ matches, const uint8_t *__restrict__ mask,
                                                      const float *__restrict__ models, const uint8_t *__restrict__ valid,
                                                      const float *__restrict__ grad_sums, int grad_per_pair, int M,
-                                                     int N, float *__restrict__ out) {
+                                                     int N, float *__restrict__ out, int groups) {
   // forward: out = sums [P,M]; backward: out = grad_models [P,M,9]
   constexpr int kV = kBackward ? 9 : 1;
-  constexpr int kMW = kEM / (kET / 64);   // models per wave
   __shared__ int s_list[kEChunk];
   __shared__ int s_wave[kET / 64];
-  const int p = blockIdx.z, m0 = blockIdx.x * kEM;
+  const int p = blockIdx.z, m0 = blockIdx.x * kEMperGroup * groups;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the model coefficients below live in SGPRs
   const float *mt = matches + (size_t)p * N * 4;
   const uint8_t *mk = mask ? mask + (size_t)p * N : nullptr;
-  ev2 acc[kMW][kV];
-#pragma unroll
-  for (int mi = 0; mi < kMW; ++mi)
-#pragma unroll
-    for (int q = 0; q < kV; ++q) acc[mi][q] = esplat(0.f);
-  float mcoef[kMW][9];
-  bool mlive[kMW];
-#pragma unroll
-  for (int mi = 0; mi < kMW; ++mi) {
-    const int m = m0 + wv * kMW + mi;
-    mlive[mi] = m < M && (!valid || valid[(size_t)p * M + m] != 0);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) mcoef[mi][q] = mlive[mi] ? models[((size_t)p * M + m) * 9 + q] : 0.f;
-  }
-  for (int c0 = 0; c0 < N; c0 += kEChunk) {
-    // ---- compact the selected points of this chunk: s_list[0..T) = their indices, ascending
+
+  // compaction of one 2048-point chunk: s_list[0..T) = indices of the selected points, ascending (block-wide, three barriers)
+  auto compact = [&](int c0) -> int {
     int T = min(kEChunk, N - c0);
     __syncthreads();
     if (mk) {
@@ -68,10 +58,10 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
         const int v = __shfl_up(inc, o, 64);
         if (lane >= o) inc += v;
       }
-      if (lane == 63) s_wave[wv] = inc;
+      if (lane == 63) s_wave[tid >> 6] = inc;
       __syncthreads();
       int base = 0;
-      for (int w = 0; w < wv; ++w) base += s_wave[w];
+      for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
       T = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
       int pos = base + inc - cnt;
 #pragma unroll
@@ -79,71 +69,104 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
         if ((bits >> j) & 1u) s_list[pos++] = c0 + tid * kEP + j;
       __syncthreads();
     }
-    for (int p0 = 0; p0 < T; p0 += kEPass) {
-      ev2 x1[kEPw / 2], y1[kEPw / 2], x2[kEPw / 2], y2[kEPw / 2], w[kEPw / 2];
+    return T;
+  };
+
+  ev2 x1[kEPw / 2], y1[kEPw / 2], x2[kEPw / 2], y2[kEPw / 2], w[kEPw / 2];
+  auto load_points = [&](int c0, int p0, int T) {
 #pragma unroll
-      for (int j = 0; j < kEPw; ++j) {
-        const int pos = p0 + j * 64 + lane;
-        const bool have = pos < T;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have) v = reinterpret_cast<const float4 *>(mt)[mk ? s_list[pos] : c0 + pos];
-        x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
-        w[j / 2][j & 1] = have ? 1.f : 0.f;
-      }
+    for (int j = 0; j < kEPw; ++j) {
+      const int pos = p0 + j * 64 + lane;
+      const bool have = pos < T;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (have) v = reinterpret_cast<const float4 *>(mt)[mk ? s_list[pos] : c0 + pos];
+      x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+      w[j / 2][j & 1] = have ? 1.f : 0.f;
+    }
+  };
+
+  const bool single = N <= kEChunk;          // one chunk: compacted once for all model groups
+  int T0 = 0;
+  if (single) T0 = compact(0);
+  const bool resident = single && T0 <= kEPass;   // ... and one pass: the points stay in registers
+  if (resident) load_points(0, 0, T0);
+
+#pragma unroll 1
+  for (int g = 0; g < groups; ++g) {
+    const int mg = m0 + (wv * groups + g) * kEMW;    // this wave's models mg .. mg + kEMW - 1 (wave-uniform)
+    ev2 acc[kEMW][kV];
 #pragma unroll
-      for (int mi = 0; mi < kMW; ++mi) {
-        if (!mlive[mi]) continue;   // wave-uniform
-        const float(&m)[9] = mcoef[mi];
+    for (int mi = 0; mi < kEMW; ++mi)
 #pragma unroll
-        for (int j = 0; j < kEPw / 2; ++j) {
-          if (p0 + 2 * j * 64 >= T) break;   // wave-uniform: the positions of this and all later pairs are empty
-          const ev2 a0 = x2[j] * esplat(m[0]) + (y2[j] * esplat(m[3]) + esplat(m[6]));
-          const ev2 a1 = x2[j] * esplat(m[1]) + (y2[j] * esplat(m[4]) + esplat(m[7]));
-          const ev2 a2 = x2[j] * esplat(m[2]) + (y2[j] * esplat(m[5]) + esplat(m[8]));
-          const ev2 b0 = x1[j] * esplat(m[0]) + (y1[j] * esplat(m[1]) + esplat(m[2]));
-          const ev2 b1 = x1[j] * esplat(m[3]) + (y1[j] * esplat(m[4]) + esplat(m[5]));
-          const ev2 r = x1[j] * a0 + (y1[j] * a1 + a2);
-          const ev2 db = b0 * b0 + (b1 * b1 + esplat(1e-15f)), da = a0 * a0 + (a1 * a1 + esplat(1e-15f));
-          ev2 ib, ia;
-          ib[0] = __builtin_amdgcn_rcpf(db[0]); ib[1] = __builtin_amdgcn_rcpf(db[1]);
-          ia[0] = __builtin_amdgcn_rcpf(da[0]); ia[1] = __builtin_amdgcn_rcpf(da[1]);
-          const ev2 rr = r * r, s = ib + ia;
-          const ev2 ys = rr * s;
-          if (!kBackward) {
-            ev2 cl;
-            cl[0] = fminf(ys[0], 1.0f); cl[1] = fminf(ys[1], 1.0f);
-            acc[mi][0] = cl * w[j] + acc[mi][0];
-          } else {
-            ev2 live;   // the clamp passes no gradient at or above 1
-            live[0] = ys[0] < 1.0f ? w[j][0] : 0.f;
-            live[1] = ys[1] < 1.0f ? w[j][1] : 0.f;
-            // d ys = c1 dr - cb (b0 db0 + b1 db1) - ca (a0 da0 + a1 da1), dr = x2^T dM x1, db = (dM x1)_{0,1}, da = (dM^T x2)_{0,1}
-            const ev2 r2l = (r + r) * live;
-            const ev2 c1 = r2l * s, cb = r2l * r * (ib * ib), ca = r2l * r * (ia * ia);
-            const ev2 u0 = c1 * x2[j] - cb * b0, u1 = c1 * y2[j] - cb * b1, v0 = ca * a0, v1 = ca * a1;
-            acc[mi][0] = acc[mi][0] + (x1[j] * u0 - v0 * x2[j]);
-            acc[mi][1] = acc[mi][1] + (y1[j] * u0 - v1 * x2[j]);
-            acc[mi][2] = acc[mi][2] + u0;
-            acc[mi][3] = acc[mi][3] + (x1[j] * u1 - v0 * y2[j]);
-            acc[mi][4] = acc[mi][4] + (y1[j] * u1 - v1 * y2[j]);
-            acc[mi][5] = acc[mi][5] + u1;
-            acc[mi][6] = acc[mi][6] + (x1[j] * c1 - v0);
-            acc[mi][7] = acc[mi][7] + (y1[j] * c1 - v1);
-            acc[mi][8] = acc[mi][8] + c1;
+      for (int q = 0; q < kV; ++q) acc[mi][q] = esplat(0.f);
+    float mcoef[kEMW][9];
+    bool mlive[kEMW];
+#pragma unroll
+    for (int mi = 0; mi < kEMW; ++mi) {
+      const int m = mg + mi;
+      mlive[mi] = m < M && (!valid || valid[(size_t)p * M + m] != 0);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) mcoef[mi][q] = mlive[mi] ? models[((size_t)p * M + m) * 9 + q] : 0.f;
+    }
+    for (int c0 = 0; c0 < N; c0 += kEChunk) {
+      const int T = single ? T0 : compact(c0);          // (several chunks: compacted again per group -- long rows only)
+      for (int p0 = 0; p0 < T; p0 += kEPass) {
+        if (!resident) load_points(c0, p0, T);
+#pragma unroll
+        for (int mi = 0; mi < kEMW; ++mi) {
+          if (!mlive[mi]) continue;   // wave-uniform
+          const float(&m)[9] = mcoef[mi];
+#pragma unroll
+          for (int j = 0; j < kEPw / 2; ++j) {
+            if (p0 + 2 * j * 64 >= T) break;   // wave-uniform: the positions of this and all later pairs are empty
+            const ev2 a0 = x2[j] * esplat(m[0]) + (y2[j] * esplat(m[3]) + esplat(m[6]));
+            const ev2 a1 = x2[j] * esplat(m[1]) + (y2[j] * esplat(m[4]) + esplat(m[7]));
+            const ev2 a2 = x2[j] * esplat(m[2]) + (y2[j] * esplat(m[5]) + esplat(m[8]));
+            const ev2 b0 = x1[j] * esplat(m[0]) + (y1[j] * esplat(m[1]) + esplat(m[2]));
+            const ev2 b1 = x1[j] * esplat(m[3]) + (y1[j] * esplat(m[4]) + esplat(m[5]));
+            const ev2 r = x1[j] * a0 + (y1[j] * a1 + a2);
+            const ev2 db = b0 * b0 + (b1 * b1 + esplat(1e-15f)), da = a0 * a0 + (a1 * a1 + esplat(1e-15f));
+            ev2 ib, ia;
+            ib[0] = __builtin_amdgcn_rcpf(db[0]); ib[1] = __builtin_amdgcn_rcpf(db[1]);
+            ia[0] = __builtin_amdgcn_rcpf(da[0]); ia[1] = __builtin_amdgcn_rcpf(da[1]);
+            const ev2 rr = r * r, s = ib + ia;
+            const ev2 ys = rr * s;
+            if (!kBackward) {
+              ev2 cl;
+              cl[0] = fminf(ys[0], 1.0f); cl[1] = fminf(ys[1], 1.0f);
+              acc[mi][0] = cl * w[j] + acc[mi][0];
+            } else {
+              ev2 live;   // the clamp passes no gradient at or above 1
+              live[0] = ys[0] < 1.0f ? w[j][0] : 0.f;
+              live[1] = ys[1] < 1.0f ? w[j][1] : 0.f;
+              // d ys = c1 dr - cb (b0 db0 + b1 db1) - ca (a0 da0 + a1 da1), dr = x2^T dM x1, db = (dM x1)_{0,1}, da = (dM^T x2)_{0,1}
+              const ev2 r2l = (r + r) * live;
+              const ev2 c1 = r2l * s, cb = r2l * r * (ib * ib), ca = r2l * r * (ia * ia);
+              const ev2 u0 = c1 * x2[j] - cb * b0, u1 = c1 * y2[j] - cb * b1, v0 = ca * a0, v1 = ca * a1;
+              acc[mi][0] = acc[mi][0] + (x1[j] * u0 - v0 * x2[j]);
+              acc[mi][1] = acc[mi][1] + (y1[j] * u0 - v1 * x2[j]);
+              acc[mi][2] = acc[mi][2] + u0;
+              acc[mi][3] = acc[mi][3] + (x1[j] * u1 - v0 * y2[j]);
+              acc[mi][4] = acc[mi][4] + (y1[j] * u1 - v1 * y2[j]);
+              acc[mi][5] = acc[mi][5] + u1;
+              acc[mi][6] = acc[mi][6] + (x1[j] * c1 - v0);
+              acc[mi][7] = acc[mi][7] + (y1[j] * c1 - v1);
+              acc[mi][8] = acc[mi][8] + c1;
+            }
           }
         }
       }
     }
-  }
 #pragma unroll
-  for (int mi = 0; mi < kMW; ++mi) {
-    const int m = m0 + wv * kMW + mi;
-    if (m >= M) continue;
-    const float gs = kBackward ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] : 1.f;
+    for (int mi = 0; mi < kEMW; ++mi) {
+      const int m = mg + mi;
+      if (m >= M) continue;
+      const float gs = kBackward ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] : 1.f;
 #pragma unroll
-    for (int q = 0; q < kV; ++q) {
-      const float v = wave_sum_lane63(acc[mi][q][0] + acc[mi][q][1]);
-      if (lane == 63) out[((size_t)p * M + m) * kV + q] = v * gs;
+      for (int q = 0; q < kV; ++q) {
+        const float v = wave_sum_lane63(acc[mi][q][0] + acc[mi][q][1]);
+        if (lane == 63) out[((size_t)p * M + m) * kV + q] = v * gs;
+      }
     }
   }
 }
@@ -184,14 +207,32 @@ __global__ __launch_bounds__(kET) void match_loss_pair_kernel(const float *__res
 
 }  // namespace dr
 
+namespace dr {
+// groups per block: the smallest count for which all waves of the launch are resident at once (`per_simd` = waves per SIMD the
+// callers pass; 4 for both directions: the backward kernel holds three, but six groups per block measured 61 us against 56 us with four), clamped to [1, 16]
+static int episym_groups(int P, int M, int per_simd) {
+  static int simds = 0;
+  if (!simds) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    simds = 4 * (cus > 0 ? cus : 256);
+  }
+  const long wave_models = ((long)P * M + kEMW - 1) / kEMW;       // (wave, group) work items
+  const long capacity = (long)simds * per_simd;
+  long g = (wave_models + capacity - 1) / capacity;
+  return (int)(g < 1 ? 1 : (g > 16 ? 16 : g));
+}
+}  // namespace dr
+
 extern "C" {
 
 int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid, int P, int M,
                       int N, float *sums, void *stream) {
   DR_REQUIRE(matches && models && sums, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  hipLaunchKernelGGL((dr::episym_kernel<false>), dim3((M + dr::kEM - 1) / dr::kEM, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, 0, M, N, sums);
+  const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
+  hipLaunchKernelGGL((dr::episym_kernel<false>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+                     (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, 0, M, N, sums, groups);
   return dr::check_launch("episym_kernel");
 }
 
@@ -199,8 +240,9 @@ int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *mo
                       const float *grad_sums, int P, int M, int N, float *grad_models, void *stream) {
   DR_REQUIRE(matches && models && grad_sums && grad_models, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + dr::kEM - 1) / dr::kEM, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, grad_sums, 0, M, N, grad_models);
+  const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
+  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+                     (hipStream_t)stream, matches, mask, models, valid, grad_sums, 0, M, N, grad_models, groups);
   return dr::check_launch("episym_kernel");
 }
 
@@ -208,8 +250,9 @@ int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const floa
                            const float *grad_pair, int P, int M, int N, float *grad_models, void *stream) {
   DR_REQUIRE(matches && models && grad_pair && grad_models, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + dr::kEM - 1) / dr::kEM, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, grad_pair, 1, M, N, grad_models);
+  const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
+  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+                     (hipStream_t)stream, matches, mask, models, valid, grad_pair, 1, M, N, grad_models, groups);
   return dr::check_launch("episym_kernel");
 }
 

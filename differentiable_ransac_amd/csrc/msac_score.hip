@@ -422,12 +422,15 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
 // model's `s_load_dword` -- and the wait-count pass, which sees a read of s17 with a scalar load to s17 in flight, puts
 // `s_waitcnt lgkmcnt(0)` right behind the prefetch: the "prefetch one model ahead" was a scalar-cache round trip per model,
 // in full, at the top of every iteration (ISA: profiles/r3_k4_isa_budget.md).  The empty asm makes both halves live.
-// Both measured in the step on one box, alternating libraries (scratch/r3_gpu_d.sh, r3_gpu_e.sh), and both OFF: pairs alone 0.602 /
-// 0.610 ms against 0.601 / 0.605 ms (nothing: the wait stays where it was, the SALU copies de-interleaving the loaded registers
-// follow the load at once); pairs + the hand-placed request below 0.623 / 0.628 ms against 0.601 / 0.602 ms -- a real prefetch
-// is 4 % SLOWER than the exposed round trip.  At four waves per SIMD the other three waves cover a parked one, and what the
-// prefetch costs (nine more scalar copies per model, a pinned scheduling region, 16 more live SGPRs) is not free.  The scalar
-// fetch is not what the kernel waits for.
+// Both measured in the step on one box, alternating libraries (scratch/r3_gpu_d.sh, r3_gpu_e.sh, r3_gpu_j.sh), and both OFF:
+//   pairs alone                                   0.602 / 0.610 ms against 0.601 / 0.605 ms (nothing: the wait stays where it was,
+//                                                 the SALU copies de-interleaving the loaded registers follow the load at once);
+//   pairs + request pinned at the top, wait at the end   0.623 / 0.628 ms against 0.601 / 0.602 ms;
+//   request pinned at the top, op_sel broadcasts (1)      0.650 / 0.651 ms against 0.603 / 0.603 ms;
+//   request placed by the scheduler (2: it sinks it behind most of the evaluation)   0.610 / 0.610 ms against 0.603 ms.
+// A REAL prefetch of the next model is 4-8 % SLOWER than the exposed scalar-cache round trip at the top of every iteration.
+// At four waves per SIMD the other three cover a parked wave, and the stall staggers the waves of a SIMD against each other
+// (without it they run their store / reduction phases in step).  The scalar fetch is not what this kernel waits for.
 // Round 3, measured in the step on one box, alternating libraries (scratch/r3_gpu_i.sh; scoring launch, two rounds):
 //   base 0.5977 / 0.5988 ms;  + v_bitop3 mask op 0.5962 / 0.5912 ms (kept);  + LDS quad-sum reduction 0.642 / 0.633 ms (7 % SLOWER:
 //   eleven fewer vector instructions per model, but 16 KB of LDS per workgroup, a masked ds_write per model in front of the next
@@ -671,7 +674,9 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
           const float *src = md + ml * 9;
           asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(nx8), "=&s"(nx1) : "s"(src));
         }
-        __builtin_amdgcn_sched_barrier(0);   // the request stays HERE, ahead of the evaluation
+#if DR_K4_ASMPREF != 2
+        __builtin_amdgcn_sched_barrier(0);   // the request stays HERE, ahead of the evaluation (2: left to the scheduler)
+#endif
 #else
         if (more) {
           ml = 32 * wd + __builtin_ctz(live);

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(cons
             }
             acc2 = acc2 + d2;
             // inlier <=> d2 < thr <=> fl(thr - d2) > 0 (a difference of two floats is zero only if they are equal); clamped
-            // to [0, 1], NaN -> 0: "positive" = biased exponent >= 64 = bit 6 of the top byte (values below 2^-63 cannot
+            // to [0, 1], NaN -> 0: "positive" = biased exponent >= 64 = bit 5 of the top byte (values below 2^-63 cannot
             // occur as a difference of f32 numbers of the sizes thresholds and squared distances have)
             v2r cl;
             asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(cl) : "v"(thr2), "v"(d2));
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(cons
           }
           const uint32_t lo2 = __builtin_amdgcn_perm(sb[1], sb[0], 0x0c0c0703u);      // [s0.b3, s1.b3, 0, 0]
           const uint32_t hi2 = __builtin_amdgcn_perm(sb[3], sb[2], 0x07030c0cu);      // [0, 0, s2.b3, s3.b3]
-          wq[g] = ((lo2 | hi2) >> 6) & 0x01010101u;
+          wq[g] = ((lo2 | hi2) >> 5) & 0x01010101u;   // top byte = sign, exponent bits 7..1: exponent bit 6 sits at bit 5
         }
         float acc = acc2[0] + acc2[1];
         if (have && live) *reinterpret_cast<uint4 *>(mrow + (size_t)ml * N + (uint32_t)n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
