@@ -165,8 +165,11 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
 #elif defined(DR_K1_NOISE_EXPERIMENT) && DR_K1_NOISE_EXPERIMENT == 2   // timing experiment: one logarithm
   return -kLn2 * __builtin_amdgcn_logf(u);
 #endif
-  const float a = -kLn2 * __builtin_amdgcn_logf(u);
-  float g = -kLn2 * __builtin_amdgcn_logf(a);
+  // -ln(-ln u) = -ln2 * log2(-ln2 * log2 u) = -ln2 * log2(-log2 u) - ln2 * log2(ln2): the inner scale factor leaves the
+  // logarithm as a constant, the sign of log2 u is a free source modifier of the second v_log_f32 -- five instructions per
+  // sample (convert, fma, log, log, fma) instead of six
+  const float t = __builtin_amdgcn_logf(u);                                  // log2 u in [-126, -1.7e-7]
+  float g = __builtin_fmaf(-kLn2, __builtin_amdgcn_logf(-t), 0.36651292058166432701f);   // -ln2 * log2(ln2) = -ln(ln 2)
   // the sample is an f32 VALUE: rounded here, then added to the logit by the caller with a second rounding -- exactly what the
   // oracle does with the noise tensor the general kernel reports.  The empty asm hides the multiply from -ffp-contract=fast,
   // which otherwise fuses it into the caller's `logit + noise` (one rounding): a top-k decided by the last bit then differs
