@@ -753,8 +753,10 @@ def main():
                                   "frac": bytes_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "note": "same launch, one stream, nothing else resident"},
                      "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                     "what_bounds_it": ("vector ALU issue: SQ_ACTIVE_INST_VALU = 0.90 of the kernel's cycles on every SIMD at this "
-                                        "shape, memory-side write stalls 8 % of a plain fill's (profiles/r2_k4_counters_p128.md)"
+                     "what_bounds_it": ("vector ALU issue: SQ_ACTIVE_INST_VALU = 0.83-0.87 of the kernel's cycles on every SIMD at "
+                                        "this shape, 211 vector instructions per (model, 16 points per lane) of which 152 are the "
+                                        "residual's packed FMAs / multiplies; the write path is not backed up "
+                                        "(profiles/r3_k4_counters_p128.md: counters + ISA budget of the shipped library)"
                                         if (not rigid and P >= 64) else None),
                      "valu_tflops": flops_per_launch / (iso_ms * 1e-3) / 1e12,
                      "valu_frac_of_157.3": flops_per_launch / (iso_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
