@@ -697,11 +697,17 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
   for (int b0 = b_lo; b0 < b_hi; b0 += 256) {
     const int nb = min(256, b_hi - b0);
     __syncthreads();
-    if ((int)threadIdx.x < nb) {
-      const size_t row = (size_t)p * a.B + b0 + threadIdx.x;
-      const T ls = lse[row];
-      T dot = T(0);
-      for (int j = 0; j < kMaxK; ++j) {
+    // per row: lse and dot = sum_m y_m a_m over its k selected points.  Eight threads per row (one per selected point, kMaxK = 8),
+    // 32 rows per sweep of the block: the k Philox calls, gathers and exponentials of a row run side by side instead of in one
+    // thread while three of the block's four waves wait at the barrier (round 3: this prologue was as long as the 32-row main
+    // loop it feeds)
+    static_assert(kMaxK == 8, "the row prologue maps eight threads to a row");
+    for (int rb = 0; rb < nb; rb += 32) {
+      const int r = rb + ((int)threadIdx.x >> 3), j = (int)threadIdx.x & 7;
+      T term = T(0), ls = T(0);
+      if (r < nb) {
+        const size_t row = (size_t)p * a.B + b0 + r;
+        ls = lse[row];
         if (j < a.k) {
           const int i = idx[row * a.k + j];
           const T av = a_sel[row * a.k + j];
@@ -709,20 +715,27 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
           T nz;
           if (a.gumbel) nz = a.gumbel[row * a.N + i];
           else {
-            uint32_t r[4];
-            Philox::gen(a.seed, (uint32_t)(i >> 2), (uint32_t)(b0 + threadIdx.x), (uint32_t)p, 0u, r);
-            nz = gumbel_from_bits_t<T>(r[i & 3]);
+            uint32_t rr[4];
+            Philox::gen(a.seed, (uint32_t)(i >> 2), (uint32_t)(b0 + r), (uint32_t)p, 0u, rr);
+            const uint32_t w = (i & 2) ? ((i & 1) ? rr[3] : rr[2]) : ((i & 1) ? rr[1] : rr[0]);
+            nz = gumbel_from_bits_t<T>(w);
           }
           const T li = a.logits ? a.logits[(size_t)p * a.N + i] : T(1);
           const T yi = exp_t<T>((unit_tau ? (li + nz) : (li + nz) / a.tau) - ls);
-          dot += yi * av;
+          term = yi * av;
           // the "+ y a" term exists only at the k selected points of a row: added here, once (by the first point-group
           // block), instead of comparing every point of the row against the k winners in the main loop
-          if (blockIdx.x == 0) atomicAdd(grad_logits + (size_t)p * a.N + i, unit_tau ? yi * av : yi * av / a.tau);
+          if (blockIdx.x == 0) atomicAdd(grad_logits + (size_t)p * a.N + i, unit_tau ? term : term / a.tau);
         }
       }
-      s_dot[threadIdx.x] = dot;
-      s_lse[threadIdx.x] = ls;
+      // dot of the row = the eight terms, summed in a fixed order (xor butterfly inside the group of eight lanes)
+      term += __shfl_xor(term, 1, 64);
+      term += __shfl_xor(term, 2, 64);
+      term += __shfl_xor(term, 4, 64);
+      if (r < nb && j == 0) {
+        s_dot[r] = term;
+        s_lse[r] = ls;
+      }
     }
     __syncthreads();
     if (q < groups) {
