@@ -366,7 +366,7 @@ class BatchedRANSAC(object):
 
     def hypotheses(self, matches, logits, gumbels=None):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
-        if self.weighted and self.fmat and not self.train and self.refit:
+        if self.weighted and self.solver == "f8" and not self.train and self.refit:
             # the weighted LSQ refit (ransac.py:151-153) needs y_soft of hypothesis 0 of the LAST batch a pair ran: take the seed
             # here so that __call__ can re-draw that one row (ops.soft_weights_row0)
             seed = self._next_seed()
@@ -458,7 +458,7 @@ class BatchedRANSAC(object):
             if have_round(0):
                 ahead = self.hypotheses(matches, logits, noise_of(0))[:2] + (getattr(self, "_row0", None),)
             r = 0
-            want_w = bool(self.weighted and self.fmat and self.refit)
+            want_w = bool(self.weighted and self.solver == "f8" and self.refit)   # (the 7-point solver takes no weights)
             last_w = torch.zeros((P, N), device=dev, dtype=dt) if want_w else None
             while ahead is not None:
                 models, valid, row0 = ahead
