@@ -172,6 +172,7 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
         match_loss = MatchLoss()                     # the reference's default training loss (-w2 1, train.py:70-79)
         gt_mask = data["inliers"].to(dev)
         no_inliers = torch.zeros(P, device=dev)      # the train step reports no inlier counts (allocated once, not per step)
+        one = torch.ones((), device=dev)             # the root gradient of loss.backward(), allocated once (not a fill per step)
 
         def step():
             lg.grad = None
@@ -181,7 +182,7 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
                 loss = (d * keep).sum()
             else:
                 loss = match_loss(chosen, matches, gt_mask, keep)
-            loss.backward()
+            loss.backward(one)
             return {"inliers": no_inliers, "grad": lg.grad}
         return step, dict(rn=tr, matches=matches, logits=lg, S=S, data=data, K=(K1, K2))
     rn = BatchedRANSAC(w["solver"], ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B, seed=seed + rank,

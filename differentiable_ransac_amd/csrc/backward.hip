@@ -55,7 +55,11 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
                                                            const MT *__restrict__ models,
                                                            const uint8_t *__restrict__ valid,
                                                            const float *__restrict__ grad_models, int Bt,
-                                                           float *__restrict__ grad_samples) {
+                                                           float *__restrict__ grad_samples,
+                                                           const int32_t *__restrict__ which) {
+  // which != NULL: the gradient arrives SPARSE -- grad_models is grad_chosen [Bt,9], the gradient of the one slot
+  // which[s] K5 picked for sample s (which[s] < 0: none) -- instead of a dense [Bt,10,9] tensor that is zero in nine slots of
+  // ten (what dr_select_closest_bwd used to write and this kernel used to scan: 11.8 MB each way per training step)
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= Bt) return;
   double x1[5][3], x2[5][3], gacc[5][4];
@@ -76,12 +80,25 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
   int next = 0;
   while (true) {
     int slot = -1;
-    for (; next < 10 && slot < 0; ++next) {
-      if (!valid[(size_t)s * 10 + next]) continue;
-      float gn = 0.f;
+    if (which) {
+      if (next == 0) {
+        const int w = which[s];
+        if (w >= 0 && w < 10 && valid[(size_t)s * 10 + w]) {
+          float gn = 0.f;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) gn += fabsf(grad_models[((size_t)s * 10 + next) * 9 + q]);
-      if (gn > 0.f) slot = next;
+          for (int q = 0; q < 9; ++q) gn += fabsf(grad_models[(size_t)s * 9 + q]);
+          if (gn > 0.f) slot = w;
+        }
+      }
+      next = 10;
+    } else {
+      for (; next < 10 && slot < 0; ++next) {
+        if (!valid[(size_t)s * 10 + next]) continue;
+        float gn = 0.f;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) gn += fabsf(grad_models[((size_t)s * 10 + next) * 9 + q]);
+        if (gn > 0.f) slot = next;
+      }
     }
     if (!__any(slot >= 0)) break;
     if (slot < 0) continue;
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       E[q / 3][q % 3] = models[((size_t)s * 10 + slot) * 9 + q];
-      g[q / 3][q % 3] = grad_models[((size_t)s * 10 + slot) * 9 + q];
+      g[q / 3][q % 3] = grad_models[which ? (size_t)s * 9 + q : ((size_t)s * 10 + slot) * 9 + q];
     }
     // tangent directions J_c (3x3 each): c<3: [e_c]x E ; c>=3: E [e_{c-3}]x
     double J[6][3][3];
@@ -580,10 +597,24 @@ int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const do
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   if (models_f64)
     hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<double>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                       samples, models_f64, valid, grad_models, Bt, grad_samples);
+                       samples, models_f64, valid, grad_models, Bt, grad_samples, (const int32_t *)nullptr);
   else
     hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<float>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                       samples, models, valid, grad_models, Bt, grad_samples);
+                       samples, models, valid, grad_models, Bt, grad_samples, (const int32_t *)nullptr);
+  return dr::check_launch("fivepoint_bwd_kernel");
+}
+
+int dr_solve_nister5_bwd_sel_f32(const float *samples, const float *models, const double *models_f64,
+                                 const uint8_t *valid, const float *grad_chosen, const int32_t *which, int Bt,
+                                 float *grad_samples, void *stream) {
+  DR_REQUIRE(samples && (models || models_f64) && valid && grad_chosen && which && grad_samples, "null pointer");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  if (models_f64)
+    hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<double>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       samples, models_f64, valid, grad_chosen, Bt, grad_samples, which);
+  else
+    hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<float>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       samples, models, valid, grad_chosen, Bt, grad_samples, which);
   return dr::check_launch("fivepoint_bwd_kernel");
 }
 

@@ -27,7 +27,8 @@ template <bool kBackward>
 __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ matches, const uint8_t *__restrict__ mask,
                                                      const float *__restrict__ models, const uint8_t *__restrict__ valid,
                                                      const float *__restrict__ grad_sums, int grad_per_pair, int M,
-                                                     int N, float *__restrict__ out, int groups) {
+                                                     int N, float *__restrict__ out, int groups,
+                                                     const float *__restrict__ grad_scalar, float scalar_scale) {
   // forward: out = sums [P,M]; backward: out = grad_models [P,M,9]
   constexpr int kV = kBackward ? 9 : 1;
   __shared__ int s_list[kEChunk];
@@ -161,7 +162,10 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
     for (int mi = 0; mi < kEMW; ++mi) {
       const int m = mg + mi;
       if (m >= M) continue;
-      const float gs = kBackward ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] : 1.f;
+      // backward: d loss / d sums[p,m] = grad_sums (per model or per pair) x, for the fused mean, the upstream scalar / P
+      const float gs = kBackward ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] *
+                                       (grad_scalar ? grad_scalar[0] * scalar_scale : 1.f)
+                                 : 1.f;
 #pragma unroll
       for (int q = 0; q < kV; ++q) {
         const float v = wave_sum_lane63(acc[mi][q][0] + acc[mi][q][1]);
@@ -205,6 +209,66 @@ __global__ __launch_bounds__(kET) void match_loss_pair_kernel(const float *__res
   }
 }
 
+// MatchLoss down to the scalar (loss.py:146-153 incl. the mean over pairs): the per-pair kernel above and the mean of its
+// P results in ONE launch -- a 1024-thread block whose sixteen waves take the pairs in turn (a pair is M sums + N mask bytes:
+// nothing), fixed reduction order.  Replaces, per training step, a torch mean kernel and the two small kernels of its
+// backward; for P <= 64 (a rank's pairs), beyond that the per-pair kernel + torch.mean stay.
+constexpr int kMeanT = 1024;
+// number of non-zero bytes among the 16 of a uint4 (the masks are torch.bool tensors, but the contract is "!= 0")
+__device__ __forceinline__ int nonzero_bytes(uint4 v) {
+  auto nz = [](uint32_t w) { return __popc((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); };
+  return nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+}
+// count of non-zero bytes of row[0..n) by one wave: 16-byte loads when the row allows it (every lane's loads are independent:
+// the byte-at-a-time loop of the per-pair kernel is a chain of ~30 dependent memory round trips per pair)
+__device__ __forceinline__ int wave_count_nonzero(const uint8_t *row, int n, int lane) {
+  int c = 0;
+  if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+    for (int i = lane; i < (n >> 4); i += 64) c += nonzero_bytes(r4[i]);
+  } else {
+    for (int i = lane; i < n; i += 64) c += row[i] != 0;
+  }
+  return wave_sum(c);
+}
+__global__ __launch_bounds__(kMeanT) void match_loss_mean_kernel(const float *__restrict__ sums, const uint8_t *__restrict__ mask,
+                                                                const uint8_t *__restrict__ keep, int P, int M, int N,
+                                                                float *__restrict__ per_pair, float *__restrict__ coef,
+                                                                float *__restrict__ mean) {
+  __shared__ float s_tot[kMeanT / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float wave_total = 0.f;
+  for (int p = wv; p < P; p += kMeanT / 64) {
+    float acc = 0.f;
+    const float *sp = sums + (size_t)p * M;
+    if ((M & 3) == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+      const float4 *s4 = reinterpret_cast<const float4 *>(sp);
+      for (int i = lane; i < (M >> 2); i += 64) {
+        const float4 v = s4[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int m = lane; m < M; m += 64) acc += sp[m];
+    }
+    acc = wave_sum(acc);
+    const int n_in = mask ? wave_count_nonzero(mask + (size_t)p * N, N, lane) : N;
+    const int n_kept = keep ? wave_count_nonzero(keep + (size_t)p * M, M, lane) : M;
+    const float den = fmaxf((float)n_in * (float)n_kept, 1.0f);
+    if (lane == 0) {
+      per_pair[p] = acc / den;
+      coef[p] = 1.0f / den;
+    }
+    wave_total += acc / den;
+  }
+  if (lane == 0) s_tot[wv] = wave_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kMeanT / 64; ++w) t += s_tot[w];
+    mean[0] = t / (float)P;
+  }
+}
+
 }  // namespace dr
 
 namespace dr {
@@ -232,7 +296,8 @@ int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *mo
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
   hipLaunchKernelGGL((dr::episym_kernel<false>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, 0, M, N, sums, groups);
+                     (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, 0, M, N, sums, groups,
+                     (const float *)nullptr, 1.0f);
   return dr::check_launch("episym_kernel");
 }
 
@@ -242,7 +307,8 @@ int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *mo
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
   hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, grad_sums, 0, M, N, grad_models, groups);
+                     (hipStream_t)stream, matches, mask, models, valid, grad_sums, 0, M, N, grad_models, groups,
+                     (const float *)nullptr, 1.0f);
   return dr::check_launch("episym_kernel");
 }
 
@@ -252,8 +318,29 @@ int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const floa
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
   hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
-                     (hipStream_t)stream, matches, mask, models, valid, grad_pair, 1, M, N, grad_models, groups);
+                     (hipStream_t)stream, matches, mask, models, valid, grad_pair, 1, M, N, grad_models, groups,
+                     (const float *)nullptr, 1.0f);
   return dr::check_launch("episym_kernel");
+}
+
+int dr_episym_bwd_mean_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
+                           const float *coef, const float *grad_mean, int P, int M, int N, float *grad_models, void *stream) {
+  DR_REQUIRE(matches && models && coef && grad_mean && grad_models, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
+  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+                     (hipStream_t)stream, matches, mask, models, valid, coef, 1, M, N, grad_models, groups, grad_mean,
+                     1.0f / (float)P);
+  return dr::check_launch("episym_kernel");
+}
+
+int dr_match_loss_mean_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,
+                           float *per_pair, float *coef, float *mean, void *stream) {
+  DR_REQUIRE(sums && per_pair && coef && mean, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0, "bad sizes");
+  hipLaunchKernelGGL(dr::match_loss_mean_kernel, dim3(1), dim3(dr::kMeanT), 0, (hipStream_t)stream, sums, mask, keep, P, M, N,
+                     per_pair, coef, mean);
+  return dr::check_launch("match_loss_mean_kernel");
 }
 
 int dr_match_loss_pair_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,

@@ -477,7 +477,7 @@ int ransac3d_update_launch(const T *pts, const T *models, const uint8_t *valid, 
 template <typename T>
 __global__ void select_closest_kernel(const T *__restrict__ models, const uint8_t *__restrict__ valid,
                                       const T *__restrict__ gt, int B, int S, T *__restrict__ chosen,
-                                      int32_t *__restrict__ which) {
+                                      int32_t *__restrict__ which, uint8_t *__restrict__ keep) {
   const int p = blockIdx.y;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -499,6 +499,7 @@ __global__ void select_closest_kernel(const T *__restrict__ models, const uint8_
     if (d < bd) { bd = d; best = s; }
   }
   which[e] = best;
+  if (keep) keep[e] = best >= 0;   // the nan_filter of ransac.py:104-106 as a flag (was a torch compare kernel per step)
 #pragma unroll
   for (int q = 0; q < 9; ++q) chosen[e * 9 + q] = best >= 0 ? models[(e * S + best) * 9 + q] : T(q % 4 == 0 ? 1 : 0);
 }
@@ -575,7 +576,15 @@ int dr_select_closest_f32(const float *models, const uint8_t *valid, const float
   DR_REQUIRE(models && gt && chosen && which, "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::select_closest_kernel<float>), dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
-                     models, valid, gt, B, S, chosen, which);
+                     models, valid, gt, B, S, chosen, which, (uint8_t *)nullptr);
+  return dr::check_launch("select_closest_kernel");
+}
+int dr_select_closest_keep_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
+                               float *chosen, int32_t *which, uint8_t *keep, void *stream) {
+  DR_REQUIRE(models && gt && chosen && which && keep, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::select_closest_kernel<float>), dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
+                     models, valid, gt, B, S, chosen, which, keep);
   return dr::check_launch("select_closest_kernel");
 }
 int dr_select_closest_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
@@ -583,7 +592,15 @@ int dr_select_closest_f64(const double *models, const uint8_t *valid, const doub
   DR_REQUIRE(models && gt && chosen && which, "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::select_closest_kernel<double>), dim3((B + 255) / 256, P), dim3(256), 0,
-                     (hipStream_t)stream, models, valid, gt, B, S, chosen, which);
+                     (hipStream_t)stream, models, valid, gt, B, S, chosen, which, (uint8_t *)nullptr);
+  return dr::check_launch("select_closest_kernel");
+}
+int dr_select_closest_keep_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
+                               double *chosen, int32_t *which, uint8_t *keep, void *stream) {
+  DR_REQUIRE(models && gt && chosen && which && keep, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::select_closest_kernel<double>), dim3((B + 255) / 256, P), dim3(256), 0,
+                     (hipStream_t)stream, models, valid, gt, B, S, chosen, which, keep);
   return dr::check_launch("select_closest_kernel");
 }
 

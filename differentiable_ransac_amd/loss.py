@@ -56,8 +56,9 @@ class MatchLoss(object):
         if gt_mask is None and gt_E is not None:
             with torch.no_grad():
                 gt_mask = ops.recover_pose_mask(matches, gt_E)[0][:, 0]
-        # per pair: sum of the clamped errors / max(#masked points * #kept models, 1) -- two launches, see ops._MatchLossPair
-        return ops.match_loss_per_pair(matches, gt_mask, models, keep).mean()
+        # per pair: sum of the clamped errors / max(#masked points * #kept models, 1), then the mean over the pairs -- two
+        # launches forward, one backward (ops._MatchLossMean)
+        return ops.match_loss_mean(matches, gt_mask, models, keep)
 
     __call__ = forward
 

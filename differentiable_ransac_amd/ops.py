@@ -420,12 +420,18 @@ def ransac3d_update(pts: torch.Tensor, models: torch.Tensor, valid: Optional[tor
     return out_res, out_model, idx
 
 
-def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torch.Tensor):
-    """K5: models [P,B,S,3,3], valid [P,B,S] | None, gt [P,3,3] -> chosen [P,B,3,3], which [P,B] int32."""
+def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torch.Tensor, want_keep: bool = False):
+    """K5: models [P,B,S,3,3], valid [P,B,S] | None, gt [P,3,3] -> chosen [P,B,3,3], which [P,B] int32 (+ keep [P,B] bool =
+    `which >= 0` from the same launch when want_keep)."""
     P, B, S = models.shape[:3]
     chosen = torch.empty((P, B, 3, 3), device=models.device, dtype=models.dtype)
     which = torch.empty((P, B), device=models.device, dtype=torch.int32)
     v = None if valid is None else valid.contiguous().view(torch.uint8)
+    if want_keep:
+        keep = torch.empty((P, B), device=models.device, dtype=torch.bool)
+        L.call(f"dr_select_closest_keep_{L.suffix(models.dtype)}", ptr(models.contiguous()), ptr(v),
+               ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), ptr(keep), stream())
+        return chosen, which, keep
     L.call(f"dr_select_closest_{L.suffix(models.dtype)}", ptr(models.contiguous()), ptr(v),
            ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), stream())
     return chosen, which
@@ -530,6 +536,45 @@ def solve_essential(samples, weights=None, which="nister"):
         raise L.DransacError("five-point solve of non-minimal samples (n = %d) is not differentiable here: train mode needs "
                              "the five-point sampler (sampler ids 1/2), or detach the samples" % samples.shape[-2])
     return _SolveEssential.apply(samples, weights, which)
+
+
+class _SolveSelectEssential(torch.autograd.Function):
+    """K3 (minimal five-point, train mode) + K5 (closest of the ten models to the ground truth) as ONE autograd node:
+    samples [P,B,5,4] f32, gt [P,3,3] -> chosen [P,B,3,3], which [P,B], keep [P,B], models [P,B,10,3,3], valid [P,B,10].
+    The backward hands the gradient of `chosen` to the solver's implicit-function backward in the sparse form
+    (dr_solve_nister5_bwd_sel): no dense [P,B,10,9] gradient is written and scanned."""
+
+    @staticmethod
+    def forward(ctx, samples, weights, gt):
+        ctx.set_materialize_grads(False)
+        models, m64, valid = solve_nister5_hp(samples, weights)
+        chosen, which, keep = select_closest(models, valid, gt, want_keep=True)
+        ctx.save_for_backward(samples, models, m64, valid, which)
+        ctx.mark_non_differentiable(which, keep, valid)
+        return chosen, which, keep, models.detach(), valid
+
+    @staticmethod
+    def backward(ctx, g_chosen, _gw, _gk, g_models, _gv):
+        if g_models is not None:
+            raise L.DransacError("solve_select_essential: gradients flow through `chosen` only (use solve_essential + "
+                                 "select_closest_autograd to differentiate the full model set)")
+        if g_chosen is None:
+            return None, None, None
+        samples, models, m64, valid, which = ctx.saved_tensors
+        s, Bt, _ = _flat_samples(samples, 4)
+        gs = torch.empty_like(s)
+        L.call("dr_solve_nister5_bwd_sel_f32", ptr(s), ptr(models.contiguous()), ptr(m64.contiguous()),
+               ptr(valid.contiguous().view(torch.uint8)), ptr(g_chosen.contiguous()), ptr(which.contiguous()), c_int(Bt),
+               ptr(gs), stream())
+        return gs.reshape(samples.shape), None, None
+
+
+def solve_select_essential(samples, gt, weights=None):
+    """Train-mode K3 + K5 in one autograd node (Nister, minimal f32 samples): -> (chosen, which, keep, models, valid);
+    `models` is returned detached (inspection / logging), the gradient path is samples -> chosen."""
+    if samples.shape[-2] != 5 or samples.dtype != torch.float32:
+        raise L.DransacError("solve_select_essential takes minimal f32 samples [...,5,4]")
+    return _SolveSelectEssential.apply(samples, weights, gt)
 
 
 class _SolveF8(torch.autograd.Function):
@@ -660,14 +705,14 @@ class _SelectClosest(torch.autograd.Function):
     @staticmethod
     def forward(ctx, models, valid, gt):
         ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
-        chosen, which = select_closest(models, valid, gt)
+        chosen, which, keep = select_closest(models, valid, gt, want_keep=True)
         ctx.save_for_backward(which)
         ctx.shape = models.shape
-        ctx.mark_non_differentiable(which)
-        return chosen, which
+        ctx.mark_non_differentiable(which, keep)
+        return chosen, which, keep
 
     @staticmethod
-    def backward(ctx, g_chosen, _gw):
+    def backward(ctx, g_chosen, _gw, _gk):
         if g_chosen is None:
             return None, None, None
         (which,) = ctx.saved_tensors
@@ -678,8 +723,10 @@ class _SelectClosest(torch.autograd.Function):
         return g, None, None
 
 
-def select_closest_autograd(models, valid, gt):
-    return _SelectClosest.apply(models, valid, gt)
+def select_closest_autograd(models, valid, gt, want_keep: bool = False):
+    """-> (chosen, which) or, with want_keep, (chosen, which, keep [P,B] bool = which >= 0, written by the same launch)."""
+    chosen, which, keep = _SelectClosest.apply(models, valid, gt)
+    return (chosen, which, keep) if want_keep else (chosen, which)
 
 
 # ------------------------------------------------------------------------------------------ MatchLoss residual (8(f) rank 2)
@@ -755,6 +802,53 @@ class _MatchLossPair(torch.autograd.Function):
         L.call("dr_episym_bwd_pair_f32", ptr(matches), ptr(mk), ptr(models), ptr(v), ptr(gp), c_int(P), c_int(M), c_int(N),
                ptr(gm), stream())
         return None, None, gm, None
+
+
+class _MatchLossMean(torch.autograd.Function):
+    """MatchLoss down to the scalar: episym forward + dr_match_loss_mean (per-pair means AND their mean over the pairs) in two
+    launches; backward = ONE launch (dr_episym_bwd_mean reads the upstream scalar gradient from device memory)."""
+
+    @staticmethod
+    def forward(ctx, matches, mask, models, keep):
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        matches, models = matches.contiguous(), models.contiguous()
+        mk = None if mask is None else mask.contiguous().view(torch.uint8)
+        v = None if keep is None else keep.contiguous().view(torch.uint8)
+        sums = torch.empty((P, M), device=matches.device, dtype=matches.dtype)
+        L.call("dr_episym_fwd_f32", ptr(matches), ptr(mk), ptr(models), ptr(v), c_int(P), c_int(M), c_int(N), ptr(sums),
+               stream())
+        per_pair = torch.empty((P,), device=matches.device, dtype=matches.dtype)
+        coef = torch.empty((P,), device=matches.device, dtype=matches.dtype)
+        mean = torch.empty((), device=matches.device, dtype=matches.dtype)
+        L.call("dr_match_loss_mean_f32", ptr(sums), ptr(mk), ptr(v), c_int(P), c_int(M), c_int(N), ptr(per_pair), ptr(coef),
+               ptr(mean), stream())
+        ctx.save_for_backward(matches, models, coef)
+        ctx.aux = (mk, v)
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        matches, models, coef = ctx.saved_tensors
+        mk, v = ctx.aux
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        gm = torch.empty_like(models)   # every slot is written (invalid: 0)
+        L.call("dr_episym_bwd_mean_f32", ptr(matches), ptr(mk), ptr(models), ptr(v), ptr(coef),
+               ptr(g.to(matches.dtype).contiguous()), c_int(P), c_int(M), c_int(N), ptr(gm), stream())
+        return None, None, gm, None
+
+
+def match_loss_mean(matches, mask, models, keep=None):
+    """MatchLoss of a batch: mean over pairs of the per-pair means (match_loss_per_pair(...).mean()) -> scalar, with the mean
+    and its backward folded into the kernels (P <= 64; larger batches take the per-pair kernel + torch.mean)."""
+    if matches.dtype != torch.float32:
+        raise L.DransacError("match_loss_mean is implemented for f32")
+    if matches.shape[0] > 64:
+        return match_loss_per_pair(matches, mask, models, keep).mean()
+    return _MatchLossMean.apply(matches, mask, models.reshape(models.shape[0], -1, 3, 3), keep)
 
 
 def match_loss_per_pair(matches, mask, models, keep=None):

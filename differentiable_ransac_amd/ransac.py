@@ -409,13 +409,20 @@ class BatchedRANSAC(object):
             out = []
             for r in range(rounds):
                 g = None if gumbels is None else gumbels[r]
+                if (self.solver == "nister" and not self.weighted and matches.dtype == torch.float32
+                        and logits.dtype == torch.float32 and logits.requires_grad):
+                    # the training path proper: sampler + gather, then solver + best-of-ten as ONE autograd node whose backward
+                    # takes the gradient of the chosen model in sparse form (ops.solve_select_essential)
+                    samples, _, _ = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, g, self._next_seed())
+                    chosen, _, keep, _, _ = ops.solve_select_essential(samples, gt_model)
+                    out.append((chosen, keep))
+                    continue
                 models, valid, _ = self.hypotheses(matches, logits, g)
                 if self.S == 1:
                     chosen = models[:, :, 0]
                     keep = valid[:, :, 0]
                 else:
-                    chosen, which = ops.select_closest_autograd(models, valid, gt_model)
-                    keep = which >= 0
+                    chosen, _, keep = ops.select_closest_autograd(models, valid, gt_model, want_keep=True)
                 out.append((chosen, keep))
             if len(out) == 1:            # one batch (train.py's max_iters = 100 with -rbs >= 100): nothing to concatenate
                 return out[0]

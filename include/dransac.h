@@ -172,6 +172,12 @@ int dr_solve_rigid_f64(const double *samples, const double *weights, int Bt, int
 int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const double *models_f64,
                              const uint8_t *valid, const float *grad_models, int Bt, float *grad_samples,
                              void *stream);
+/* The same with the gradient in the form K5 leaves it (ransac.py:87-96 picks ONE of a sample's ten models): grad_chosen [Bt,9]
+ * = gradient of the model in slot which[s] (which [Bt] int32 from dr_select_closest; < 0 = no model picked), all other slots
+ * carry none.  Replaces dr_select_closest_bwd + dr_solve_nister5_bwd on the training path (no dense [Bt,10,9] gradient). */
+int dr_solve_nister5_bwd_sel_f32(const float *samples, const float *models, const double *models_f64,
+                                 const uint8_t *valid, const float *grad_chosen, const int32_t *which, int Bt,
+                                 float *grad_samples, void *stream);
 int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float *models, const float *grad_models,
                         int Bt, int n, float *grad_samples, float *grad_weights, void *stream);
 int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const float *grad_models, int Bt, int n,
@@ -236,6 +242,11 @@ int dr_select_closest_f32(const float *models, const uint8_t *valid, const float
                           float *chosen, int32_t *which, void *stream);
 int dr_select_closest_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
                           double *chosen, int32_t *which, void *stream);
+/* the same with keep [P*B] uint8 = (which >= 0): the `nan_filter` of ransac.py:104-106 as a flag the loss consumes. */
+int dr_select_closest_keep_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
+                               float *chosen, int32_t *which, uint8_t *keep, void *stream);
+int dr_select_closest_keep_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
+                               double *chosen, int32_t *which, uint8_t *keep, void *stream);
 /* backward: grad_models [P,B,S,9] = grad_chosen [P,B,9] at slot which[p,b], 0 elsewhere (all of it is written). */
 int dr_select_closest_bwd_f32(const float *grad_chosen, const int32_t *which, int P, int B, int S, float *grad_models,
                               void *stream);
@@ -339,6 +350,14 @@ int dr_match_loss_pair_f32(const float *sums, const uint8_t *mask, const uint8_t
                            float *per_pair, float *coef, void *stream);
 int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
                            const float *grad_pair, int P, int M, int N, float *grad_models, void *stream);
+/* MatchLoss down to the scalar (loss.py:146-153 including `.mean()` over the pairs of the batch), one launch:
+ *   per_pair / coef as above and mean[0] = sum_p per_pair[p] / P.  dr_episym_bwd_mean is the matching backward:
+ *   d loss / d sums[p,m] = grad_mean[0] * coef[p] / P (grad_mean = the upstream gradient of the scalar, one float in device
+ *   memory), so no per-pair gradient tensor is formed on the host side. */
+int dr_match_loss_mean_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,
+                           float *per_pair, float *coef, float *mean, void *stream);
+int dr_episym_bwd_mean_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,
+                           const float *coef, const float *grad_mean, int P, int M, int N, float *grad_models, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * pose error of essential matrices -- the body of PoseLoss.forward_average (loss.py:11-68) =
