@@ -432,17 +432,27 @@ __global__ __launch_bounds__(kU3Threads) void ransac3d_update_kernel(
 #pragma unroll
   for (int w = 1; w < kU3Threads / 64; ++w)
     if (s_val[w] < bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
-  const T old = best_res_in[p];
+  // best_res_in == NULL: the first round of a call -- no previous state (residual +inf, model = identity, mask = empty), so the
+  // driver allocates and fills nothing before its first round (three torch fill / copy launches per call otherwise)
+  const bool first = best_res_in == nullptr;
+  const T old = first ? T(INFINITY) : best_res_in[p];
   const bool better = bi != 0x7fffffff && bv < old;            // strict: an equal later round does not replace the model
   if (blockIdx.x == 0) {
     if (tid < 16) best_model_out[(size_t)p * 16 + tid] = better ? models[((size_t)p * M + bi) * 16 + tid]
-                                                                : best_model_in[(size_t)p * 16 + tid];
+                                                       : (first ? T(tid % 5 == 0 ? 1 : 0) : best_model_in[(size_t)p * 16 + tid]);
     if (tid == 0) {
       best_res_out[p] = better ? bv : old;
       if (best_idx) best_idx[p] = better ? bi : -1;            // winner of THIS round, -1 when the state was kept
     }
   }
-  if (!better || !best_mask) return;
+  if (!best_mask) return;
+  if (!better) {
+    if (first) {   // nothing selected in the first round: the mask is defined (empty), not left uninitialised
+      const int n_begin = blockIdx.x * pts_per_block, n_end = min(N, n_begin + pts_per_block);
+      for (int n = n_begin + tid; n < n_end; n += kU3Threads) best_mask[(size_t)p * N + n] = 0;
+    }
+    return;
+  }
   T m[12];
 #pragma unroll
   for (int q = 0; q < 12; ++q) m[q] = models[((size_t)p * M + bi) * 16 + q];
@@ -555,7 +565,8 @@ int dr_rigid_residual_f64(const double *pts, const double *models, double thresh
 int dr_ransac3d_update_f32(const float *pts, const float *models, const uint8_t *valid, const float *res, float threshold,
                            int P, int M, int N, const float *best_res_in, const float *best_model_in, float *best_res_out,
                            float *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream) {
-  DR_REQUIRE(pts && models && res && best_res_in && best_model_in && best_res_out && best_model_out, "null pointer");
+  DR_REQUIRE(pts && models && res && best_res_out && best_model_out, "null pointer");
+  DR_REQUIRE((best_res_in == nullptr) == (best_model_in == nullptr), "first round: pass NULL for BOTH input states");
   DR_REQUIRE(best_res_in != best_res_out && best_model_in != best_model_out, "the state is ping-ponged: in and out must differ");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   return dr::ransac3d_update_launch<float>(pts, models, valid, res, threshold, P, M, N, best_res_in, best_model_in,
@@ -564,7 +575,8 @@ int dr_ransac3d_update_f32(const float *pts, const float *models, const uint8_t 
 int dr_ransac3d_update_f64(const double *pts, const double *models, const uint8_t *valid, const double *res, double threshold,
                            int P, int M, int N, const double *best_res_in, const double *best_model_in, double *best_res_out,
                            double *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream) {
-  DR_REQUIRE(pts && models && res && best_res_in && best_model_in && best_res_out && best_model_out, "null pointer");
+  DR_REQUIRE(pts && models && res && best_res_out && best_model_out, "null pointer");
+  DR_REQUIRE((best_res_in == nullptr) == (best_model_in == nullptr), "first round: pass NULL for BOTH input states");
   DR_REQUIRE(best_res_in != best_res_out && best_model_in != best_model_out, "the state is ping-ponged: in and out must differ");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   return dr::ransac3d_update_launch<double>(pts, models, valid, res, threshold, P, M, N, best_res_in, best_model_in,

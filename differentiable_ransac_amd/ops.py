@@ -402,7 +402,7 @@ def rigid_residual(pts: torch.Tensor, models: torch.Tensor, threshold: float = 0
 
 
 def ransac3d_update(pts: torch.Tensor, models: torch.Tensor, valid: Optional[torch.Tensor], res: torch.Tensor,
-                    threshold: float, best_res: torch.Tensor, best_model: torch.Tensor,
+                    threshold: float, best_res: Optional[torch.Tensor], best_model: Optional[torch.Tensor],
                     best_mask: Optional[torch.Tensor] = None):
     """K6 of the 3-D path (dr_ransac3d_update): per pair the valid model with the smallest residual sum replaces the state
     where it is strictly better.  pts [P,N,6], models [P,M,4,4], valid [P,M] | None, res [P,M]; state best_res [P],
@@ -410,13 +410,16 @@ def ransac3d_update(pts: torch.Tensor, models: torch.Tensor, valid: Optional[tor
     place, idx [P] int32 = the round's winner or -1."""
     P, N, _ = pts.shape
     M = models.shape[1]
-    out_res, out_model = torch.empty_like(best_res), torch.empty_like(best_model)
+    # best_res = best_model = None: the first round (state = +inf / identity / empty mask, nothing to allocate or fill)
+    out_res = torch.empty((P,), device=pts.device, dtype=pts.dtype)
+    out_model = torch.empty((P, 4, 4), device=pts.device, dtype=pts.dtype)
     idx = torch.empty((P,), device=pts.device, dtype=torch.int32)
     v = None if valid is None else valid.contiguous().view(torch.uint8)
     mk = None if best_mask is None else best_mask.view(torch.uint8)
     L.call(f"dr_ransac3d_update_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()), ptr(v),
-           ptr(res.contiguous()), L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(best_res.contiguous()),
-           ptr(best_model.contiguous()), ptr(out_res), ptr(out_model), ptr(mk), ptr(idx), stream())
+           ptr(res.contiguous()), L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N),
+           ptr(None if best_res is None else best_res.contiguous()), ptr(None if best_model is None else best_model.contiguous()),
+           ptr(out_res), ptr(out_model), ptr(mk), ptr(idx), stream())
     return out_res, out_model, idx
 
 

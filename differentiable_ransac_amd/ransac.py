@@ -573,9 +573,8 @@ class BatchedRANSAC3D(object):
                         residuals=torch.cat([o[2] for o in out], 1), mean_residuals=torch.stack([o[3] for o in out], 1))
         with torch.no_grad():
             matches = matches.contiguous()
-            best = torch.full((P,), float("inf"), device=matches.device, dtype=matches.dtype)
-            best_model = torch.eye(4, device=matches.device, dtype=matches.dtype).repeat(P, 1, 1)
-            best_mask = torch.zeros((P, N), device=matches.device, dtype=torch.bool) if self.keep_masks else None
+            best, best_model = None, None      # "no state yet": the first update writes it (no fill / copy launches per call)
+            best_mask = torch.empty((P, N), device=matches.device, dtype=torch.bool) if self.keep_masks else None
             masks = None
             for r in range(rounds):
                 g = None if gumbels is None else gumbels[r]

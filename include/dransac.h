@@ -225,7 +225,9 @@ int dr_rigid_residual_bwd_f32(const float *pts, const float *models, const float
  * valid slots (valid [P,M] or NULL; NaN sums never win; ties -> lowest index), compared STRICTLY with best_res_in [P].
  * Where it is better: best_res_out / best_model_out [P,16] take the winner and best_mask [P,N] (or NULL) is rewritten with
  * `d2 < threshold` of the winner; elsewhere the state is copied through and the mask left alone.  The small state is
- * ping-ponged (in != out) because several blocks serve one pair.  best_idx [P] (or NULL): the round's winner, -1 if kept. */
+ * ping-ponged (in != out) because several blocks serve one pair.  best_idx [P] (or NULL): the round's winner, -1 if kept.
+ * First round of a call: best_res_in = best_model_in = NULL stands for "no state yet" (residual +inf, model = identity, empty
+ * mask -- the mask is then written in full even where no model is selected). */
 int dr_ransac3d_update_f32(const float *pts, const float *models, const uint8_t *valid, const float *res, float threshold,
                            int P, int M, int N, const float *best_res_in, const float *best_model_in, float *best_res_out,
                            float *best_model_out, uint8_t *best_mask, int32_t *best_idx, void *stream);
