@@ -438,6 +438,10 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
 #ifndef DR_K4_BITOP3
 #define DR_K4_BITOP3 1
 #endif
+#ifndef DR_K4_PRELOAD
+#define DR_K4_PRELOAD 1   // the block's first 16 point loads issued ahead of the model check: scoring launch 0.5941 / 0.5946 ms
+                          // against 0.5970 / 0.5977 ms in the step (scratch/r3_gpu_p.sh) -- kept
+#endif
 #ifndef DR_K4_LDSRED
 #define DR_K4_LDSRED 0   // 1: per-model score partials as quad sums in LDS, one dense reduction per tile (0: six DPP steps per model)
 #endif
@@ -581,6 +585,21 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
   const float *md = models + ((size_t)p * M + m0) * 9;
   for (int i = threadIdx.x; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
   uint32_t vword[kTile / 32];
+#if DR_K4_PRELOAD
+  // the first chunk's points are requested BEFORE the model check: its strided model reads, the ballots and the block barrier
+  // then run under the latency of the sixteen point loads instead of in front of it
+  v2f x1[kP16 / 2], y1[kP16 / 2], x2[kP16 / 2], y2[kP16 / 2];
+  {
+    const int n0p = blockIdx.y * chunks_per_block * kChunk16 + tid * kP16;
+    const bool havep = n0p < N;
+#pragma unroll
+    for (int j = 0; j < kP16; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (havep) v = reinterpret_cast<const float4 *>(mt)[n0p + j];
+      x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+    }
+  }
+#endif
 #if DR_K4_PRECHECK
   // non-finite / all-zero models of the tile are found here, once (lane l looks at slot l), instead of in every wave of
   // every chunk: they leave the evaluated set (empty mask row like an invalid slot) and their score is NaN
@@ -621,12 +640,18 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
     if (c * kChunk16 >= N) break;
     const int n0 = c * kChunk16 + tid * kP16;
     const bool have = n0 < N;   // N % 16 == 0: a lane's 16 points are all inside or all outside
+#if DR_K4_PRELOAD
+    if (c != c_begin)
+#else
     v2f x1[kP16 / 2], y1[kP16 / 2], x2[kP16 / 2], y2[kP16 / 2];
+#endif
+    {
 #pragma unroll
-    for (int j = 0; j < kP16; ++j) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (have) v = reinterpret_cast<const float4 *>(mt)[n0 + j];
-      x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+      for (int j = 0; j < kP16; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) v = reinterpret_cast<const float4 *>(mt)[n0 + j];
+        x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
+      }
     }
 
 #pragma unroll 1
