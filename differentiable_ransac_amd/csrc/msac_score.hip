@@ -438,6 +438,11 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
 #ifndef DR_K4_BITOP3
 #define DR_K4_BITOP3 1
 #endif
+#ifndef DR_K4_TAILSYNC
+#define DR_K4_TAILSYNC 0   // 1: the halves of a workgroup finish independently (LDS rendezvous of a half's two waves instead of the
+                           // block barrier).  In the step: 0.6052 / 0.6064 ms against 0.6035 / 0.6029 ms with the barrier
+                           // (scratch/r3_gpu_p.sh) -- nothing to gain: off
+#endif
 #ifndef DR_K4_PRELOAD
 #define DR_K4_PRELOAD 1   // the block's first 16 point loads issued ahead of the model check: scoring launch 0.5941 / 0.5946 ms
                           // against 0.5970 / 0.5977 ms in the step (scratch/r3_gpu_p.sh) -- kept
@@ -584,6 +589,10 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
   const float *mt = matches + (size_t)p * N * 4;
   const float *md = models + ((size_t)p * M + m0) * 9;
   for (int i = threadIdx.x; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
+#if DR_K4_TAILSYNC
+  __shared__ int s_done[DR_K4_HALVES > 1 ? DR_K4_HALVES : 1];
+  if (threadIdx.x < DR_K4_HALVES) s_done[threadIdx.x] = 0;
+#endif
   uint32_t vword[kTile / 32];
 #if DR_K4_PRELOAD
   // the first chunk's points are requested BEFORE the model check: its strided model reads, the ballots and the block barrier
@@ -811,6 +820,24 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
       }
     }
   }
+#if DR_K4_TAILSYNC
+  // No block barrier at the end: the two halves of a workgroup own different tiles with different numbers of valid slots, and a
+  // block-wide barrier makes the faster half's two waves sit on their registers until the slower half is done.  The two waves
+  // of a HALF rendezvous through an LDS counter instead; whichever arrives second adds the two partials and stores the scores.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's partial sums are in LDS before it arrives
+  int arrived = 0;
+  if (lane == 0) arrived = atomicAdd(&s_done[half], 1);
+  arrived = __builtin_amdgcn_readfirstlane(arrived);
+  if (arrived == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = lane; i < mcount; i += kWave) {
+      const float v = part[2 * half][i] + part[2 * half + 1][i];
+      float *dst = scores + (size_t)p * M + m0 + i;
+      if (use_atomic) atomicAdd(dst, v);
+      else *dst = v;
+    }
+  }
+#else
   __syncthreads();
   for (int i = tid; i < mcount; i += kH16) {
     const float v = part[2 * half][i] + part[2 * half + 1][i];
@@ -818,6 +845,7 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
     if (use_atomic) atomicAdd(dst, v);
     else *dst = v;
   }
+#endif
 }
 
 // ---- f32, short rows (N <= 256): a WAVE per model ------------------------------------------------------------------------
