@@ -929,7 +929,14 @@ static int gumbel_bwd_f32_impl(const float *logits, const float *gumbel, uint64_
   const size_t smem = sizeof(float) * 256 * 2;
   const int gx = ((N + 3) / 4 + 255) / 256;
   // enough row chunks to put >= ~2048 blocks on the chip, at least 32 rows each
-  int chunks = (int)std::min<long>((B + 31) / 32, std::max<long>(1, 2048 / std::max<long>(1, (long)gx * P)));
+#ifndef DR_K1_BWD_BLOCKS
+#define DR_K1_BWD_BLOCKS 2048
+#endif
+#ifndef DR_K1_BWD_MINROWS
+#define DR_K1_BWD_MINROWS 32
+#endif
+  int chunks = (int)std::min<long>((B + DR_K1_BWD_MINROWS - 1) / DR_K1_BWD_MINROWS,
+                                   std::max<long>(1, DR_K1_BWD_BLOCKS / std::max<long>(1, (long)gx * P)));
   const int rows_per_block = (B + chunks - 1) / chunks;
   chunks = (B + rows_per_block - 1) / rows_per_block;
   if (hipMemsetAsync(grad_logits, 0, sizeof(float) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
