@@ -24,6 +24,11 @@ namespace dr {
 #ifndef DR_K1_FAST
 #define DR_K1_FAST 1   // 0: always the general kernel (A/B builds)
 #endif
+#ifndef DR_K1_PASSB_ATOMIC
+#define DR_K1_PASSB_ATOMIC 0   // 1: register kernel collects the candidates in the lanes that own them (LDS counter) instead of by
+                               // wave-wide ballots.  In the step (scratch/r3_gpu_s.sh): 1.035 / 1.036 ms against 1.026 / 1.032 ms
+                               // with the ballots -- the per-element divergent branches cost more than the ballots they replace: off
+#endif
 constexpr int kRowsPerBlock = 4;   // one wave per row
 constexpr int kMaxK = 8;
 constexpr int kMaxCand = 64;
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
+  __shared__ int s_cnt[kRowsPerBlock];
   if (seed_ptr) seed = *seed_ptr;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
@@ -359,8 +365,34 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
     if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
   }
 
-  // ---------------- pass B: compact candidates { g >= thr } (same order as the general kernel: group-major, element, lane)
+  // ---------------- pass B: the candidates { g >= thr } into the wave's LDS list
   int ncand = 0;
+#if DR_K1_PASSB_ATOMIC
+  // Only the lanes whose maximum reaches the threshold (k .. ~10 of 64) hold candidates: they walk their own elements and take
+  // list slots with an LDS counter.  The list order is then arbitrary -- the ranking below is by (value, index), a total order,
+  // so the result does not depend on it.  (Round 2's wave-wide compaction kept the general kernel's order with a ballot, a
+  // popcount and an mbcnt per element of every group that holds a candidate: ~160 of the ~250 vector instructions the
+  // selection costs per row.)
+  if (lane == 0) s_cnt[wv] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lmax >= thr) {
+#pragma unroll
+    for (int i = 0; i < kFastGroups; ++i) {
+      if (!(fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3])) >= thr)) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (g[i][j] >= thr) {
+          const int pos = atomicAdd(&s_cnt[wv], 1);
+          if (pos < kMaxCand) { cand_val[pos] = g[i][j]; cand_idx[pos] = 4 * (lane + 64 * i) + j; }
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  ncand = s_cnt[wv];
+#else
 #pragma unroll
   for (int i = 0; i < kFastGroups; ++i) {
     if (64 * i >= groups) break;   // wave-uniform
@@ -379,6 +411,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
+#endif
 
   if (ncand <= kMaxCand) {
     const bool have = lane < ncand;
