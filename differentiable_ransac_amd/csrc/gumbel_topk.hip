@@ -311,7 +311,9 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
+#if DR_K1_PASSB_ATOMIC
   __shared__ int s_cnt[kRowsPerBlock];
+#endif
   if (seed_ptr) seed = *seed_ptr;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
