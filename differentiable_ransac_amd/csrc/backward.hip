@@ -179,6 +179,194 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
     for (int d = 0; d < 4; ++d) grad_samples[(size_t)s * 20 + 4 * k + d] = (float)gacc[k][d];
 }
 
+// ---------------------------------------------------------------------------------------------- five-point, n > 5
+// Non-minimal samples (ransac.py:82-83: the 8-point Gumbel sampler feeding the five-point estimator; nister.py:64-65 runs the
+// minimal code on all rows): the forward takes S = span of the four eigenvectors of M = sum_r w_r^2 rho_r rho_r^T with the
+// smallest eigenvalues and returns the unit-norm essential matrices inside S.  A returned model e is therefore DEFINED by
+//   q_j(M)^T e = 0  for the five eigenvectors q_j of the complement,  e on the essential manifold, |e| = 1,
+// the same shape as the minimal case with the rows x2_k (x) x1_k replaced by the q_j.  Implicit differentiation on the tangent
+// space (directions J_c as above) gives lambda = (AJ AJ^T)^-1 AJ Jg with AJ[j][c] = q_j . vec(J_c), and the part of dq_j that
+// matters is its component inside S:  dq_j^T e = sum_{i in S} (v_i . e) (v_i^T dM q_j) / (mu_j - mu_i).  Hence
+//   dL = <Mbar, dM>,  Mbar = -sum_j p_j q_j^T,  p_j = sum_{i in S} lambda_j (v_i . e) / (mu_j - mu_i) v_i   (summed over slots),
+// and rho_bar_r = -w_r^2 sum_j [p_j (q_j . rho_r) + q_j (p_j . rho_r)],  w_bar_r = -2 w_r sum_j (p_j . rho_r)(q_j . rho_r).
+// One lane per sample; M and its eigenvectors (cyclic Jacobi) live in LDS (162 doubles per lane), in the forward's entry
+// order rho[3a + b] = x1_a x2_b, so a stored model E[i][j] (x2^T E x1) is the vector e[3j + i].
+template <typename MT>
+__global__ __launch_bounds__(64) void fivepoint_nm_bwd_kernel(const float *__restrict__ samples, const float *__restrict__ weights,
+                                                              const MT *__restrict__ models, const uint8_t *__restrict__ valid,
+                                                              const float *__restrict__ grad_models, int Bt, int n,
+                                                              float *__restrict__ grad_samples, float *__restrict__ grad_weights) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x * 64 + lane;
+  const bool active = s < Bt;
+  const int sc = active ? s : Bt - 1;
+  const float *pts = samples + (size_t)sc * n * 4;
+  const float *wts = weights ? weights + (size_t)sc * n : nullptr;
+  LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
+  for (int e = 0; e < 81; ++e) A[e] = 0.0;
+  for (int r = 0; r < n; ++r) {
+    double row[9];
+    const double w = wts ? (double)wts[r] : 1.0;
+    epipolar_row_5pt((double)pts[4 * r], (double)pts[4 * r + 1], (double)pts[4 * r + 2], (double)pts[4 * r + 3], w, row);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) A[i * 9 + j] += row[i] * row[j];
+  }
+  jacobi_eig_lds<9>(A, V);
+  // the forward's choice of S: four times the smallest remaining eigenvalue (fivepoint_basis_nonminimal)
+  unsigned inS = 0;
+  int si[4], cj[5];
+  for (int t = 0; t < 4; ++t) {
+    int best = 0;
+    double bv = INFINITY;
+    for (int i = 0; i < 9; ++i) {
+      const double ev = A[i * 9 + i];
+      if (!((inS >> i) & 1u) && ev < bv) { bv = ev; best = i; }
+    }
+    inS |= 1u << best;
+    si[t] = best;
+  }
+  {
+    int k = 0;
+    for (int i = 0; i < 9; ++i)
+      if (!((inS >> i) & 1u)) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+          if (t == k) cj[t] = i;
+        ++k;
+      }
+  }
+  double Pm[5][9];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Pm[j][q] = 0;
+#pragma unroll 1
+  for (int slot = 0; slot < 10; ++slot) {
+    bool has = active && valid[(size_t)sc * 10 + slot];
+    double E[3][3], g[3][3];
+    float gn = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      E[q / 3][q % 3] = (double)models[((size_t)sc * 10 + slot) * 9 + q];
+      const float gv = grad_models[((size_t)sc * 10 + slot) * 9 + q];
+      g[q / 3][q % 3] = gv;
+      gn += fabsf(gv);
+    }
+    has = has && gn > 0.f;
+    if (!__any(has)) continue;
+    double J[6][3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      J[0][0][j] = 0;        J[0][1][j] = -E[2][j]; J[0][2][j] = E[1][j];
+      J[1][0][j] = E[2][j];  J[1][1][j] = 0;        J[1][2][j] = -E[0][j];
+      J[2][0][j] = -E[1][j]; J[2][1][j] = E[0][j];  J[2][2][j] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      J[3][i][0] = 0;        J[3][i][1] = E[i][2];  J[3][i][2] = -E[i][1];
+      J[4][i][0] = -E[i][2]; J[4][i][1] = 0;        J[4][i][2] = E[i][0];
+      J[5][i][0] = E[i][1];  J[5][i][1] = -E[i][0]; J[5][i][2] = 0;
+    }
+    double AJ[5][6], Jg[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double acc = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += J[c][i][j] * g[i][j];
+      Jg[c] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      double qv[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) qv[q] = V[q * 9 + cj[k]];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double a = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a += qv[3 * j + i] * J[c][i][j];
+        AJ[k][c] = a;
+      }
+    }
+    double G[5][5], lam[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      double r = 0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) r += AJ[a][c] * Jg[c];
+      lam[a] = r;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        double v = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v += AJ[a][c] * AJ[b][c];
+        G[a][b] = v;
+      }
+    }
+    bool fin = solve_spd5(G, lam);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) fin = fin && is_finite(lam[k]);
+    if (!(has && fin)) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) lam[k] = 0;
+    }
+    for (int t = 0; t < 4; ++t) {
+      double vi[9], ui = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) vi[q] = V[q * 9 + si[t]];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ui += vi[3 * j + i] * E[i][j];
+      const double mui = A[si[t] * 9 + si[t]];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const double gap = A[cj[k] * 9 + cj[k]] - mui;
+        const double kap = gap > 0 ? lam[k] * ui / gap : 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Pm[k][q] += kap * vi[q];
+      }
+    }
+  }
+  if (!active) return;
+  for (int r = 0; r < n; ++r) {
+    const double x1 = pts[4 * r], y1 = pts[4 * r + 1], x2 = pts[4 * r + 2], y2 = pts[4 * r + 3];
+    const double w = wts ? (double)wts[r] : 1.0;
+    double rho[9], gr[9];
+    epipolar_row_5pt(x1, y1, x2, y2, 1.0, rho);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) gr[q] = 0;
+    double gw = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      double qv[9], a = 0, b = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        qv[q] = V[q * 9 + cj[k]];
+        a += qv[q] * rho[q];
+        b += Pm[k][q] * rho[q];
+      }
+      gw += a * b;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) gr[q] -= Pm[k][q] * a + qv[q] * b;
+    }
+    const double w2 = w * w;
+    // rho = (x1 x2, x1 y2, x1, y1 x2, y1 y2, y1, x2, y2, 1)
+    grad_samples[((size_t)s * n + r) * 4 + 0] = (float)(w2 * (gr[0] * x2 + gr[1] * y2 + gr[2]));
+    grad_samples[((size_t)s * n + r) * 4 + 1] = (float)(w2 * (gr[3] * x2 + gr[4] * y2 + gr[5]));
+    grad_samples[((size_t)s * n + r) * 4 + 2] = (float)(w2 * (gr[0] * x1 + gr[3] * y1 + gr[6]));
+    grad_samples[((size_t)s * n + r) * 4 + 3] = (float)(w2 * (gr[1] * x1 + gr[4] * y1 + gr[7]));
+    if (grad_weights) grad_weights[(size_t)s * n + r] = (float)(-2.0 * w * gw);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- 8-point / LSQ
 __global__ __launch_bounds__(64) void f8_bwd_kernel(const float *__restrict__ samples, const float *__restrict__ weights,
                                                     const float *__restrict__ models,
@@ -616,6 +804,31 @@ int dr_solve_nister5_bwd_sel_f32(const float *samples, const float *models, cons
     hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<float>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream,
                        samples, models, valid, grad_chosen, Bt, grad_samples, which);
   return dr::check_launch("fivepoint_bwd_kernel");
+}
+
+int dr_solve_nister5_nm_bwd_f32(const float *samples, const float *weights, const float *models, const double *models_f64,
+                                const uint8_t *valid, const float *grad_models, int Bt, int n, float *grad_samples,
+                                float *grad_weights, void *stream) {
+  DR_REQUIRE(samples && (models || models_f64) && valid && grad_models && grad_samples, "null pointer");
+  DR_REQUIRE(Bt > 0 && n > 5, "need Bt > 0 and n > 5 points per sample (minimal samples: dr_solve_nister5_bwd_f32)");
+  const size_t smem = sizeof(double) * 162 * 64;
+  static bool attr_set[64] = {false};   // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dr::fivepoint_nm_bwd_kernel<double>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dr::fivepoint_nm_bwd_kernel<float>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  if (models_f64)
+    hipLaunchKernelGGL((dr::fivepoint_nm_bwd_kernel<double>), dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream,
+                       samples, weights, models_f64, valid, grad_models, Bt, n, grad_samples, grad_weights);
+  else
+    hipLaunchKernelGGL((dr::fivepoint_nm_bwd_kernel<float>), dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream,
+                       samples, weights, models, valid, grad_models, Bt, n, grad_samples, grad_weights);
+  return dr::check_launch("fivepoint_nm_bwd_kernel");
 }
 
 int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float *models, const float *grad_models,

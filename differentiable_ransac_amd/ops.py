@@ -511,6 +511,7 @@ class _SolveEssential(torch.autograd.Function):
             m64 = torch.empty(0, device=samples.device, dtype=torch.float64)
         ctx.save_for_backward(samples, models, m64, valid)
         ctx.minimal = samples.shape[-2] == 5
+        ctx.weights = None if ctx.minimal or weights is None else weights.detach()
         ctx.mark_non_differentiable(valid)
         return models, valid
 
@@ -519,12 +520,20 @@ class _SolveEssential(torch.autograd.Function):
         if g_models is None:
             return None, None, None
         samples, models, m64, valid = ctx.saved_tensors
-        if not ctx.minimal:
-            raise L.DransacError("backward of the non-minimal five-point fallback is not defined (refit is test-mode only)")
         if samples.dtype != torch.float32:
             raise L.DransacError("backward is implemented for f32 only")
-        s, Bt, _ = _flat_samples(samples, 4)
+        s, Bt, n = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
+        if not ctx.minimal:
+            # n > 5 rows per sample (the reference's `-sam 3`: 8-point Gumbel sampler feeding the five-point estimator,
+            # ransac.py:82-83): derivative of the invariant subspace the models live in, row weights included
+            w = ctx.weights
+            gw = None if w is None or not ctx.needs_input_grad[1] else torch.empty((Bt, n), device=s.device, dtype=torch.float32)
+            L.call("dr_solve_nister5_nm_bwd_f32", ptr(s), ptr(None if w is None else w.reshape(Bt, n).float().contiguous()),
+                   ptr(models.contiguous()), ptr(m64.contiguous() if m64.numel() else None),
+                   ptr(valid.contiguous().view(torch.uint8)), ptr(g_models.contiguous()), c_int(Bt), c_int(n), ptr(gs), ptr(gw),
+                   stream())
+            return gs.reshape(samples.shape), (None if gw is None else gw.reshape(w.shape).to(w.dtype)), None
         L.call("dr_solve_nister5_bwd_f32", ptr(s), ptr(models.contiguous()), ptr(m64.contiguous() if m64.numel() else None),
                ptr(valid.contiguous().view(torch.uint8)), ptr(g_models.contiguous()), c_int(Bt), ptr(gs), stream())
         return gs.reshape(samples.shape), None, None
@@ -532,12 +541,9 @@ class _SolveEssential(torch.autograd.Function):
 
 def solve_essential(samples, weights=None, which="nister"):
     """Differentiable five-point solve: samples [...,n,4] -> (models [...,10,3,3], valid [...,10]).
-    Gradients exist for MINIMAL samples only (n = 5): a non-minimal sample that requires grad (the reference's `-sam 3`
-    eight-point Gumbel sampler feeding the five-point estimator in train mode) is refused here, at forward time, instead
-    of failing inside .backward()."""
-    if samples.shape[-2] != 5 and samples.requires_grad and torch.is_grad_enabled():
-        raise L.DransacError("five-point solve of non-minimal samples (n = %d) is not differentiable here: train mode needs "
-                             "the five-point sampler (sampler ids 1/2), or detach the samples" % samples.shape[-2])
+    Minimal samples (n = 5): implicit derivative of the five epipolar constraints.  Non-minimal samples (n > 5, Nister only:
+    the reference's `-sam 3`, eight-point Gumbel sampler feeding the five-point estimator, ransac.py:82-83): implicit
+    derivative of the invariant subspace the models live in (dr_solve_nister5_nm_bwd), gradients for the row weights too."""
     return _SolveEssential.apply(samples, weights, which)
 
 

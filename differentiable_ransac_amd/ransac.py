@@ -182,8 +182,12 @@ class RANSAC(object):
             batch += 1
             B, S = valid.shape
             if self.train:
-                if self.sampler.num_samples == 8 or S == 1:
+                if S == 1:
                     chosen, keep = models[:, 0], valid[:, 0]
+                elif self.sampler.num_samples == 8:
+                    # ransac.py:82-83: with the 8-point sampler every estimated model is kept (no best-of-S); here that is
+                    # every VERIFIED solution of every sample (the reference's ten slots include the non-real ones)
+                    chosen, keep = models.reshape(B * S, 3, 3), valid.reshape(B * S)
                 else:
                     chosen, which = ops.select_closest_autograd(models.unsqueeze(0), valid.unsqueeze(0),
                                                                 gt_model.unsqueeze(0))
@@ -316,7 +320,9 @@ class BatchedRANSAC(object):
 
     def __init__(self, solver="nister", ransac_batch_size=1024, train=False, threshold=0.75, confidence=0.999,
                  max_iterations=5000, tau=1.0, seed=0, weighted=0, keep_masks=False, refit=True, eps=1e-5,
-                 sampling="gumbel"):
+                 sampling="gumbel", num_samples=None):
+        # num_samples: points per sample when it is not the solver's minimal count -- 8 with solver="nister" is the reference's
+        # `-sam 3` (8-point Gumbel sampler) feeding the five-point estimator (ransac.py:82-83; nister.py:64-65 runs on all rows)
         # sampling: "gumbel" = the reference's sampler (noise for every point of every hypothesis, top-k);
         # "topdown" = the same index-set distribution drawn as k sequential soft-max draws without replacement
         # (ops.topdown_sample, O(B k log N)); test mode only, no soft weights (weighted=0), no explicit noise.
@@ -332,6 +338,10 @@ class BatchedRANSAC(object):
         self._pipe = None
         self.solver = solver
         self.k, self.S = self._SOLVERS[solver]
+        if num_samples is not None and num_samples != self.k:
+            if solver not in ("nister", "f8") or not self.k < num_samples <= 8:
+                raise ValueError(f"solver {solver!r} takes {self.k} points per sample (non-minimal samples: 'nister' / 'f8', up to 8)")
+            self.k = int(num_samples)
         self.B = ransac_batch_size
         self.train = train
         self.threshold = threshold
@@ -409,7 +419,7 @@ class BatchedRANSAC(object):
             out = []
             for r in range(rounds):
                 g = None if gumbels is None else gumbels[r]
-                if (self.solver == "nister" and not self.weighted and matches.dtype == torch.float32
+                if (self.solver == "nister" and self.k == 5 and not self.weighted and matches.dtype == torch.float32
                         and logits.dtype == torch.float32 and logits.requires_grad):
                     # the training path proper: sampler + gather, then solver + best-of-ten as ONE autograd node whose backward
                     # takes the gradient of the chosen model in sparse form (ops.solve_select_essential)
@@ -421,6 +431,9 @@ class BatchedRANSAC(object):
                 if self.S == 1:
                     chosen = models[:, :, 0]
                     keep = valid[:, :, 0]
+                elif self.k == 8:      # ransac.py:82-83: the 8-point sampler keeps every model of every sample
+                    chosen = models.reshape(P, self.B * self.S, 3, 3)
+                    keep = valid.reshape(P, self.B * self.S)
                 else:
                     chosen, _, keep = ops.select_closest_autograd(models, valid, gt_model, want_keep=True)
                 out.append((chosen, keep))

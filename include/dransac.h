@@ -178,6 +178,14 @@ int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const do
 int dr_solve_nister5_bwd_sel_f32(const float *samples, const float *models, const double *models_f64,
                                  const uint8_t *valid, const float *grad_chosen, const int32_t *which, int Bt,
                                  float *grad_samples, void *stream);
+/* Non-minimal samples (n > 5 rows per sample, optional row weights: ransac.py:82-83 `num_samples == 8` feeding the five-point
+ * estimator, which runs its minimal code on all rows -- nister.py:64-65, weighted rows :88-93).  The returned models lie in the
+ * span of the four smallest eigenvectors of sum_r w_r^2 rho_r rho_r^T; the backward differentiates that invariant subspace and
+ * the essential-manifold constraints implicitly.  grad_models [Bt,10,9] dense, grad_samples [Bt,n,4] and grad_weights [Bt,n]
+ * (optional) are overwritten. */
+int dr_solve_nister5_nm_bwd_f32(const float *samples, const float *weights, const float *models, const double *models_f64,
+                                const uint8_t *valid, const float *grad_models, int Bt, int n, float *grad_samples,
+                                float *grad_weights, void *stream);
 int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float *models, const float *grad_models,
                         int Bt, int n, float *grad_samples, float *grad_weights, void *stream);
 int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const float *grad_models, int Bt, int n,

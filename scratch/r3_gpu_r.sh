@@ -1,9 +1,10 @@
 #!/bin/bash
-# round 3, GPU pass R: sampler backward with 4096 / 1024 blocks (16 / 64 rows each) against the tree's 2048 x 32, in the train step
+# round 3, GPU pass R: K3 with the residual pre-check before the first Gauss-Newton step ("k3pre") against the tree ("cur")
 mkdir -p gpurun_out/r3r
-for round in 1 2; do
-  for n in cur bwd4k bwd1k; do
-    lib=""; [ "$n" != "cur" ] && lib=$PWD/scratch/libdransac_$n.so
-    DRANSAC_LIB=$lib timeout 200 python bench.py --mode train --graph off --steps 300 --warmup 10 --segments 3 --prewarm-s 0.3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n', round(d['value']/1e6,2), 'M  step', round(d['ms_per_step'],4), 'ms')"
-  done
-done 2>&1 | tee gpurun_out/r3r/ab_bwd_blocks.log
+V=$PWD/scratch/libdransac_k3pre.so
+python scratch/k3_ab.py gpurun_out/r3r/cur.npz 2>&1 | tee gpurun_out/r3r/k3_cur.log
+DRANSAC_LIB=$V python scratch/k3_ab.py gpurun_out/r3r/pre.npz 2>&1 | tee gpurun_out/r3r/k3_pre.log
+python scratch/k3_ab.py cmp gpurun_out/r3r/cur.npz gpurun_out/r3r/pre.npz 2>&1 | tee gpurun_out/r3r/cmp.log
+rm -f gpurun_out/r3r/*.npz
+DRANSAC_LIB=$V timeout 600 python -m pytest tests/test_gpu_solvers.py tests/test_gpu_configs.py tests/test_gpu_drivers.py -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/r3r/tests.log
+AB_ARGS="--segments 3 --prewarm-s 0.3" bash scratch/ab_step.sh cur k3pre 2>&1 | tee gpurun_out/r3r/ab.log
