@@ -15,6 +15,13 @@ namespace dr {
 #ifndef DR_K3_PRECHECK
 #define DR_K3_PRECHECK 1
 #endif
+// 1: the Gauss-Newton step forms the Jacobian of the nine trace constraints as (2 dG - tr(dG) I) E + (2 G - tr(G) I) H
+// (G = E E^T, dG = H E^T + E H^T: three 3x3 products per direction instead of six), takes the residual from the same
+// pieces and evaluates |r|^2 at the new point with the symmetric G formed once.  68.7 -> 64 us per 32 x 1024 samples with
+// the pre-check; all 158 800 f32 models of the A/B set bit-identical (the f64 differences round away), same valid flags.
+#ifndef DR_K3_JAC2
+#define DR_K3_JAC2 1
+#endif
 // 1: the root search of the two-lanes-per-sample kernels deals the brackets that hold a sign change out over the wave
 // (real_roots_half_wave) instead of refining every bracket in every lane
 #ifndef DR_K3_WAVE_ROOTS
@@ -109,6 +116,25 @@ __device__ __forceinline__ void essential_residual(const double (&E)[9], double 
   r[9] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
 }
 
+// |r(E)|^2 alone, with the symmetric G = E E^T formed once (6 entries) and r = (2 G - tr(G) I) E: ~80 instead of ~120 FMAs
+__device__ __forceinline__ double essential_residual_norm2(const double (&E)[9]) {
+  const double g00 = E[0] * E[0] + E[1] * E[1] + E[2] * E[2], g01 = E[0] * E[3] + E[1] * E[4] + E[2] * E[5];
+  const double g02 = E[0] * E[6] + E[1] * E[7] + E[2] * E[8], g11 = E[3] * E[3] + E[4] * E[4] + E[5] * E[5];
+  const double g12 = E[3] * E[6] + E[4] * E[7] + E[5] * E[8], g22 = E[6] * E[6] + E[7] * E[7] + E[8] * E[8];
+  const double tr = g00 + g11 + g22;
+  const double a00 = 2.0 * g00 - tr, a11 = 2.0 * g11 - tr, a22 = 2.0 * g22 - tr, a01 = 2.0 * g01, a02 = 2.0 * g02, a12 = 2.0 * g12;
+  double n = 0;
+#pragma unroll
+  for (int jx = 0; jx < 3; ++jx) {
+    const double r0 = a00 * E[jx] + a01 * E[3 + jx] + a02 * E[6 + jx];
+    const double r1 = a01 * E[jx] + a11 * E[3 + jx] + a12 * E[6 + jx];
+    const double r2 = a02 * E[jx] + a12 * E[3 + jx] + a22 * E[6 + jx];
+    n += r0 * r0 + r1 * r1 + r2 * r2;
+  }
+  const double det = E[0] * (E[4] * E[8] - E[5] * E[7]) + E[1] * (E[5] * E[6] - E[3] * E[8]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
+  return n + det * det;
+}
+
 // Gauss-Newton in HOMOGENEOUS coordinates: E = sum_k u_k N_k with |u| = 1 (so |E|_F = 1: the basis is orthonormal).
 // r(E) is homogeneous of degree 3, hence J u = 3 r ~ 0 and the normal matrix is singular along u; adding u u^T picks the
 // step orthogonal to u.  No chart, no scaling problem when a solution has a vanishing N3 component (|z| -> infinity), and
@@ -121,11 +147,64 @@ __device__ __forceinline__ void polish_step(const double (&nb)[4][9], const doub
   double E[9], r[10];
 #pragma unroll
   for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
+#if !DR_K3_JAC2
   essential_residual(E, r);
   double n0 = 0;
 #pragma unroll
   for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
+#endif
   double J[4][10];
+#if DR_K3_JAC2
+  // d r[H] = (2 dG - tr(dG) I) E + (2 G - tr(G) I) H  with G = E E^T, dG = H E^T + E H^T : three 3x3 products per direction
+  // instead of six
+  double A2[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx)
+      A2[3 * i + jx] = 2.0 * (E[3 * i] * E[3 * jx] + E[3 * i + 1] * E[3 * jx + 1] + E[3 * i + 2] * E[3 * jx + 2]);
+  {
+    const double trG = 0.5 * (A2[0] + A2[4] + A2[8]);
+    A2[0] -= trG; A2[4] -= trG; A2[8] -= trG;
+  }
+  const double cof[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
+                         E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
+                         E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
+  // the residual itself from the same pieces: r = (2 G - tr(G) I) E, det E by the first row of cofactors
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx) r[3 * i + jx] = A2[3 * i] * E[jx] + A2[3 * i + 1] * E[3 + jx] + A2[3 * i + 2] * E[6 + jx];
+  r[9] = E[0] * cof[0] + E[1] * cof[1] + E[2] * cof[2];
+  double n0 = 0;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double(&H)[9] = nb[k];
+    double HEt[9], A1[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx)
+        HEt[3 * i + jx] = H[3 * i] * E[3 * jx] + H[3 * i + 1] * E[3 * jx + 1] + H[3 * i + 2] * E[3 * jx + 2];
+    const double trd = 2.0 * (HEt[0] + HEt[4] + HEt[8]);   // tr(dG)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) A1[3 * i + jx] = 2.0 * (HEt[3 * i + jx] + HEt[3 * jx + i]) - (i == jx ? trd : 0.0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx)
+        J[k][3 * i + jx] = A1[3 * i] * E[jx] + A1[3 * i + 1] * E[3 + jx] + A1[3 * i + 2] * E[6 + jx] +
+                           A2[3 * i] * H[jx] + A2[3 * i + 1] * H[3 + jx] + A2[3 * i + 2] * H[6 + jx];
+    double dd = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
+    J[k][9] = dd;
+  }
+#else
   double EEt[9], EtE[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -164,6 +243,7 @@ __device__ __forceinline__ void polish_step(const double (&nb)[4][9], const doub
     for (int q = 0; q < 9; ++q) dd += cof[q] * H[q];
     J[k][9] = dd;
   }
+#endif
   // (J^T J + u u^T) d = J^T r : 4x4 SPD, LDL^T without pivoting
   double a[4][4], g[4];
 #pragma unroll
@@ -205,12 +285,17 @@ __device__ __forceinline__ void polish_step(const double (&nb)[4][9], const doub
   const double sc = 1.0 / sqrt(nn);
 #pragma unroll
   for (int k = 0; k < 4; ++k) un[k] *= sc;
-  double E2[9], r2[10], n1 = 0;
+  double E2[9], n1 = 0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) E2[q] = un[0] * nb[0][q] + un[1] * nb[1][q] + un[2] * nb[2][q] + un[3] * nb[3][q];
+#if DR_K3_JAC2
+  n1 = essential_residual_norm2(E2);
+#else
+  double r2[10];
   essential_residual(E2, r2);
 #pragma unroll
   for (int q = 0; q < 10; ++q) n1 += r2[q] * r2[q];
+#endif
   n0_out = n0;
   n1_out = n1;
 }
@@ -374,16 +459,21 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     const unsigned m = fq.meta[ec];
     bool lv = has && ((m >> 6) & 1u);
     if (precheck) {
-      double nb[4][9], u[4], E[9], r[10];
+      double nb[4][9], u[4], E[9];
       fq.load_basis((m & 63) >> 1, nb);
 #pragma unroll
       for (int k = 0; k < 4; ++k) u[k] = fq.u[k * 320 + ec];
 #pragma unroll
       for (int q = 0; q < 9; ++q) E[q] = u[0] * nb[0][q] + u[1] * nb[1][q] + u[2] * nb[2][q] + u[3] * nb[3][q];
+#if DR_K3_JAC2
+      const double n0 = essential_residual_norm2(E);
+#else
+      double r[10];
       essential_residual(E, r);
       double n0 = 0;
 #pragma unroll
       for (int q = 0; q < 10; ++q) n0 += r[q] * r[q];
+#endif
       lv = lv && !(n0 <= tol2);
       if (has) fq.rn[e] = n0;
     }

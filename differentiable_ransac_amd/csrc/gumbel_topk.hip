@@ -24,6 +24,11 @@ namespace dr {
 #ifndef DR_K1_FAST
 #define DR_K1_FAST 1   // 0: always the general kernel (A/B builds)
 #endif
+#ifndef DR_K1_PASSB_LDS
+#define DR_K1_PASSB_LDS 0   // 1: register kernel: the (few) lanes whose maximum reaches the threshold park their 32 values in LDS and
+#endif                      // the whole wave scans those, instead of a ballot per element of every group (see pass B there).
+                            // Measured in the step: 1.0219 vs 1.0195 ms (slower: the compare + branch per element it
+                            // replaces mostly falls through) -- off.
 #ifndef DR_K1_PASSB_ATOMIC
 #define DR_K1_PASSB_ATOMIC 0   // 1: register kernel collects the candidates in the lanes that own them (LDS counter) instead of by
                                // wave-wide ballots.  In the step (scratch/r3_gpu_s.sh): 1.035 / 1.036 ms against 1.026 / 1.032 ms
@@ -314,6 +319,11 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 #if DR_K1_PASSB_ATOMIC
   __shared__ int s_cnt[kRowsPerBlock];
 #endif
+#if DR_K1_PASSB_LDS
+  constexpr int kHotMax = 8, kHotStride = 4 * kFastGroups + 4;   // stride 36 words: rows start in different banks, 16 B aligned
+  __shared__ __align__(16) float s_stage[kRowsPerBlock][kHotMax * kHotStride];
+  __shared__ int s_hot[kRowsPerBlock][kHotMax];
+#endif
   if (seed_ptr) seed = *seed_ptr;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
@@ -395,6 +405,43 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   __builtin_amdgcn_wave_barrier();
   ncand = s_cnt[wv];
 #else
+#if DR_K1_PASSB_LDS
+  // Only the lanes whose maximum reaches the threshold hold candidates: exactly k of 64 unless values tie.  They park their 32
+  // values in LDS (eight 16-byte writes under one exec mask) and the WAVE scans the k x 32 values, 64 per step: three steps
+  // for k = 5 instead of a compare + branch per element of every group and a ballot / popcount / mbcnt per candidate.  The
+  // list order differs from the element-order scan; the ranking below is by (value, index), a total order, so the winners and
+  // their output positions do not depend on it.
+  const unsigned long long hotb = __ballot(lmax >= thr);
+  const int nhot = __popcll(hotb);
+  if (nhot <= kHotMax) {
+    float *stage = s_stage[wv];
+    if (lmax >= thr) {
+      const int hr = __popcll(hotb & ((1ull << lane) - 1ull));
+#pragma unroll
+      for (int i = 0; i < kFastGroups; ++i)
+        *reinterpret_cast<float4 *>(stage + hr * kHotStride + 4 * i) = make_float4(g[i][0], g[i][1], g[i][2], g[i][3]);
+      s_hot[wv][hr] = lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int total = nhot * 4 * kFastGroups;
+#pragma unroll 1
+    for (int base = 0; base < total; base += 64) {
+      const int sl = base + lane;
+      const bool in = sl < total;
+      const int h = in ? sl / (4 * kFastGroups) : 0, e = sl % (4 * kFastGroups);
+      const float val = in ? stage[h * kHotStride + e] : -INFINITY;
+      const int src = s_hot[wv][h];
+      const bool c = in && val >= thr;
+      const unsigned long long bal = __ballot(c);
+      if (bal) {
+        const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+        if (c && pos < kMaxCand) { cand_val[pos] = val; cand_idx[pos] = 4 * (src + 64 * (e >> 2)) + (e & 3); }
+        ncand += __popcll(bal);
+      }
+    }
+  } else
+#endif
 #pragma unroll
   for (int i = 0; i < kFastGroups; ++i) {
     if (64 * i >= groups) break;   // wave-uniform
