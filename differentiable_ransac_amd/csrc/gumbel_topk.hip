@@ -752,6 +752,15 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
   return check_launch("gumbel_topk_kernel");
 }
 
+#ifndef DR_K1_BWD_RACE
+#define DR_K1_BWD_RACE 1
+#endif
+// log2 of the uniform that gumbel_from_bits (dr_common.hpp) draws from the same bits -- the same convert + fma + v_log_f32
+__device__ __forceinline__ float log2_uniform_from_bits(uint32_t bits) {
+  constexpr float kScale = 2.3283064365386963e-10f * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f);   // 2^-32 * c
+  return __builtin_amdgcn_logf(__builtin_fmaf((float)bits, kScale, 1.17549435e-38f));
+}
+
 // ---- backward of K1 (+K2):  grad_logits[p,n] = (1/tau) sum_b y_bn (a_bn - sum_m y_bm a_bm), a non-zero only at idx
 template <typename T>
 __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const int32_t *__restrict__ idx,
@@ -776,6 +785,16 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
     l[j] = (n < a.N) ? (a.logits ? a.logits[(size_t)p * a.N + n] : T(1)) : T(0);
   }
   const int b_lo = blockIdx.z * rows_per_block, b_hi = min(a.B, b_lo + rows_per_block);
+#if DR_K1_BWD_RACE
+  // f32, in-kernel noise, tau = 1: y = exp(l + G - lse) with exp(G) = 1 / (-ln u) = -1 / (ln2 log2 u), so
+  //   y dot = w_j [exp(lref - lse) dot / ln2] (-1 / log2 u),   w_j = exp(l_j - lref) constant over the rows:
+  // per element convert, fma, ONE logarithm, a reciprocal and an fma -- the second logarithm, the add, the subtract, the
+  // exponential and its scale of the general form (y = exp((l + G) - lse)) are gone; per row and thread one exponential.
+  // lref = the thread's largest logit: lref - lse <= -G <= 3.2, no overflow; rows far above the thread's points flush to 0.
+  const bool race = sizeof(T) == 4 && !a.gumbel && unit_tau;
+  const float lref = fmaxf(fmaxf((float)l[0], (float)l[1]), fmaxf((float)l[2], (float)l[3]));
+  float racc[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
   for (int b0 = b_lo; b0 < b_hi; b0 += 256) {
     const int nb = min(256, b_hi - b0);
     __syncthreads();
@@ -820,6 +839,20 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
       }
     }
     __syncthreads();
+#if DR_K1_BWD_RACE
+    if (race) {
+      if (q < groups) {
+        for (int r = 0; r < nb; ++r) {
+          uint32_t rr[4];
+          Philox::gen(a.seed, (uint32_t)q, (uint32_t)(b0 + r), (uint32_t)p, 0u, rr);
+          const float c = __expf(lref - (float)s_lse[r]) * ((float)s_dot[r] * 1.44269504088896340736f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) racc[j] = __builtin_fmaf(c, __builtin_amdgcn_rcpf(log2_uniform_from_bits(rr[j])), racc[j]);
+        }
+      }
+      continue;
+    }
+#endif
     if (q < groups) {
       for (int r = 0; r < nb; ++r) {
         const int b = b0 + r;
@@ -842,6 +875,12 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
       }
     }
   }
+#if DR_K1_BWD_RACE
+  if (race) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += (T)(__expf((float)l[j] - lref) * racc[j]);
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (4 * q + j < a.N) atomicAdd(grad_logits + (size_t)p * a.N + 4 * q + j, acc[j] / a.tau);
