@@ -19,6 +19,15 @@ namespace dr {
 // (G = E E^T, dG = H E^T + E H^T: three 3x3 products per direction instead of six), takes the residual from the same
 // pieces and evaluates |r|^2 at the new point with the symmetric G formed once.  68.7 -> 64 us per 32 x 1024 samples with
 // the pre-check; all 158 800 f32 models of the A/B set bit-identical (the f64 differences round away), same valid flags.
+// 1: the f32 models and validity bytes of a block's 32 samples (11.5 KB + 320 B, contiguous in the output) are assembled in
+// LDS -- identity pattern first, verified solutions over it -- and written out as whole 16-byte pieces of consecutive lanes:
+// 12 + 1 coalesced store instructions per wave instead of ~120 scattered ones (9 dwords per verified solution and per
+// identity filler, 360 bytes apart from lane to lane: every dword its own 64-byte request).  Measured: 55.9 -> 57.7 us per
+// 32 x 1024 samples, step 0.973 vs 0.974 ms -- the scattered stores are not what the final stage waits for (it is ~7 k
+// instructions per wave: the per-lane start vectors, 2.3 Gauss-Newton rounds, three verification rounds).  Off; bit-identical.
+#ifndef DR_K3_STAGE_OUT
+#define DR_K3_STAGE_OUT 0
+#endif
 #ifndef DR_K3_JAC2
 #define DR_K3_JAC2 1
 #endif
@@ -378,13 +387,17 @@ struct FinishQueue {
   int *cnt;          // 64: verified solutions so far of (sample, half) = source lane
   uint16_t *live;    // 2 x 320: candidates that need another Gauss-Newton step (this round | next round)
   double *rn;        // 320: squared norm of the ten constraints at the candidate's current vector (DR_K3_PRECHECK)
-  static constexpr int kQueueDoubles = 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4 + 320;
+  float *stage;      // 32 x 90: the block's f32 output, assembled here and written out in whole lines (DR_K3_STAGE_OUT)
+  uint8_t *vstage;   // 32 x 10 validity bytes of the same
+  static constexpr int kQueueDoubles = 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4 + 320 + (DR_K3_STAGE_OUT ? 32 * 90 / 2 + 320 / 8 : 0);
   static constexpr int kDoubles = 36 * 32 + kQueueDoubles;
   __device__ __forceinline__ explicit FinishQueue(double *lds)
       : nb_src(lds), nb_lds(lds), u(lds + 36 * 32), meta(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 4 * 320)),
         cnt(reinterpret_cast<int *>(lds + 36 * 32 + 4 * 320 + 320 / 4)),
         live(reinterpret_cast<uint16_t *>(lds + 36 * 32 + 4 * 320 + 320 / 4 + 64 / 2)),
-        rn(lds + 36 * 32 + 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4) {}
+        rn(lds + 36 * 32 + 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4),
+        stage(reinterpret_cast<float *>(lds + 36 * 32 + 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4 + 320)),
+        vstage(reinterpret_cast<uint8_t *>(lds + 36 * 32 + 4 * 320 + 320 / 4 + 64 / 2 + 2 * 320 / 4 + 320 + 32 * 90 / 2)) {}
   __device__ __forceinline__ void load_basis(int j, double (&nb)[4][9]) const {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -482,6 +495,10 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     nlive += __popcll(bm);
   }
   wave_lds_order();
+#ifdef DR_PROFILE_STAGES
+  if (lane == 0) { atomicAdd(&::dr::g_stage_cycles[13], (unsigned long long)nlive); atomicAdd(&::dr::g_stage_cycles[14], (unsigned long long)total); }
+  int _steps = 0;
+#endif
   // ---- (B') steps 1..8 of the candidates that asked for them
 #pragma unroll 1
   for (int it = 0; it < 8 && nlive > 0; ++it) {
@@ -490,6 +507,9 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     int nnext = 0;
 #pragma unroll 1
     for (int base = 0; base < nlive; base += 64) {
+#ifdef DR_PROFILE_STAGES
+      ++_steps;
+#endif
       const bool has = base + lane < nlive;
       const int e = cur[has ? base + lane : base];
       double nb[4][9], u[4], un[4], n0, n1;
@@ -511,6 +531,9 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     nlive = nnext;
     wave_lds_order();
   }
+#ifdef DR_PROFILE_STAGES
+  if (lane == 0) atomicAdd(&::dr::g_stage_cycles[15], (unsigned long long)_steps);
+#endif
 #else
   // ---- (A) first step
   int nlive = 0;
@@ -567,6 +590,22 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     wave_lds_order();
   }
 #endif
+  constexpr bool kStage = DR_K3_STAGE_OUT && sizeof(T) == 4;
+  if (kStage) {
+    // every slot starts as the eye(3) filler with validity 0
+#pragma unroll 1
+    for (int i = lane; i < 32 * 90 / 4; i += 64) {
+      const int e0 = (4 * i) % 9;
+      float4 v;
+      v.x = (e0 % 4 == 0) ? 1.f : 0.f;
+      v.y = (((e0 + 1) % 9) % 4 == 0) ? 1.f : 0.f;
+      v.z = (((e0 + 2) % 9) % 4 == 0) ? 1.f : 0.f;
+      v.w = (((e0 + 3) % 9) % 4 == 0) ? 1.f : 0.f;
+      *reinterpret_cast<float4 *>(fq.stage + 4 * i) = v;
+    }
+    for (int i = lane; i < 320 / 4; i += 64) *reinterpret_cast<uint32_t *>(fq.vstage + 4 * i) = 0u;
+    wave_lds_order();
+  }
   // ---- (C) verification of the ten constraints, rank among the verified candidates of the same source lane, store
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
@@ -605,18 +644,60 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     if (good && rank < 10) {
       const int slot = (src & 1) ? 9 - rank : rank;
       const size_t sm_ = s0 + (size_t)j;
-      store_model<T>(E, models + sm_ * 90 + 9 * slot, models64 ? models64 + sm_ * 90 + 9 * slot : nullptr);
-      valid[sm_ * 10 + slot] = 1;
+      if (kStage) {
+        float *dst = fq.stage + (j * 10 + slot) * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int jx = 0; jx < 3; ++jx) dst[3 * i + jx] = (float)E[3 * jx + i];   // stored transposed (nister.py:407)
+        fq.vstage[j * 10 + slot] = 1;
+        if (models64) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jx = 0; jx < 3; ++jx) models64[sm_ * 90 + 9 * slot + 3 * i + jx] = E[3 * jx + i];
+        }
+      } else {
+        store_model<T>(E, models + sm_ * 90 + 9 * slot, models64 ? models64 + sm_ * 90 + 9 * slot : nullptr);
+        valid[sm_ * 10 + slot] = 1;
+      }
     }
   }
   // eye(3) between the two halves' solutions
-  if (active && (lane & 1) == 0) {
+  if ((!kStage || models64) && active && (lane & 1) == 0) {
     const int lo = min(fq.cnt[lane], 10), hi = min(fq.cnt[lane + 1], 10);
     const size_t sm_ = s0 + (size_t)(lane >> 1);
     for (int s = min(lo, 10 - hi); s < 10 - hi; ++s) {
-      write_identity<T>(models + sm_ * 90 + 9 * s);
+      if (!kStage) {
+        write_identity<T>(models + sm_ * 90 + 9 * s);
+        valid[sm_ * 10 + s] = 0;
+      }
       if (models64) write_identity<double>(models64 + sm_ * 90 + 9 * s);
-      valid[sm_ * 10 + s] = 0;
+    }
+  }
+  if (kStage) {
+    // the block's output rows [s0, s0 + ns) x 90 floats and x 10 bytes are contiguous: whole 16-byte pieces, lane after lane
+    wave_lds_order();
+    const int ns = __popcll(__ballot(active)) >> 1;
+    const int nf = ns * 90, nv = ns * 10;
+    float *out = reinterpret_cast<float *>(models) + s0 * 90;    // 16-byte aligned: s0 is a multiple of 32
+#pragma unroll 1
+    for (int i = lane; i < 32 * 90 / 4; i += 64) {
+      const float4 val = *reinterpret_cast<const float4 *>(fq.stage + 4 * i);
+      if (4 * i + 3 < nf) *reinterpret_cast<float4 *>(out + 4 * i) = val;
+      else {
+        if (4 * i < nf) out[4 * i] = val.x;
+        if (4 * i + 1 < nf) out[4 * i + 1] = val.y;
+        if (4 * i + 2 < nf) out[4 * i + 2] = val.z;
+      }
+    }
+    uint8_t *vout = valid + s0 * 10;                                // 4-byte aligned: s0 * 10 is a multiple of 320
+    for (int i = lane; i < 320 / 4; i += 64) {
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(fq.vstage + 4 * i);
+      if (4 * i + 3 < nv) *reinterpret_cast<uint32_t *>(vout + 4 * i) = w;
+      else
+        for (int b = 0; b < 4; ++b)
+          if (4 * i + b < nv) vout[4 * i + b] = (uint8_t)(w >> (8 * b));
     }
   }
 }
@@ -731,7 +812,7 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
 constexpr int kPairFinishDoubles = (36 + 39) * 32;
 constexpr int kmax(int a, int b) { return a > b ? a : b; }
 constexpr int kNisterPairDoubles =
-    kmax(100 * 32, kmax(FinishQueue::kDoubles, kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? RootWs<10>::kDoubles : 0)));
+    kmax(100 * 32, kmax(FinishQueue::kDoubles, kPairFinishDoubles + (DR_K3_WAVE_ROOTS ? kmax(RootWs<10>::kDoubles, DR_K3_STURM ? SturmWs<10>::kDoubles : 0) : 0)));
 
 // B(z) (rows k = e - z f, l = g - z h, m = i - z j of the reduced system; columns x: degree 3, y: degree 3, 1: degree 4) as
 // 39 doubles bz[13 r + (0..3 | 4..7 | 8..12)] and its determinant's coefficients cs[0..10] (ascending)
@@ -836,7 +917,11 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
   int nroots;
   DR_STAGE_BEGIN();
 #if DR_K3_WAVE_ROOTS
+#if DR_K3_STURM
+  real_roots_half_sturm<10>(cs, half != 0, roots, nroots, lds + kPairFinishDoubles, lane);
+#else
   real_roots_half_wave<10>(cs, half != 0, roots, nroots, lds + kPairFinishDoubles, lane);
+#endif
 #else
   real_roots_half<10>(cs, half != 0, roots, nroots);
 #endif
@@ -851,6 +936,10 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
     nister_xy_of_roots(bz, roots, nroots, xs, ys, cand);
   }
   DR_STAGE(4);
+#ifdef DR_K3_SKIP_FINAL   // timing experiment: everything but the final stage (the results are kept alive by one store)
+  if (active && lane == 0) models[s0 * 90] = (T)(xs[0] + ys[1] + (double)cand);
+  return;
+#endif
   balanced_finish<T>(fq, lane, nroots, xs, ys, roots, cand, s0, active, models, valid, models64);
 }
 

@@ -194,7 +194,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
   double roots[10];
   int nroots;
 #if DR_K3_WAVE_ROOTS
+#if DR_K3_STURM
+  real_roots_half_sturm<10>(cs, half != 0, roots, nroots, lds, lane);   // the right block's LDS is free again
+#else
   real_roots_half_wave<10>(cs, half != 0, roots, nroots, lds, lane);   // the right block's LDS is free again
+#endif
 #else
   real_roots_half<10>(cs, half != 0, roots, nroots);
 #endif
@@ -297,6 +301,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
 #endif
 }
 
+static inline bool aligned_out(const void *models, const void *valid) {
+  return !DR_K3_STAGE_OUT || ((reinterpret_cast<uintptr_t>(models) & 15u) == 0 && (reinterpret_cast<uintptr_t>(valid) & 3u) == 0);
+}
+
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st,
                   double *models64 = nullptr) {
@@ -327,7 +335,7 @@ template <typename T>
 int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st) {
   // the right 10x10 block of 32 samples, later the root-search workspace, then the candidate queue
   constexpr int kDoubles = (DR_K3_BALANCED && FinishQueue::kDoubles > 100 * 32) ? FinishQueue::kDoubles : 100 * 32;
-  static_assert(!DR_K3_WAVE_ROOTS || RootWs<10>::kDoubles <= kDoubles, "root-search workspace");
+  static_assert(!DR_K3_WAVE_ROOTS || (RootWs<10>::kDoubles <= kDoubles && SturmWs<10>::kDoubles <= kDoubles), "root-search workspace");
   const size_t smem = sizeof(double) * kDoubles;
   hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, Bt, models, valid);
   return check_launch("stewenius5_pair_kernel");
@@ -342,6 +350,7 @@ extern "C" {
 int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
                          void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
   DR_REQUIRE(Bt > 0 && n >= 5, "need Bt > 0 and n >= 5 points per sample");
   return dr::nister_launch<float>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
 }
@@ -354,11 +363,13 @@ int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, i
 int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
                             uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && models_f64 && valid, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, models_f64);
 }
 int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream);
 }

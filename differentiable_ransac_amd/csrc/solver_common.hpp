@@ -97,6 +97,9 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
 #ifndef DR_ROOT_F32_LOW
 #define DR_ROOT_F32_LOW 0
 #endif
+#ifndef DR_K3_STURM
+#define DR_K3_STURM 1   // 1: the two-lanes-per-sample kernels isolate the roots by a Sturm sequence (real_roots_half_sturm)
+#endif
 #ifndef DR_ROOT_BIS_LOW
 #define DR_ROOT_BIS_LOW 6
 #define DR_ROOT_NEWT_LOW 4
@@ -472,6 +475,272 @@ __device__ __forceinline__ void real_roots_half_wave(const double (&c)[D + 1], b
     if (take) {
 #pragma unroll
       for (int t = 0; t < D; ++t) roots[t] = (t == count) ? v : roots[t];
+    }
+    count += take ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Root ISOLATION by a Sturm sequence (DR_K3_STURM): the derivative chain above isolates the roots of p by finding, level by
+// level, ALL roots of p', p'', ... in [-1, 1] first -- 45 k of the 56 k cycles a wave spends in the root search, although a
+// sample-half holds 2.3 real roots on average.  Here a lane builds the Sturm chain of its polynomial once (f0 = p, f1 = p',
+// f_{k+1} = -rem(f_{k-1}, f_k) as division-free pseudo-remainders with positive multipliers, each renormalised to max |coef| = 1
+// by an approximate reciprocal -- any positive scale keeps the signs), keeps it in registers (66 doubles) and bisects (-1, 1]
+// on the sign-variation count V: an interval (a, b] holds V(a) - V(b) distinct real roots.  Intervals wait on a per-lane
+// stack in LDS (left part on top, so isolated intervals come off in ascending order); they share one array of D entries with
+// the output list (isolated + pending <= number of roots <= D).  4.4 evaluations of V per polynomial on RANSAC samples, 12-14
+// for the slowest lane of a wave (scratch/sturm_proto.py, against numpy's eigenvalues: 0-5e-5 of the real roots missed, the
+// same as the idealised derivative chain misses).  The isolated roots are then refined by the SAME wave-wide task rounds on p
+// (bisection + Newton on a bracket with a sign change), so the final accuracy is the one of the level-D tasks.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct SturmWs {
+  double *lo, *hi;     // D x 64 each: entry e of lane l at [e * 64 + l]; after the refine tasks lo holds the root
+  uint32_t *vv;        // D x 64: V(lo) | sign(p(lo)) << 4 | V(hi) << 8 | sign(p(hi)) << 12
+  double *q;           // (D + 1) x 64: coefficient i of lane l's polynomial (for the tasks)
+  uint16_t *queue;     // D x 64 tasks: source lane | entry << 6 | (p(lo) < 0) << 10
+  static constexpr int kDoubles = 2 * D * 64 + D * 64 / 2 + (D + 1) * 64 + (D * 64 + 3) / 4;
+  __device__ __forceinline__ explicit SturmWs(double *ws)
+      : lo(ws), hi(ws + D * 64), vv(reinterpret_cast<uint32_t *>(ws + 2 * D * 64)), q(ws + 2 * D * 64 + D * 64 / 2),
+        queue(reinterpret_cast<uint16_t *>(ws + 2 * D * 64 + D * 64 / 2 + (D + 1) * 64)) {}
+};
+
+// the refine rounds: root_tasks with the bracket ends in separate arrays and the polynomial always of degree D
+template <int D, int R>
+__device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int lane, int kBis, int kNewt) {
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64 * R) {
+    double a[R], b[R], y[R], qq[R][D + 1];
+    bool neg[R], val[R];
+    int dst[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int t = base + 64 * r + lane;
+      val[r] = t < total;
+      const unsigned m = ws.queue[val[r] ? t : base];
+      const int src = m & 63, e = (m >> 6) & 15;
+      neg[r] = (m >> 10) & 1u;
+      dst[r] = e * 64 + src;
+      a[r] = ws.lo[dst[r]];
+      b[r] = ws.hi[dst[r]];
+#pragma unroll
+      for (int k = 0; k <= D; ++k) qq[r][k] = ws.q[k * 64 + src];
+    }
+#pragma unroll 1
+    for (int it = 0; it < kBis; ++it) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double m = 0.5 * (a[r] + b[r]);
+        double fx = qq[r][D];
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) fx = fx * m + qq[r][k];
+        const bool left = (fx < 0) == neg[r];
+        a[r] = left ? m : a[r];
+        b[r] = left ? b[r] : m;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r] = 0.5 * (a[r] + b[r]);
+#pragma unroll 1
+    for (int it = 0; it < kNewt; ++it) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double fx = qq[r][D], dfx = 0;
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) {
+          dfx = dfx * y[r] + fx;
+          fx = fx * y[r] + qq[r][k];
+        }
+        const bool left = (fx < 0) == neg[r];
+        a[r] = left ? y[r] : a[r];
+        b[r] = left ? b[r] : y[r];
+        double yn = y[r] - fx * __builtin_amdgcn_rcp(dfx);
+        if (!(yn > a[r] && yn < b[r])) yn = 0.5 * (a[r] + b[r]);
+        y[r] = (fx == 0.0) ? y[r] : yn;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (val[r]) ws.lo[dst[r]] = y[r];
+  }
+}
+
+// wave-cooperative (block = one wave): every lane must call it.  Same outputs as real_roots_half_wave.
+template <int D, int kBisLast = DR_ROOT_BIS_LAST, int kNewtLast = DR_ROOT_NEWT_LAST>
+__device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count, double *lds_ws,
+                                                      int lane) {
+  const SturmWs<D> ws(lds_ws);
+#ifdef DR_PROFILE_STAGES
+  unsigned long long _st0 = __builtin_readcyclecounter();
+  int _iters = 0;
+#endif
+  double cmax = 0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
+  const bool ok = is_finite(cmax) && cmax > 0;
+  const double sc = ok ? 1.0 / cmax : 0.0;
+  // chain F[k] = polynomial of degree D - k, ascending coefficients F[k][0 .. D - k]
+  double F[D + 1][D + 1];
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    const double a = ok ? c[i] * sc : (i == 0 ? 1.0 : 0.0);
+    const double b = ok ? c[D - i] * sc : (i == 0 ? 1.0 : 0.0);
+    F[0][i] = outer ? b : a;
+    ws.q[i * 64 + lane] = F[0][i];
+  }
+  auto renorm = [](double (&f)[D + 1], int deg) {   // positive scale only: an approximate reciprocal is enough
+    double mx = 0;
+#pragma unroll
+    for (int i = 0; i <= D; ++i)
+      if (i <= deg) mx = fmax(mx, fabs(f[i]));
+    const double s = (mx > 0 && is_finite(mx)) ? (double)__builtin_amdgcn_rcpf((float)mx) : 1.0;
+#pragma unroll
+    for (int i = 0; i <= D; ++i)
+      if (i <= deg) f[i] *= s;
+  };
+#pragma unroll
+  for (int i = 0; i < D; ++i) F[1][i] = F[0][i + 1] * (double)(i + 1);
+  renorm(F[1], D - 1);
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    // A = F[k-1] (degree n), B = F[k] (degree n - 1):  F[k+1] = -(b^2 A - (a_n b x + (a_{n-1} b - a_n b_{n-2})) B), degree n - 2
+    const int n = D - k + 1;
+    const double an = F[k - 1][n], an1 = F[k - 1][n - 1], b = F[k][n - 1], b2 = (n >= 2) ? F[k][n - 2] : 0.0;
+    const double q1 = an * b, q0 = an1 * b - an * b2, bb = b * b;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+      if (i <= n - 2) {
+        double r = q0 * F[k][i] - bb * F[k - 1][i];
+        if (i >= 1) r += q1 * F[k][i - 1];
+        F[k + 1][i] = r;
+      }
+    }
+    renorm(F[k + 1], n - 2);
+  }
+  // sign variations of the chain at x (bits 0-3) and the sign of p(x) (bit 4)
+  auto variations = [&](double x) -> unsigned {
+    // all Horner chains advance together (step i touches every polynomial that still has a coefficient left): eleven independent
+    // dependency chains instead of one after the other
+    double val[D + 1];
+#pragma unroll
+    for (int k = 0; k <= D; ++k) val[k] = F[k][D - k];
+#pragma unroll
+    for (int i = 1; i <= D; ++i)
+#pragma unroll
+      for (int k = 0; k + i <= D; ++k) val[k] = val[k] * x + F[k][D - k - i];
+    unsigned w = 0;
+#pragma unroll
+    for (int k = 0; k <= D; ++k) w |= ((unsigned)__double2hiint(val[k]) >> 31) << k;
+    const unsigned ch = (w ^ (w >> 1)) & ((1u << D) - 1u);
+    return (unsigned)__popc(ch) | ((w & 1u) << 4);
+  };
+  const unsigned vm = variations(-1.0), vp = variations(1.0);
+#ifdef DR_PROFILE_STAGES
+  if (D == 10 && lane == 0) atomicAdd(&::dr::g_stage_cycles[6], __builtin_readcyclecounter() - _st0);
+  _st0 = __builtin_readcyclecounter();
+#endif
+  // entries [0, nout) = isolated intervals in ascending order; entries [top, D) = pending, the leftmost on top; the interval a
+  // lane is working on stays in registers (LDS is read only when an interval is popped: once per root, not once per step)
+  int nout = 0, top = D;
+  bool have = ok && (int)(vm & 15u) - (int)(vp & 15u) >= 1;
+  double l = -1.0, h = 1.0;
+  unsigned v = vm | (vp << 8);
+  auto pop = [&]() {
+    have = top < D;
+    const int tc = have ? top : D - 1;
+    l = ws.lo[tc * 64 + lane];
+    h = ws.hi[tc * 64 + lane];
+    v = ws.vv[tc * 64 + lane];
+    top += have ? 1 : 0;
+  };
+#pragma unroll 1
+  for (int guard = 0; guard < 64 * D; ++guard) {
+    if (!__any(have)) break;
+#ifdef DR_PROFILE_STAGES
+    ++_iters;
+#endif
+    // one action per lane and step: an isolated interval goes to the output list and the next pending one comes off the stack
+    // (LDS only), any other interval is split at its midpoint (one evaluation of the chain)
+    const bool iso = have && ((int)(v & 15u) - (int)((v >> 8) & 15u) == 1);
+    if (iso) {
+      ws.lo[nout * 64 + lane] = l;
+      ws.hi[nout * 64 + lane] = h;
+      ws.vv[nout * 64 + lane] = v;
+      ++nout;
+      pop();
+    } else if (have) {
+      const double mid = 0.5 * (l + h);
+      const unsigned vmid = variations(mid);
+      const int nl = (int)(v & 15u) - (int)(vmid & 15u), nr = (int)(vmid & 15u) - (int)((v >> 8) & 15u);
+      // an interval that cannot be split any more (a multiple root to rounding) or whose halves both come out empty
+      // (inconsistent counts of a degenerate chain) is dropped
+      const bool splittable = mid > l && mid < h && (h - l) > 1e-12;
+      if (!splittable || (nl < 1 && nr < 1)) {
+        pop();
+      } else if (nl == 1 && nr >= 1 && top - 2 >= nout) {
+        // the left part is isolated: straight to the output list (it is the leftmost interval of this lane), go on with the right
+        ws.lo[nout * 64 + lane] = l;
+        ws.hi[nout * 64 + lane] = mid;
+        ws.vv[nout * 64 + lane] = (v & 31u) | ((vmid & 31u) << 8);
+        ++nout;
+        l = mid;
+        v = (vmid & 31u) | (v & 0xff00u);
+      } else if (nl >= 1) {
+        if (nr >= 1 && top - 2 >= nout) {   // right part waits on the stack (dropped if there is no room: degenerate counts)
+          --top;
+          ws.lo[top * 64 + lane] = mid;
+          ws.hi[top * 64 + lane] = h;
+          ws.vv[top * 64 + lane] = (vmid & 31u) | (v & 0xff00u);
+        }
+        h = mid;
+        v = (v & 31u) | ((vmid & 31u) << 8);
+      } else {
+        l = mid;
+        v = (vmid & 31u) | (v & 0xff00u);
+      }
+    }
+  }
+  wave_lds_order();
+#ifdef DR_PROFILE_STAGES
+  if (D == 10 && lane == 0) { atomicAdd(&::dr::g_stage_cycles[7], __builtin_readcyclecounter() - _st0); atomicAdd(&::dr::g_stage_cycles[9], (unsigned long long)_iters); atomicMax(&::dr::g_stage_cycles[10], (unsigned long long)_iters); }
+  _st0 = __builtin_readcyclecounter();
+#endif
+  // tasks: the isolated intervals whose ends differ in the sign of p
+  unsigned has_mask = 0;
+  int offs = 0;
+#pragma unroll
+  for (int e = 0; e < D; ++e) {
+    const unsigned v = ws.vv[(e < nout ? e : 0) * 64 + lane];
+    const bool h = e < nout && (((v >> 4) ^ (v >> 12)) & 1u);
+    const unsigned long long bm = __ballot(h);
+    if (bm) {
+      const int pos = offs + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+      if (h) {
+        has_mask |= 1u << e;
+        ws.queue[pos] = (uint16_t)(lane | (e << 6) | (((v >> 4) & 1u) << 10));
+      }
+      offs += __popcll(bm);
+    }
+  }
+  wave_lds_order();
+  if (offs <= 64) sturm_tasks<D, 1>(ws, offs, lane, kBisLast, kNewtLast);
+  else if (offs <= 128) sturm_tasks<D, 2>(ws, offs, lane, kBisLast, kNewtLast);
+  else sturm_tasks<D, 3>(ws, offs, lane, kBisLast, kNewtLast);
+  wave_lds_order();
+#ifdef DR_PROFILE_STAGES
+  if (D == 10 && lane == 0) atomicAdd(&::dr::g_stage_cycles[8], __builtin_readcyclecounter() - _st0);
+#endif
+  count = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) roots[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double xk = ws.lo[k * 64 + lane];
+    const double vv_ = outer ? 1.0 / xk : xk;
+    const bool take = ((has_mask >> k) & 1u) && (!outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0));
+    if (take) {
+#pragma unroll
+      for (int t = 0; t < D; ++t) roots[t] = (t == count) ? vv_ : roots[t];
     }
     count += take ? 1 : 0;
   }

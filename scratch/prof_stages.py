@@ -5,12 +5,14 @@ import torch
 src = sorted(glob.glob('differentiable_ransac_amd/csrc/*.hip'))
 out = 'gpurun_out/libdransac_prof.so'
 os.makedirs('gpurun_out', exist_ok=True)
+extra = [a for a in sys.argv[1:] if a.startswith('-D')]
+tag = ''.join(a.replace('-D', '_').replace('=', '') for a in extra)
 if '--build' in sys.argv:
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
-                           '-DDR_PROFILE_STAGES', '-o', 'scratch/libdransac_prof.so', *src])
+                           '-DDR_PROFILE_STAGES', *extra, '-o', f'scratch/libdransac_prof{tag}.so', *src])
     sys.exit(0)
 import differentiable_ransac_amd._lib as L
-L.LIB_PATH = os.path.abspath('scratch/libdransac_prof.so')
+L.LIB_PATH = os.path.abspath(f'scratch/libdransac_prof{tag}.so')
 from differentiable_ransac_amd import ops, synth
 dev = 'cuda'
 P, N, B = 32, 2000, 1024
@@ -25,4 +27,4 @@ for name, fn in (('nister', ops.solve_nister5),):
     fn(smp); torch.cuda.synchronize()
     lib.dr_debug_stage_read_fivepoint(buf)
     tot = sum(buf)
-    print(name, 'waves', P * B // 64, 'cycles/wave by stage:', [int(b) // (P * B // 64) for b in buf[:8]])
+    print(name, 'waves', P * B // 32, 'cycles/wave by stage:', [int(b) // (P * B // 32) for b in buf[:10]] + [round(int(buf[i]) / (P * B // 32), 2) for i in (13, 14, 15)], 'max isolation iterations of a wave', int(buf[10]))
