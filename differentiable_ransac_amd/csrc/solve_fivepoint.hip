@@ -341,6 +341,30 @@ int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStr
   return check_launch("stewenius5_pair_kernel");
 }
 
+// ---- test hook: the real-root search of the two-lanes-per-sample kernels on given degree-10 polynomials -------------------
+// One lane pair per polynomial (even lane: |z| <= 1, odd lane: |z| > 1 through the reversed polynomial), exactly as the solver
+// kernels call it.  method 0 = derivative chain (real_roots_half_wave), 1 = Sturm isolation (real_roots_half_sturm).
+template <int kMethod>
+__global__ __launch_bounds__(64) void debug_roots10_kernel(const double *__restrict__ coef, int n, double *__restrict__ roots,
+                                                           int32_t *__restrict__ counts) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x, half = lane & 1;
+  const int s = blockIdx.x * 32 + (lane >> 1);
+  const int sc = s < n ? s : n - 1;
+  double cs[11];
+#pragma unroll
+  for (int i = 0; i <= 10; ++i) cs[i] = coef[(size_t)sc * 11 + i];
+  double r[10];
+  int nr = 0;
+  if (kMethod == 1) real_roots_half_sturm<10>(cs, half != 0, r, nr, lds, lane);
+  else real_roots_half_wave<10>(cs, half != 0, r, nr, lds, lane);
+  if (s < n) {
+    counts[(size_t)s * 2 + half] = nr;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) roots[((size_t)s * 2 + half) * 10 + i] = r[i];
+  }
+}
+
 }  // namespace dr
 
 DR_DEFINE_STAGE_READER(dr_debug_stage_read_fivepoint)
@@ -367,6 +391,18 @@ int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, 
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, models_f64);
 }
+int dr_debug_real_roots10(const double *coef, int n, int method, double *roots, int32_t *counts, void *stream) {
+  DR_REQUIRE(coef && roots && counts, "null pointer");
+  DR_REQUIRE(n > 0 && (method == 0 || method == 1), "need n > 0 and method 0 (derivative chain) or 1 (Sturm)");
+  constexpr int kD = dr::RootWs<10>::kDoubles > dr::SturmWs<10>::kDoubles ? dr::RootWs<10>::kDoubles : dr::SturmWs<10>::kDoubles;
+  const size_t smem = sizeof(double) * kD;
+  if (method == 1)
+    hipLaunchKernelGGL((dr::debug_roots10_kernel<1>), dim3((n + 31) / 32), dim3(64), smem, (hipStream_t)stream, coef, n, roots, counts);
+  else
+    hipLaunchKernelGGL((dr::debug_roots10_kernel<0>), dim3((n + 31) / 32), dim3(64), smem, (hipStream_t)stream, coef, n, roots, counts);
+  return dr::check_launch("debug_roots10_kernel");
+}
+
 int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");

@@ -105,6 +105,26 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
 #define DR_ROOT_NEWT_LOW 4
 #endif
 __device__ __forceinline__ double root_rcp(double v) { return __builtin_amdgcn_rcp(v); }
+// The safeguarded Newton step of the fixed schedules: y - step when that stays inside the bracket [a, b], else the midpoint --
+// EXCEPT when the step has already shrunk to rounding level.  After `a = y` (or `b = y`) a converged iterate sits ON the end of
+// its bracket, and a last-bit step (zero, or one ulp outwards: the sign of f is noise there) used to fail the strict test
+// `a < yn < b` and send the iterate to the midpoint -- half a bracket away from the root it had found, which the remaining
+// steps of the schedule then only bisected back (rounds 1-2: 22 % of the roots left the refinement with a backward error above
+// 1e-13, up to 1e-2, and the Gauss-Newton polish repaired them; tests/test_gpu_roots.py).  DR_ROOT_KEEP_CONVERGED=0: old rule.
+#ifndef DR_ROOT_KEEP_CONVERGED
+#define DR_ROOT_KEEP_CONVERGED 1
+#endif
+template <typename F>
+__device__ __forceinline__ F safeguarded_newton(F y, F step, F a, F b) {
+  F yn = y - step;
+#if DR_ROOT_KEEP_CONVERGED
+  const F tiny = (sizeof(F) == 8 ? (F)4e-16 : (F)5e-7) * ((F)1 + fabs(y));
+  if (!(yn >= a && yn <= b)) yn = (fabs(step) <= tiny) ? y : (F)0.5 * (a + b);
+#else
+  if (!(yn > a && yn < b)) yn = (F)0.5 * (a + b);
+#endif
+  return yn;
+}
 __device__ __forceinline__ float root_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 
 template <int D, int kBisLast, int kNewtLast>
@@ -166,9 +186,10 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
 #pragma unroll
       for (int i = 0; i < d; ++i) {
         const F m = (F)0.5 * (a[i] + b[i]);
-        const bool left = (evalf(m) < 0) == neg_a[i];
-        a[i] = left ? m : a[i];
-        b[i] = left ? b[i] : m;
+        const F fm = evalf(m);
+        const bool left = (fm < 0) == neg_a[i], hit = fm == (F)0;   // a midpoint that IS the root closes the bracket on it
+        a[i] = (left || hit) ? m : a[i];
+        b[i] = (left && !hit) ? b[i] : m;
       }
     }
 #pragma unroll
@@ -182,8 +203,7 @@ __device__ __forceinline__ void roots_in_unit(const double (&c)[D + 1], double (
         const bool left = (fx < 0) == neg_a[i];
         a[i] = left ? y[i] : a[i];
         b[i] = left ? b[i] : y[i];
-        F yn = y[i] - fx * root_rcp(dfx);
-        if (!(yn > a[i] && yn < b[i])) yn = (F)0.5 * (a[i] + b[i]);
+        const F yn = safeguarded_newton<F>(y[i], fx * root_rcp(dfx), a[i], b[i]);
         y[i] = (fx == 0) ? y[i] : yn;
       }
     }
@@ -339,9 +359,9 @@ __device__ __forceinline__ void root_tasks(const RootWs<D> &ws, const double *__
         double fx = qq[r][d];
 #pragma unroll
         for (int k = d - 1; k >= 0; --k) fx = fx * m + qq[r][k];
-        const bool left = (fx < 0) == neg[r];
-        a[r] = left ? m : a[r];
-        b[r] = left ? b[r] : m;
+        const bool left = (fx < 0) == neg[r], hit = fx == 0.0;   // a midpoint that IS the root closes the bracket on it
+        a[r] = (left || hit) ? m : a[r];
+        b[r] = (left && !hit) ? b[r] : m;
       }
     }
 #pragma unroll
@@ -359,8 +379,7 @@ __device__ __forceinline__ void root_tasks(const RootWs<D> &ws, const double *__
         const bool left = (fx < 0) == neg[r];
         a[r] = left ? y[r] : a[r];
         b[r] = left ? b[r] : y[r];
-        double yn = y[r] - fx * __builtin_amdgcn_rcp(dfx);
-        if (!(yn > a[r] && yn < b[r])) yn = 0.5 * (a[r] + b[r]);
+        const double yn = safeguarded_newton<double>(y[r], fx * __builtin_amdgcn_rcp(dfx), a[r], b[r]);
         y[r] = (fx == 0.0) ? y[r] : yn;
       }
     }
@@ -534,9 +553,9 @@ __device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int
         double fx = qq[r][D];
 #pragma unroll
         for (int k = D - 1; k >= 0; --k) fx = fx * m + qq[r][k];
-        const bool left = (fx < 0) == neg[r];
-        a[r] = left ? m : a[r];
-        b[r] = left ? b[r] : m;
+        const bool left = (fx < 0) == neg[r], hit = fx == 0.0;   // a midpoint that IS the root closes the bracket on it
+        a[r] = (left || hit) ? m : a[r];
+        b[r] = (left && !hit) ? b[r] : m;
       }
     }
 #pragma unroll
@@ -554,8 +573,7 @@ __device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int
         const bool left = (fx < 0) == neg[r];
         a[r] = left ? y[r] : a[r];
         b[r] = left ? b[r] : y[r];
-        double yn = y[r] - fx * __builtin_amdgcn_rcp(dfx);
-        if (!(yn > a[r] && yn < b[r])) yn = 0.5 * (a[r] + b[r]);
+        const double yn = safeguarded_newton<double>(y[r], fx * __builtin_amdgcn_rcp(dfx), a[r], b[r]);
         y[r] = (fx == 0.0) ? y[r] : yn;
       }
     }
@@ -669,7 +687,9 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
       ++nout;
       pop();
     } else if (have) {
-      const double mid = 0.5 * (l + h);
+      // split a hair off the centre: a root AT a split point would be counted with the sign of +0 (nice inputs have nice roots:
+      // 0, 1/2, 1/4 ... are exactly where plain halving of (-1, 1] looks)
+      const double mid = __builtin_fma(h - l, 0.49999952316284180, l);
       const unsigned vmid = variations(mid);
       const int nl = (int)(v & 15u) - (int)(vmid & 15u), nr = (int)(vmid & 15u) - (int)((v >> 8) & 15u);
       // an interval that cannot be split any more (a multiple root to rounding) or whose halves both come out empty

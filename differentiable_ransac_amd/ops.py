@@ -340,6 +340,17 @@ def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = No
     return models.reshape(*lead, 10, 3, 3), m64.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 
+def debug_real_roots10(coef: torch.Tensor, method: int = 1):
+    """Test hook (dr_debug_real_roots10): coef [n,11] f64 ascending -> roots [n,2,10] f64, counts [n,2] int32; half 0 = |z| <= 1,
+    half 1 = |z| > 1; method 0 = derivative chain, 1 = Sturm isolation (what the five-point kernels run)."""
+    coef = coef.to(torch.float64).contiguous()
+    n = coef.shape[0]
+    roots = torch.zeros((n, 2, 10), device=coef.device, dtype=torch.float64)
+    counts = torch.zeros((n, 2), device=coef.device, dtype=torch.int32)
+    L.call("dr_debug_real_roots10", ptr(coef), c_int(n), c_int(method), ptr(roots), ptr(counts), stream())
+    return roots, counts
+
+
 def solve_stewenius5(samples: torch.Tensor):
     s, Bt, n = _flat_samples(samples, 4)
     if n != 5:

@@ -157,6 +157,12 @@ int dr_solve_f8_f32(const float *samples, const float *weights, int Bt, int n, f
                     void *stream);
 int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n, double *models, uint8_t *valid,
                     void *stream);
+/* Test hook: the real-root search of the five-point kernels (replaces torch.linalg.eigvals of the companion matrix,
+ * nister.py:361-370, and eig, stewenius.py:74) on given polynomials.  coef [n,11] ascending; per polynomial two searches,
+ * exactly as the solver kernels run them: roots [n,2,10] -- [.,0,.] the roots with |z| <= 1 ascending, [.,1,.] those with
+ * |z| > 1 (found as roots w of the reversed polynomial, ascending in w, returned as 1/w) -- and counts [n,2].
+ * method 0 = derivative chain (rounds 1-2), 1 = Sturm-sequence isolation (round 3, what the kernels run). */
+int dr_debug_real_roots10(const double *coef, int n, int method, double *roots, int32_t *counts, void *stream);
 int dr_solve_f7_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
 int dr_solve_f7_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
 int dr_solve_rigid_f32(const float *samples, const float *weights, int Bt, int n, int flag, float *models, float *R,
