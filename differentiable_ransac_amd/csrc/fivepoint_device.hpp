@@ -33,6 +33,10 @@ namespace dr {
                               // 1e-16: 57.1 -> 54.6 us per 32 x 1024 samples, same valid flags and error statistics, but 24 of 158 874
                               // models move by up to 7e-6 (ill-conditioned ones: the skipped step mattered) -- not adopted.
 #endif
+#ifndef DR_K3_PRECHECK_F64
+#define DR_K3_PRECHECK_F64 1   // 1: the residual pre-check also with the f64 stopping tolerance (train mode): with converged roots
+                               // most candidates are at rounding level already -- train step 0.2898 -> 0.2865 ms
+#endif
 #ifndef DR_K3_JAC2
 #define DR_K3_JAC2 1
 #endif
@@ -464,11 +468,11 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
   };
 #if DR_K3_PRECHECK
   // ---- (A') residual of every candidate as the root search left it; only those above the stopping tolerance queue for
-  // Gauss-Newton steps (the others are final: the same rule that ends the iteration after a step).  With the f64 tolerance
-  // (train mode) next to no candidate passes, so there everybody queues unseen.  Every queued candidate's residual norm is
+  // Gauss-Newton steps (the others are final: the same rule that ends the iteration after a step).  (DR_K3_PRECHECK_F64 = 0:
+  // with the f64 tolerance of train mode everybody queues unseen.)  Every queued candidate's residual norm is
   // (re)written by its steps, and (C) reads it back instead of evaluating the ten constraints a last time.
   int nlive = 0;
-  const bool precheck = tol2 > 1e-20;
+  const bool precheck = DR_K3_PRECHECK_F64 || tol2 > 1e-20;
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int e = base + lane;
