@@ -112,3 +112,32 @@ def test_sturm_separates_close_root_pairs_and_survives_degenerate_polynomials(de
     assert all(np.any(np.abs(got5 - r) < 1e-9) for r in (-1.5, 0.3, 1.5))
     got6 = _found(roots, counts, 6)                                   # the simple roots are found; the double root may or may not be
     assert np.any(np.abs(got6 + 0.7) < 1e-9) and np.any(np.abs(got6 - 1.8) < 1e-9) and np.all(np.isfinite(roots))
+
+
+def test_hip_isolation_counts_equal_the_cpu_restatement(dev):
+    """The kernel's Sturm isolation against its numpy restatement (oracle/sturm_ref.py) on the degree-10 polynomials of
+    RANSAC-like five-point samples: the same number of roots per half for (almost) every polynomial, and every root the kernel
+    returns lies in one of the restatement's isolating intervals."""
+    from differentiable_ransac_amd import ops, synth
+    from oracle import cpu_ref as O
+    from oracle import sturm_ref as S
+    rng = np.random.default_rng(12)
+    pairs = [synth.two_view_pair(700 + i, 400, inlier_ratio=0.5, noise=1e-3, dtype=torch.float64) for i in range(4)]
+    smp = torch.stack([pairs[i % 4]["matches"][rng.choice(400, 5, replace=False)] for i in range(2048)])
+    s = O.nister_poly_system(smp)
+    cs = s["cs"].numpy()[s["ok"].numpy()]
+    roots, counts = ops.debug_real_roots10(torch.from_numpy(cs).to(dev), 1)
+    roots, counts = roots.cpu().numpy(), counts.cpu().numpy()
+    inner, _ = S.isolate(cs)
+    outer, _ = S.isolate(cs[:, ::-1].copy())
+    differ = outside = total = 0
+    for i in range(cs.shape[0]):
+        for half, ivs in ((0, inner[i]), (1, outer[i])):
+            got = roots[i, half, : counts[i, half]]
+            w = got if half == 0 else 1.0 / got          # the search variable of the outer half is w = 1 / z
+            ivs = [iv for iv in ivs if half == 0 or iv[1] > -1 + 1e-12]
+            differ += len(w) != len(ivs)
+            for x in w:
+                total += 1
+                outside += not any(l - 1e-9 <= x <= h + 1e-9 for (l, h) in ivs)
+    assert total > 5000 and differ <= 2e-3 * 2 * cs.shape[0] + 1 and outside <= 1e-3 * total + 1, (differ, outside, total)
