@@ -833,8 +833,6 @@ def kernel_breakdown(w, rn, matches, logits, ops):
     out["K4_msac_masks"], (sc, mk) = t(lambda: ops.msac_score(matches, flat, thr, True, vflat))
     out["K4_msac_nomask"], _ = t(lambda: ops.msac_score(matches, flat, thr, False, vflat))
     out["K4_msac_masks_all_slots"], _ = t(lambda: ops.msac_score(matches, flat, thr, True))
-    if N % 16 == 0 and 16 <= N <= 2048:
-        out["K4_msac_masks_filter_kernel_path2"], _ = t(lambda: ops.msac_score(matches, flat, thr, True, vflat, path=2))
     out["valid_fraction"] = float(valid.float().mean())
     out["K6_select_best"], _ = t(lambda: ops.select_best(matches, flat, sc, thr, valid.reshape(P, -1)))
     return out

@@ -44,9 +44,8 @@
 // 200 us, with 64-slot tiles 247 us: the hardware's dynamic dispatch of 5 120 unequal blocks balances better than equal
 // static shares started in lock step (scratch/ab_k4nt.py); register budgets for 3 / 5 / 6 waves per SIMD instead of 4:
 // 233 / 221 / 343 us; 32- and 128-slot tiles at 128 pairs per launch: 793 / 757 against 692 us.  The matrix-core
-// candidate filter is csrc/msac_filter.hip.
+// candidate filter of round 2 (correct, slower: DESIGN 2b) is kept as scratch/k4_filter_kernel.patch.
 #include "dr_common.hpp"
-#include "msac_filter.hpp"
 
 namespace dr {
 
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
   const T inv_thr2 = T(1) / (t * t);
   const T *mt = matches + (size_t)p * N * 4;
   const T *md = models + ((size_t)p * M + m0) * 9;
-  const bool row_aligned = (N % 8) == 0;
+  const bool row_aligned = (N % 8) == 0 && (reinterpret_cast<uintptr_t>(masks) % 8) == 0;
 
   for (int i = tid; i < (kThreads / kWave) * kModelsPerBlock; i += kThreads) (&part[0][0])[i] = T(0);
   __syncthreads();
@@ -161,29 +160,17 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel(const T *__restric
 
 // ---- f32 fast path ---------------------------------------------------------------------------------------------
 // Same mapping as above, hand-shaped for the VALU (the binding unit at this shape):
-//  * points are processed in PAIRS so that the 19 FMAs per (model, point) become v_pk_fma_f32 (two lanes-worth of
+//  * points are processed in PAIRS so that the 16 FMAs per (model, point) become v_pk_fma_f32 (two lanes-worth of
 //    FMAs per issue; the model coefficient is an SGPR broadcast to both halves through op_sel);
 //  * the next model's nine coefficients are fetched through the scalar cache while the current one is evaluated;
-//  * non-finite models are detected on the scalar unit from the exponent bits (no VALU work);
-//  * the soft score is acc = fma(max(-s, 0), w, acc) with a per-point 0/1 weight (tail handling for free) and the
-//    mask byte is the sign bit of s, packed four at a time with v_perm_b32.
+//  * non-finite models are detected from the exponent bits, once per tile;
+//  * the soft-score term max(0, 1 - d2/thr2) comes out of ONE packed FMA with the clamp modifier and the mask byte is
+//    an exponent bit of that term, packed four at a time with v_perm_b32.
+// The variants measured and dropped in rounds 1-3 (non-temporal stores, LDS quad-sum reduction, contiguous zero-run fill,
+// real SGPR pairs, hand-placed scalar prefetch, per-half rendezvous, register budgets for 3 / 5 / 6 waves, 32- / 128-slot
+// tiles, ...) are kept as scratch/k4_dropped_variants.patch; their numbers are in profiles/r3_k4_counters_p128.md.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// Store policy of the mask rows.  Non-temporal stores, which help the LDS-assembled contiguous stream of msac_filter.hip
-// (130 against 207-222 us for the stream alone), LOSE here, where a wave store is a 1 KiB row piece: 226 against 208 us
-// (scratch/ab_k4nt.py) -- plain stores stay.
-#ifndef DR_K4_STORE
-#define DR_K4_STORE 0   // 0 plain, 1 nt
-#endif
-__device__ __forceinline__ void mask_row_store(uint8_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-  const u32x4 v = {a, b, c, d};
-#if DR_K4_STORE
-  __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
-#else
-  *reinterpret_cast<u32x4 *>(dst) = v;
-#endif
-}
 
 // 16-byte store at (wave-uniform 64-bit base) + (per-lane unsigned 32-bit offset): the SGPR-base form of global_store, so that
 // the vector ALU computes no address (hipcc otherwise forms base + row * N + n0 per lane with a quarter-rate v_mad_u64_u32)
@@ -198,46 +185,9 @@ __device__ __forceinline__ void mask_row_store_saddr(const uint8_t *base_uniform
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
-// 1: the soft-score term max(0, 1 - d2/thr2) comes out of ONE packed FMA with the clamp modifier (result clamped to [0, 1], NaN -> 0)
-// instead of fma + two v_min_i32: the same rounded values and the same inlier decisions (sign of the exact d2/thr2 - 1 either
-// way; masks and scores bit-identical on 164 M evaluations, scratch/k4_equal.py), scoring launch 0.644 -> 0.621 ms in the step.
-#ifndef DR_K4_CLAMP
-#define DR_K4_CLAMP 1
-#endif
+constexpr int kFastTile = 64;   // model slots per block in the f32 fast paths (two 32-bit validity words)
 
-// A/B knobs (scratch/ab_k4.py builds one shared object per variant)
-#ifndef DR_K4_VARIANT
-#define DR_K4_VARIANT 6
-#endif
-#if DR_K4_VARIANT == 0      // 128-slot tiles, zero rows first, 8-byte stores
-#define DR_K4_TILE 128
-#define DR_K4_ZERO 0
-#elif DR_K4_VARIANT == 1    // 128-slot tiles, zero rows first, 16-byte row stores spread over the waves
-#define DR_K4_TILE 128
-#define DR_K4_ZERO 1
-#elif DR_K4_VARIANT == 2    // 32-slot tiles
-#define DR_K4_TILE 32
-#define DR_K4_ZERO 0
-#elif DR_K4_VARIANT == 3    // 64-slot tiles
-#define DR_K4_TILE 64
-#define DR_K4_ZERO 0
-#elif DR_K4_VARIANT == 4    // zero rows after the evaluations
-#define DR_K4_TILE 128
-#define DR_K4_ZERO 2
-#elif DR_K4_VARIANT == 5    // 64-slot tiles, zero rows after
-#define DR_K4_TILE 64
-#define DR_K4_ZERO 2
-#elif DR_K4_VARIANT == 6    // 16 points per lane, 16-byte mask stores (N % 16 == 0), else as variant 5
-#define DR_K4_TILE 64
-#define DR_K4_ZERO 2
-#define DR_K4_FAST16 1
-#endif
-#ifndef DR_K4_FAST16
-#define DR_K4_FAST16 0
-#endif
-
-constexpr int kFastTile = DR_K4_TILE;   // model slots per block in the f32 fast path (32-bit validity words)
-
+// ---- f32, 8 points per lane (rows with N % 16 != 0) ---------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const float *__restrict__ matches,
                                                                        const float *__restrict__ models,
                                                                        const uint8_t *__restrict__ valid,
@@ -254,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
   const float inv_thr2 = 1.0f / (t * t);
   const float *mt = matches + (size_t)p * N * 4;
   const float *md = models + ((size_t)p * M + m0) * 9;
-  const bool row_aligned = (N % 8) == 0;
+  const bool row_aligned = (N % 8) == 0 && (reinterpret_cast<uintptr_t>(masks) % 8) == 0;
   for (int i = tid; i < (kThreads / kWave) * kFastTile; i += kThreads) (&part[0][0])[i] = 0.f;
   // Validity of the tile's slots as wave-uniform bit masks.  Slots the solver marked invalid (non-real roots: more than
   // half of the ten five-point slots) are never evaluated: the loop below walks the set bits only, so a block's work is
@@ -288,40 +238,6 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
     for (int j = 0; j < kPts; ++j) {
       if (j < nvalid) { if (j < 4) vlo |= 1u << (8 * j); else vhi |= 1u << (8 * (j - 4)); }
     }
-
-    auto zero_rows = [&]() {
-      // store-only pass: empty mask rows of the invalid slots.  When the whole row belongs to this block (one chunk) and
-    // rows are 16-byte aligned, each wave zero-fills every fourth invalid row with 16-byte stores (half the store
-    // instructions of the per-lane 8-byte layout, and the width the memory pipeline issues best)
-    if (write_masks) {
-      const bool wide = (DR_K4_ZERO == 1) && (N <= kChunk) && ((N & 15) == 0) && gridDim.y == 1;
-      int seen = 0;
-#pragma unroll
-      for (int wd = 0; wd < kFastTile / 32; ++wd) {
-        uint32_t inv = ~vword[wd];
-        if (32 * wd + 32 > mcount) inv &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
-        while (inv) {
-          const int ml = 32 * wd + __builtin_ctz(inv);
-          inv &= inv - 1;
-          uint8_t *row0 = masks + ((size_t)p * M + m0 + ml) * N;
-          if (wide) {
-            if ((seen & 3) == wv) {
-              for (int off = lane * 16; off < N; off += 64 * 16)
-                *reinterpret_cast<uint4 *>(row0 + off) = make_uint4(0u, 0u, 0u, 0u);
-            }
-          } else if (nvalid > 0) {
-            uint8_t *row = row0 + n0;
-            if (row_aligned && nvalid == kPts) *reinterpret_cast<uint2 *>(row) = make_uint2(0u, 0u);
-            else
-              for (int j = 0; j < nvalid; ++j) row[j] = 0;
-          }
-          ++seen;
-        }
-      }
-    }
-
-    };
-    if (DR_K4_ZERO != 2) zero_rows();
 
 #pragma unroll 1
     for (int wd = 0; wd < kFastTile / 32; ++wd) {
@@ -374,7 +290,9 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
           const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);   // s = d2/thr2 - 1
           sb[2 * j] = __float_as_uint(sv[0]);
           sb[2 * j + 1] = __float_as_uint(sv[1]);
-          v2f mn;   // min(sv, 0) by one integer instruction each (see msac_eval16); acc holds the negated sum
+          // min(sv, 0) by one integer instruction each: for IEEE bit patterns min_i32(bits(sv), 0) is sv when the sign bit is
+          // set and +0 otherwise (fmaxf costs two -- the compiler canonicalises its operand first); acc holds the negated sum
+          v2f mn;
           mn[0] = __int_as_float(min((int)sb[2 * j], 0));
           mn[1] = __int_as_float(min((int)sb[2 * j + 1], 0));
           acc = mn * w[j] + acc;
@@ -401,7 +319,22 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
         if (!more) break;
       }
     }
-    if (DR_K4_ZERO == 2) zero_rows();
+    // store-only pass after the evaluations: empty mask rows of the invalid slots
+    if (write_masks && nvalid > 0) {
+#pragma unroll
+      for (int wd = 0; wd < kFastTile / 32; ++wd) {
+        uint32_t inv = ~vword[wd];
+        if (32 * wd + 32 > mcount) inv &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
+        while (inv) {
+          const int ml = 32 * wd + __builtin_ctz(inv);
+          inv &= inv - 1;
+          uint8_t *row = masks + ((size_t)p * M + m0 + ml) * N + n0;
+          if (row_aligned && nvalid == kPts) *reinterpret_cast<uint2 *>(row) = make_uint2(0u, 0u);
+          else
+            for (int j = 0; j < nvalid; ++j) row[j] = 0;
+        }
+      }
+    }
   }
   __syncthreads();
   for (int i = tid; i < mcount; i += kThreads) {
@@ -412,176 +345,72 @@ __global__ __launch_bounds__(kThreads) void msac_score_kernel_f32_fast(const flo
   }
 }
 
-// Sixteen points of one lane against one model: mask bytes (uint4) + the lane's NEGATED soft-score partial.
-//   sv = d2/thr2 - 1 (inlier <=> sv < 0); the soft score max(-sv, 0) is accumulated as min(sv, 0) with ONE integer
-//   instruction per point: for IEEE bit patterns min_i32(bits(sv), 0) is sv when the sign bit is set and +0 otherwise
-//   (fmaxf costs two -- the compiler has to canonicalise its operand first); a 0/0 point (sv = +NaN) contributes 0.
-// DR_K4_SPAIR = 1: a model coefficient reaches the packed FMAs as a REAL SGPR pair (c, c) instead of one SGPR broadcast through
-// op_sel.  With the op_sel form the upper half of the aligned pair a `v_pk_fma_f32 ..., s[16:17] op_sel_hi:[1,0,0]` names is
-// undefined, the register allocator parks something else there -- in the shipped round-2 build the destination of the NEXT
-// model's `s_load_dword` -- and the wait-count pass, which sees a read of s17 with a scalar load to s17 in flight, puts
-// `s_waitcnt lgkmcnt(0)` right behind the prefetch: the "prefetch one model ahead" was a scalar-cache round trip per model,
-// in full, at the top of every iteration (ISA: profiles/r3_k4_isa_budget.md).  The empty asm makes both halves live.
-// Both measured in the step on one box, alternating libraries (scratch/r3_gpu_d.sh, r3_gpu_e.sh, r3_gpu_j.sh), and both OFF:
-//   pairs alone                                   0.602 / 0.610 ms against 0.601 / 0.605 ms (nothing: the wait stays where it was,
-//                                                 the SALU copies de-interleaving the loaded registers follow the load at once);
-//   pairs + request pinned at the top, wait at the end   0.623 / 0.628 ms against 0.601 / 0.602 ms;
-//   request pinned at the top, op_sel broadcasts (1)      0.650 / 0.651 ms against 0.603 / 0.603 ms;
-//   request placed by the scheduler (2: it sinks it behind most of the evaluation)   0.610 / 0.610 ms against 0.603 ms.
-// A REAL prefetch of the next model is 4-8 % SLOWER than the exposed scalar-cache round trip at the top of every iteration.
-// At four waves per SIMD the other three cover a parked wave, and the stall staggers the waves of a SIMD against each other
-// (without it they run their store / reduction phases in step).  The scalar fetch is not what this kernel waits for.
-// Round 3, measured in the step on one box, alternating libraries (scratch/r3_gpu_i.sh; scoring launch, two rounds):
-//   base 0.5977 / 0.5988 ms;  + v_bitop3 mask op 0.5962 / 0.5912 ms (kept);  + LDS quad-sum reduction 0.642 / 0.633 ms (7 % SLOWER:
-//   eleven fewer vector instructions per model, but 16 KB of LDS per workgroup, a masked ds_write per model in front of the next
-//   model's scalar-load wait, and the dense pass at the end of the tile; off).
-#ifndef DR_K4_BITOP3
-#define DR_K4_BITOP3 1
-#endif
-#ifndef DR_K4_TAILSYNC
-#define DR_K4_TAILSYNC 0   // 1: the halves of a workgroup finish independently (LDS rendezvous of a half's two waves instead of the
-                           // block barrier).  In the step: 0.6052 / 0.6064 ms against 0.6035 / 0.6029 ms with the barrier
-                           // (scratch/r3_gpu_p.sh) -- nothing to gain: off
-#endif
-#ifndef DR_K4_PRELOAD
-#define DR_K4_PRELOAD 1   // the block's first 16 point loads issued ahead of the model check: scoring launch 0.5941 / 0.5946 ms
-                          // against 0.5970 / 0.5977 ms in the step (scratch/r3_gpu_p.sh) -- kept
-#endif
-#ifndef DR_K4_LDSRED
-#define DR_K4_LDSRED 0   // 1: per-model score partials as quad sums in LDS, one dense reduction per tile (0: six DPP steps per model)
-#endif
-#ifndef DR_K4_SPAIR
-#define DR_K4_SPAIR 0
-#endif
-#ifndef DR_K4_ASMPREF
-#define DR_K4_ASMPREF 0   // the next model's scalar loads as inline asm, awaited at the end of the iteration (see the model loop)
-#endif
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ v2f sgpr_pair(float c) {
-#if DR_K4_SPAIR
-  const uint32_t b = __builtin_amdgcn_readfirstlane(__float_as_uint(c));
-  unsigned long long pr = ((unsigned long long)b << 32) | b;
-  asm("" : "+s"(pr));
-  v2f r;
-  __builtin_memcpy(&r, &pr, 8);
-  return r;
-#else
-  return splat(c);
-#endif
+// One point PAIR against one model: the soft-score terms max(0, 1 - d2/thr2) of both points by the clamp modifier of the
+// packed FMA ([0, 1]; NaN -> 0): inlier <=> term > 0 <=> bit 5 of its top byte (biased exponent 64..127) is set.
+// ms[q] = the model coefficient q in both halves (an SGPR broadcast through op_sel, or a VGPR pair).
+__device__ __forceinline__ v2f msac_pair_term(v2f x1, v2f y1, v2f x2, v2f y2, const v2f (&ms)[9], float inv_thr2) {
+  const v2f a0 = x2 * ms[0] + (y2 * ms[3] + ms[6]);
+  const v2f a1 = x2 * ms[1] + (y2 * ms[4] + ms[7]);
+  const v2f a2 = x2 * ms[2] + (y2 * ms[5] + ms[8]);
+  const v2f b0 = x1 * ms[0] + (y1 * ms[1] + ms[2]);
+  const v2f b1 = x1 * ms[3] + (y1 * ms[4] + ms[5]);
+  const v2f r = x1 * a0 + (y1 * a1 + a2);
+  const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
+  const v2f rr = r * r;
+  v2f rc;
+  rc[0] = __builtin_amdgcn_rcpf(jj[0]);
+  rc[1] = __builtin_amdgcn_rcpf(jj[1]);
+  const v2f pq = rr * rc;
+  const v2f one = splat(1.0f), ith = splat(inv_thr2);
+  v2f c;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(c) : "v"(pq), "v"(ith), "v"(one));
+  return c;
 }
 
+// four terms -> one dword of 0/1 mask bytes: top bytes gathered by v_perm_b32, (lo | hi) & 0x20202020 as ONE three-input
+// boolean op (v_bitop3_b32, truth table 0xA8), then the shift
+__device__ __forceinline__ uint32_t msac_mask_word(v2f c01, v2f c23) {
+  const uint32_t lo2 = __builtin_amdgcn_perm(__float_as_uint(c01[1]), __float_as_uint(c01[0]), 0x0c0c0703u);
+  const uint32_t hi2 = __builtin_amdgcn_perm(__float_as_uint(c23[1]), __float_as_uint(c23[0]), 0x07030c0cu);
+  uint32_t bits;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8" : "=v"(bits) : "v"(lo2), "v"(hi2), "s"(0x20202020u));
+  return bits >> 5;
+}
+
+// Sixteen points of one lane against one model: mask bytes (uint4) + the lane's NEGATED soft-score partial.
 __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)[8], const v2f (&x2)[8], const v2f (&y2)[8],
-                                            const v2f (&ms)[9], float inv_thr2, bool finite, v2f &nacc) {
-  uint32_t sb[16];
+                                            const v2f (&ms)[9], float inv_thr2, v2f &nacc) {
+  v2f c[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const v2f a0 = x2[j] * ms[0] + (y2[j] * ms[3] + ms[6]);
-    const v2f a1 = x2[j] * ms[1] + (y2[j] * ms[4] + ms[7]);
-    const v2f a2 = x2[j] * ms[2] + (y2[j] * ms[5] + ms[8]);
-    const v2f b0 = x1[j] * ms[0] + (y1[j] * ms[1] + ms[2]);
-    const v2f b1 = x1[j] * ms[3] + (y1[j] * ms[4] + ms[5]);
-    const v2f r = x1[j] * a0 + (y1[j] * a1 + a2);
-    const v2f jj = a0 * a0 + (a1 * a1 + (b0 * b0 + b1 * b1));
-    const v2f rr = r * r;
-    v2f rc;
-    rc[0] = __builtin_amdgcn_rcpf(jj[0]);
-    rc[1] = __builtin_amdgcn_rcpf(jj[1]);
-#if DR_K4_CLAMP
-    // the soft-score term max(0, 1 - d2/thr2) itself, by the clamp modifier of the packed FMA ([0, 1]; NaN -> 0): the same
-    // rounded value as -min(d2/thr2 - 1, 0), one instruction per point pair instead of three; inlier <=> term > 0 <=> bit 5 of
-    // its top byte (biased exponent 64..127) is set.  nacc holds the NEGATED sum, as in the other form.
-    const v2f pq = rr * rc;
-    const v2f one = splat(1.0f), ith = splat(inv_thr2);
-    v2f c;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(c) : "v"(pq), "v"(ith), "v"(one));
-    sb[2 * j] = __float_as_uint(c[0]);
-    sb[2 * j + 1] = __float_as_uint(c[1]);
-    nacc = nacc - c;
-#else
-    const v2f sv = (rr * rc) * splat(inv_thr2) - splat(1.0f);
-    sb[2 * j] = __float_as_uint(sv[0]);
-    sb[2 * j + 1] = __float_as_uint(sv[1]);
-    v2f mn;
-    mn[0] = __int_as_float(min((int)sb[2 * j], 0));
-    mn[1] = __int_as_float(min((int)sb[2 * j + 1], 0));
-    nacc = nacc + mn;
-#endif
+    c[j] = msac_pair_term(x1[j], y1[j], x2[j], y2[j], ms, inv_thr2);
+    nacc = nacc - c[j];
   }
-  uint32_t wq[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const uint32_t lo2 = __builtin_amdgcn_perm(sb[4 * g + 1], sb[4 * g], 0x0c0c0703u);
-    const uint32_t hi2 = __builtin_amdgcn_perm(sb[4 * g + 3], sb[4 * g + 2], 0x07030c0cu);
-#if DR_K4_BITOP3
-    // (lo2 | hi2) & 0x20202020 (0x80808080) as ONE three-input boolean op (v_bitop3_b32, truth table 0xA8), then the shift
-    uint32_t bits;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8" : "=v"(bits) : "v"(lo2), "v"(hi2), "s"(DR_K4_CLAMP ? 0x20202020u : 0x80808080u));
-    wq[g] = finite ? (bits >> (DR_K4_CLAMP ? 5 : 7)) : 0u;
-#else
-    wq[g] = finite ? (((lo2 | hi2) >> (DR_K4_CLAMP ? 5 : 7)) & 0x01010101u) : 0u;
-#endif
-  }
-  return make_uint4(wq[0], wq[1], wq[2], wq[3]);
+  return make_uint4(msac_mask_word(c[0], c[1]), msac_mask_word(c[2], c[3]), msac_mask_word(c[4], c[5]), msac_mask_word(c[6], c[7]));
 }
 
 // ---- f32 fast path, 16 points per lane ---------------------------------------------------------------------------
-// Same algorithm with a lane owning 16 consecutive points (64 VGPRs), 128-thread blocks (two waves cover 2048 points):
+// Same algorithm with a lane owning 16 consecutive points (64 VGPRs), 128-thread halves (two waves cover 2048 points):
 // every mask row segment is one 16-byte store per lane (1 KiB per wave instruction) -- the mask stream is store-ISSUE
 // bound with 8-byte stores.  Requires N % 16 == 0 (otherwise the 8-point kernel above is used).
-#ifndef DR_K4_ZERO_RUNS
-#define DR_K4_ZERO_RUNS 0   // 1: runs of invalid slots zero-filled as contiguous byte ranges.  Measured in the step, same box,
-                            // alternating libraries (scratch/r3_gpu_c.sh): scoring launch 0.621 / 0.627 ms against 0.606 / 0.606 ms
-                            // for the row pieces -- SLOWER (the sweep is a store-only phase at the end of the block; the row
-                            // pieces of an invalid slot cost no more than a valid row's store): kept as a knob, off
-#endif
-#ifndef DR_K4_SMALL
-#define DR_K4_SMALL 1   // 0: rows of <= 256 points take the general kernels too (A/B builds)
-#endif
-#ifndef DR_K4_TILE16
-#define DR_K4_TILE16 64   // model slots per block (multiple of 32)
-#endif
-// DR_K4_HALVES = 2: a 256-thread block is two independent 128-thread halves, each with its own 64-slot model tile (nothing
-// shared but the workgroup slot): a CU holds at most 8 workgroups, i.e. 16 waves of 128-thread blocks = 4 waves per SIMD
-#ifndef DR_K4_HALVES
-#define DR_K4_HALVES 2
-#endif
-constexpr int kH16 = 128, kT16 = kH16 * DR_K4_HALVES, kP16 = 16, kChunk16 = kH16 * kP16;
+// A 256-thread block is two independent 128-thread halves, each with its own 64-slot model tile (nothing shared but the
+// workgroup slot): a CU holds at most 8 workgroups, i.e. 16 waves of 128-thread blocks = 4 waves per SIMD.
+constexpr int kH16 = 128, kHalves = 2, kT16 = kH16 * kHalves, kP16 = 16, kChunk16 = kH16 * kP16;
 
-#ifndef DR_K4_SADDR
-#define DR_K4_SADDR 1   // mask rows stored through an SGPR base + 32-bit lane offset (in-step: scoring launch 0.610 -> 0.602 ms)
-#endif
-#ifndef DR_K4_PRECHECK
-#define DR_K4_PRECHECK 1   // 16-point kernel: the finite / non-zero test of a tile's models once per block (prologue)
-#endif
-#ifndef DR_K4_WAVES
-#define DR_K4_WAVES 0   // A/B knob: > 0 pins the register budget to that many waves per SIMD (amdgpu_waves_per_eu)
-#endif
-#if DR_K4_WAVES > 0
-#define DR_K4_OCC __attribute__((amdgpu_waves_per_eu(DR_K4_WAVES, DR_K4_WAVES)))
-#else
-#define DR_K4_OCC
-#endif
-__global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
+__global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
                                                                      const float *__restrict__ models,
                                                                      const uint8_t *__restrict__ valid,
                                                                      const float *__restrict__ thr, int M, int N,
                                                                      float *__restrict__ scores,
                                                                      uint8_t *__restrict__ masks, int write_masks,
                                                                      int chunks_per_block, int use_atomic) {
-  constexpr int kTile = DR_K4_TILE16;
+  constexpr int kTile = kFastTile;
   __shared__ float part[kT16 / kWave][kTile];
-#if DR_K4_LDSRED
-  // [wave][slot][quad]: the sixteen quad sums of a wave's (model, 1024 points) evaluation, written once per model (two DPP steps
-  // + one ds_write_b32 from every fourth lane) and reduced densely after the tile's last model: lane l adds the sixteen
-  // partials of slot l.  16 KB per workgroup; replaces four more DPP steps, two moves and an LDS atomic per model.
-  __shared__ __align__(16) float part16[kT16 / kWave][kTile][16];
-  static_assert(kTile == 64, "the dense reduction maps lane l to slot l of the tile");
-#endif
   const int p = blockIdx.z;
   // wave-uniform BY CONSTRUCTION (a half is two whole waves) -- and it must look so to the compiler: with `half` in a VGPR the
   // tile's model coefficients stop being scalar loads and the kernel is 40 % slower
-  const int half = DR_K4_HALVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kH16)) : 0;
-  const int m0 = (blockIdx.x * DR_K4_HALVES + half) * kTile;
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kH16));
+  const int m0 = (blockIdx.x * kHalves + half) * kTile;
   const int tid = threadIdx.x % kH16, lane = tid & 63, wv = threadIdx.x >> 6;
   const int mcount = max(0, min(kTile, M - m0));
   const float t = 1.5f * thr[p];
@@ -589,12 +418,6 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
   const float *mt = matches + (size_t)p * N * 4;
   const float *md = models + ((size_t)p * M + m0) * 9;
   for (int i = threadIdx.x; i < (kT16 / kWave) * kTile; i += kT16) (&part[0][0])[i] = 0.f;
-#if DR_K4_TAILSYNC
-  __shared__ int s_done[DR_K4_HALVES > 1 ? DR_K4_HALVES : 1];
-  if (threadIdx.x < DR_K4_HALVES) s_done[threadIdx.x] = 0;
-#endif
-  uint32_t vword[kTile / 32];
-#if DR_K4_PRELOAD
   // the first chunk's points are requested BEFORE the model check: its strided model reads, the ballots and the block barrier
   // then run under the latency of the sixteen point loads instead of in front of it
   v2f x1[kP16 / 2], y1[kP16 / 2], x2[kP16 / 2], y2[kP16 / 2];
@@ -608,17 +431,13 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
       x1[j / 2][j & 1] = v.x; y1[j / 2][j & 1] = v.y; x2[j / 2][j & 1] = v.z; y2[j / 2][j & 1] = v.w;
     }
   }
-#endif
-#if DR_K4_PRECHECK
   // non-finite / all-zero models of the tile are found here, once (lane l looks at slot l), instead of in every wave of
   // every chunk: they leave the evaluated set (empty mask row like an invalid slot) and their score is NaN
-  uint32_t nanword[kTile / 32];
-#endif
+  uint32_t vword[kTile / 32], nanword[kTile / 32];
 #pragma unroll
   for (int w = 0; w < kTile / 32; ++w) {
     const int ml = 32 * w + (lane & 31);
     const bool v = (ml < mcount) && (!valid || valid[(size_t)p * M + m0 + ml] != 0);
-#if DR_K4_PRECHECK
     uint32_t ex = 0, anybit = 0;
     if (v) {
 #pragma unroll
@@ -631,30 +450,20 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
     const bool bad = v && (ex == 0x7f800000u || anybit == 0u);
     vword[w] = (uint32_t)(__ballot(v && !bad && lane < 32));
     nanword[w] = (uint32_t)(__ballot(bad && lane < 32));
-#else
-    vword[w] = (uint32_t)(__ballot(v && lane < 32));
-#endif
   }
   __syncthreads();
-#if DR_K4_PRECHECK
   if ((wv & 1) == 0 && lane < 32) {
 #pragma unroll
     for (int w = 0; w < kTile / 32; ++w)
       if ((nanword[w] >> lane) & 1u) part[wv][32 * w + lane] = NAN;
   }
-#endif
 
   const int c_begin = blockIdx.y * chunks_per_block;
   for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
     if (c * kChunk16 >= N) break;
     const int n0 = c * kChunk16 + tid * kP16;
     const bool have = n0 < N;   // N % 16 == 0: a lane's 16 points are all inside or all outside
-#if DR_K4_PRELOAD
-    if (c != c_begin)
-#else
-    v2f x1[kP16 / 2], y1[kP16 / 2], x2[kP16 / 2], y2[kP16 / 2];
-#endif
-    {
+    if (c != c_begin) {
 #pragma unroll
       for (int j = 0; j < kP16; ++j) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -670,139 +479,32 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
       int ml = 32 * wd + __builtin_ctz(live);
       live &= live - 1;
       float mc[9];
-#if DR_K4_ASMPREF
-      {   // the first model of the word through the same path as the others (one kind of value in the loop-carried registers)
-        u32x8 f8;
-        uint32_t f1;
-        const float *src = md + ml * 9;
-        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(f8), "=&s"(f1) : "s"(src));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) mc[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(f8[q]));
-        mc[8] = __uint_as_float(__builtin_amdgcn_readfirstlane(f1));
-      }
-#else
 #pragma unroll
       for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
-#endif
       while (true) {
-        float m[9];
         v2f ms[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { m[q] = mc[q]; ms[q] = sgpr_pair(mc[q]); }
+        for (int q = 0; q < 9; ++q) ms[q] = splat(mc[q]);
         const int cur = ml;
         const bool more = live != 0;
-#if DR_K4_ASMPREF
-        // The next model's nine coefficients, requested NOW and awaited at the END of this iteration.  Written as the two
-        // scalar loads themselves: the compiler's own loads are followed at once by the SALU copies that de-interleave them
-        // (and so by `s_waitcnt lgkmcnt(0)`), whatever the source order.  The matching wait below takes the results as
-        // in/out operands, so nothing that reads them can move above it.  Issued in EVERY iteration (the last one re-reads
-        // its own model): a conditional request makes the results a phi of inline-asm values, which the compiler treats
-        // as divergent and keeps in VGPRs.
-        if (more) {
-          ml = 32 * wd + __builtin_ctz(live);
-          live &= live - 1;
-        }
-        u32x8 nx8;
-        uint32_t nx1;
-        {
-          const float *src = md + ml * 9;
-          asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(nx8), "=&s"(nx1) : "s"(src));
-        }
-#if DR_K4_ASMPREF != 2
-        __builtin_amdgcn_sched_barrier(0);   // the request stays HERE, ahead of the evaluation (2: left to the scheduler)
-#endif
-#else
-        if (more) {
+        if (more) {   // the next valid model through the scalar cache
           ml = 32 * wd + __builtin_ctz(live);
           live &= live - 1;
 #pragma unroll
           for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
         }
-#endif
-#if DR_K4_PRECHECK
-        constexpr bool finite = true;   // the others never get here (prologue)
-#else
-        uint32_t ex = 0, anybit = 0;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const uint32_t mb = __builtin_amdgcn_readfirstlane(__float_as_uint(m[q]));
-          ex = max(ex, mb & 0x7f800000u);
-          anybit |= mb & 0x7fffffffu;
-        }
-        // an all-zero model is treated like a non-finite one (score NaN, empty mask): the reference's 0/0 gives NaN
-        // scores and `NaN < thr` = False masks (msac_score.py:42-48)
-        const bool finite = ex != 0x7f800000u && anybit != 0u;
-#endif
         v2f nacc = splat(0.f);
-        const uint4 q = msac_eval16(x1, y1, x2, y2, ms, inv_thr2, finite, nacc);
+        const uint4 q = msac_eval16(x1, y1, x2, y2, ms, inv_thr2, nacc);
         float a = have ? -(nacc[0] + nacc[1]) : 0.f;
-#if DR_K4_SADDR
         // row base = wave-uniform 64-bit address (scalar ALU), lane part = unsigned 32-bit offset: the store takes the SGPR-base form
         // and the vector ALU computes no address at all (the 64-bit multiply-add per store was a quarter-rate instruction)
         if (write_masks && have) mask_row_store_saddr(masks + ((size_t)p * M + m0 + cur) * N, (uint32_t)n0, q.x, q.y, q.z, q.w);
-#else
-        if (write_masks && have) mask_row_store(masks + ((size_t)p * M + m0 + cur) * N + n0, q.x, q.y, q.z, q.w);
-#endif
-#if DR_K4_LDSRED
-        a += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-        a += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-        if ((lane & 3) == 0) part16[wv][cur][lane >> 2] = a;
-#else
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
-        // (row sums + four adding lanes instead of the two row_bcast steps: no gain in the step, 0.606 vs 0.609 ms)
-        if (lane == 63) atomicAdd(&part[wv][cur], finite ? a : NAN);   // ds_add_f32, no return: nothing to wait for (-2 %)
-#endif
-#if DR_K4_ASMPREF
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nx8), "+s"(nx1));   // (also before leaving: the request must not outlive its registers)
-#endif
+        if (lane == 63) atomicAdd(&part[wv][cur], a);   // ds_add_f32, no return: nothing to wait for (-2 %)
         if (!more) break;
-#if DR_K4_ASMPREF
-#pragma unroll
-        // (readfirstlane: inline-asm results count as divergent -- without it the whole loop-carried model moves to VGPRs,
-        //  the first fetch becomes a vector load and every iteration starts with `s_waitcnt vmcnt(0)`, i.e. waits for the
-        //  previous mask store: 0.69 instead of 0.60 ms per launch.  On an SGPR the intrinsic is a plain copy.)
-        for (int q = 0; q < 8; ++q) mc[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(nx8[q]));
-        mc[8] = __uint_as_float(__builtin_amdgcn_readfirstlane(nx1));
-#endif
       }
     }
-#if DR_K4_LDSRED
-    {   // dense reduction of this chunk's quad sums: lane l <-> slot l of the tile (evaluated slots only: the others hold stale data)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      const bool mine = (vword[lane >> 5] >> (lane & 31)) & 1u;
-      if (mine) {
-        const float4 *src = reinterpret_cast<const float4 *>(&part16[wv][lane][0]);
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-        part[wv][lane] += ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) + (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-#endif
     // empty mask rows of the invalid slots (store-only)
-#if DR_K4_ZERO_RUNS
-    // The five-point solvers fill a sample's ten slots from both ends (|z| <= 1 roots upwards from slot 0, |z| > 1 roots
-    // downwards from slot 9), so the invalid slots of a sample are ONE run in the middle: 5.5 rows = 11 KB on average at the
-    // benchmark shape.  With the whole row inside this block's chunk (N <= 2048) a run of R rows is the contiguous byte range
-    // [r0 N, (r0 + R) N) of the output: the half-block's 128 lanes sweep it 2 KiB per step (whole 128-byte lines except at the
-    // two ends) instead of writing R row pieces of 1024 + 976 bytes per wave.
-    if (write_masks && gridDim.y == 1 && N <= kChunk16) {
-      static_assert(kTile == 64, "the run walk below reads the tile's validity as one 64-bit word");
-      unsigned long long inv = ~(((unsigned long long)vword[1] << 32) | vword[0]);
-      if (mcount < 64) inv &= (mcount > 0) ? ((1ull << mcount) - 1ull) : 0ull;
-      uint8_t *tile_base = masks + ((size_t)p * M + m0) * N;
-      while (inv) {
-        const int r0 = __builtin_ctzll(inv);
-        const unsigned long long rest = ~(inv >> r0);
-        const int len = rest ? __builtin_ctzll(rest) : 64 - r0;
-        inv &= ~((((len < 64) ? (1ull << len) : 0ull) - 1ull) << r0);
-        const uint32_t nbytes = (uint32_t)len * (uint32_t)N;
-        const uint8_t *run = tile_base + (size_t)r0 * N;      // wave-uniform
-        for (uint32_t off = (uint32_t)tid * 16u; off < nbytes; off += (uint32_t)kH16 * 16u)
-          mask_row_store_saddr(run, off, 0u, 0u, 0u, 0u);
-      }
-    } else
-#endif
     if (write_masks && have) {
 #pragma unroll
       for (int wd = 0; wd < kTile / 32; ++wd) {
@@ -811,33 +513,11 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
         while (inv) {
           const int ml = 32 * wd + __builtin_ctz(inv);
           inv &= inv - 1;
-#if DR_K4_SADDR
           mask_row_store_saddr(masks + ((size_t)p * M + m0 + ml) * N, (uint32_t)n0, 0u, 0u, 0u, 0u);
-#else
-          mask_row_store(masks + ((size_t)p * M + m0 + ml) * N + n0, 0u, 0u, 0u, 0u);
-#endif
         }
       }
     }
   }
-#if DR_K4_TAILSYNC
-  // No block barrier at the end: the two halves of a workgroup own different tiles with different numbers of valid slots, and a
-  // block-wide barrier makes the faster half's two waves sit on their registers until the slower half is done.  The two waves
-  // of a HALF rendezvous through an LDS counter instead; whichever arrives second adds the two partials and stores the scores.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's partial sums are in LDS before it arrives
-  int arrived = 0;
-  if (lane == 0) arrived = atomicAdd(&s_done[half], 1);
-  arrived = __builtin_amdgcn_readfirstlane(arrived);
-  if (arrived == 1) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = lane; i < mcount; i += kWave) {
-      const float v = part[2 * half][i] + part[2 * half + 1][i];
-      float *dst = scores + (size_t)p * M + m0 + i;
-      if (use_atomic) atomicAdd(dst, v);
-      else *dst = v;
-    }
-  }
-#else
   __syncthreads();
   for (int i = tid; i < mcount; i += kH16) {
     const float v = part[2 * half][i] + part[2 * half + 1][i];
@@ -845,7 +525,6 @@ __global__ __launch_bounds__(kT16) DR_K4_OCC void msac_score_kernel_f32_fast16(c
     if (use_atomic) atomicAdd(dst, v);
     else *dst = v;
   }
-#endif
 }
 
 // ---- f32, short rows (N <= 256): a WAVE per model ------------------------------------------------------------------------
@@ -878,7 +557,8 @@ __global__ __launch_bounds__(kSmallWaves * 64) void msac_score_kernel_f32_small(
     if (j < nvalid) v = mt[n0 + j];
     x1[j] = v.x; y1[j] = v.y; x2[j] = v.z; y2[j] = v.w;
   }
-  const bool row_word = (N % kPtsS) == 0;   // every lane's segment is whole and its row offset naturally aligned
+  // every lane's segment is whole and its row offset naturally aligned (the base pointer too: a caller may pass a slice)
+  const bool row_word = (N % kPtsS) == 0 && (reinterpret_cast<uintptr_t>(masks) % kPtsS) == 0;
 #pragma unroll 1
   for (int r = 0; r < kSmallPerWave; ++r) {
     const int m = blockIdx.x * kSmallTile + r * kSmallWaves + wv;   // wave-uniform
@@ -1143,19 +823,12 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
   for (int n = threadIdx.x; n < N; n += blockDim.x) best_mask[(size_t)p * N + n] = 0;
 }
 
-// path: 0 = choose (the matrix-core filter kernel of msac_filter.hip when the shape allows and fills the chip, else the
-// general kernels here), 1 = general kernels, 2 = filter kernel (the caller has checked msac_filter_supported)
 template <typename T>
 int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, const T *thr, int P, int M, int N,
-                      T *scores, uint8_t *masks, hipStream_t st, int path = 0) {
+                      T *scores, uint8_t *masks, hipStream_t st) {
   constexpr bool kFast = sizeof(T) == 4;
   if constexpr (kFast) {
-    if (path == 2 || (path == 0 && msac_filter_supported(N) && msac_filter_profitable(P, M, N)))
-      return msac_filter_launch((const float *)matches, (const float *)models, valid, (const float *)thr, P, M, N,
-                                (float *)scores, masks, st);
-  }
-  if constexpr (kFast) {
-    if (DR_K4_SMALL && N <= kSmallMaxN) {   // short rows: a wave per model (BASELINE configs[0])
+    if (N <= kSmallMaxN) {   // short rows: a wave per model (BASELINE configs[0])
       const dim3 g((M + kSmallTile - 1) / kSmallTile, 1, P), b(kSmallWaves * 64);
       const float *mt = (const float *)matches, *md = (const float *)models, *th = (const float *)thr;
       if (N <= 64) hipLaunchKernelGGL(msac_score_kernel_f32_small<1>, g, b, 0, st, mt, md, valid, th, M, N, (float *)scores, masks);
@@ -1164,8 +837,9 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
       return check_launch("msac_score_kernel_f32_small");
     }
   }
-  const bool fast16 = kFast && DR_K4_FAST16 && (N % 16 == 0);
-  const int tile = fast16 ? DR_K4_TILE16 * DR_K4_HALVES : (kFast ? kFastTile : kModelsPerBlock);
+  // (16-byte mask stores: whole rows and a 16-byte aligned base -- a caller may pass a slice of a larger buffer)
+  const bool fast16 = kFast && (N % 16 == 0) && (reinterpret_cast<uintptr_t>(masks) % 16 == 0);
+  const int tile = fast16 ? kFastTile * kHalves : (kFast ? kFastTile : kModelsPerBlock);
   const int tiles = (M + tile - 1) / tile;
   const int chunks = (N + kChunk - 1) / kChunk;   // kChunk16 == kChunk
   // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip
@@ -1215,9 +889,9 @@ int dr_msac_score_path_f32(const float *matches, const float *models, const uint
                            int M, int N, float *scores, uint8_t *masks, int path, void *stream) {
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   DR_REQUIRE(matches && models && thr && scores, "null pointer");
-  DR_REQUIRE(path >= 0 && path <= 2, "path must be 0 (auto), 1 (general kernels) or 2 (filter kernel)");
-  DR_REQUIRE(path != 2 || dr::msac_filter_supported(N), "the filter kernel needs N % 16 == 0 and 16 <= N <= 2048");
-  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream, path);
+  DR_REQUIRE(path == 0 || path == 1, "path must be 0 or 1 (the general kernels); path 2, the matrix-core candidate filter of "
+                                     "round 2, was measured slower and left the library (scratch/k4_filter_kernel.patch)");
+  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
 }
 
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,

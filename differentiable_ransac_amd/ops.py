@@ -26,8 +26,8 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
                valid: Optional[torch.Tensor] = None, path: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None.
     valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row).
-    path (f32 only): 0 = 1 = the general kernels (the default never picks the filter kernel: it is slower),
-    2 = matrix-core candidate filter kernel, opt-in only (include/dransac.h: dr_msac_score_path_f32)."""
+    path (f32 only): 0 = 1 = the general kernels; 2 (the matrix-core candidate filter of round 2, measured slower: DESIGN 2b)
+    left the library in round 4 and is refused (include/dransac.h: dr_msac_score_path_f32)."""
     P, N, _ = matches.shape
     M = models.shape[1]
     matches = matches.contiguous()

@@ -209,14 +209,11 @@ int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *
                       int M, int N, float *scores, uint8_t *masks, void *stream);
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,
                       int M, int N, double *scores, uint8_t *masks, void *stream);
-/* The same operation with the kernel family named explicitly (dr_msac_score_f32 = path 0):
- *   path 0  what dr_msac_score_f32 runs: the general kernels (path 1) for every shape -- the filter kernel is never chosen
- *           automatically (measured slower), it is opt-in through path 2;
- *   path 1  general kernels: every (model, point) through the f32 fma chain on the vector units (any N; rows of <= 256
- *           points: a wave per model with 1 / 2 / 4 points per lane, longer rows: a lane owns 8 / 16 points);
- *   path 2  matrix-core candidate filter + the same f32 chain for the candidates + LDS-assembled, line-aligned
- *           mask stream; needs N % 16 == 0 and 16 <= N <= 2048, else DR_EINVAL.  Masks are bit-identical to path 1;
- *           scores are accumulated in 64-bit fixed point (order-independent) and agree with path 1 to f32 rounding. */
+/* The same operation with the kernel family named explicitly (kept for ABI stability):
+ *   path 0 = path 1 = what dr_msac_score_f32 runs: every (model, point) through the f32 fma chain on the vector units (any N;
+ *           rows of <= 256 points: a wave per model with 1 / 2 / 4 points per lane, longer rows: a lane owns 8 / 16 points);
+ *   path 2  (round 2: matrix-core candidate filter + exact evaluation of the candidates; bit-identical masks, measured slower,
+ *           DESIGN.md section 2b) left the library in round 4 (scratch/k4_filter_kernel.patch): DR_EINVAL. */
 int dr_msac_score_path_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
                            int M, int N, float *scores, uint8_t *masks, int path, void *stream);
 /* dL/dmodels [P,M,9] from dL/dscores [P,M] (flows only through points with d2 < thr2). */

@@ -12,8 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the counters belong to the kernels as compiled from these files: bench.py re-hashes them and drops the traffic figure
 # when they have changed since the capture
-KERNEL_SOURCES = ["differentiable_ransac_amd/csrc/msac_score.hip", "differentiable_ransac_amd/csrc/msac_filter.hip",
-                  "differentiable_ransac_amd/csrc/dr_common.hpp"]
+KERNEL_SOURCES = ["differentiable_ransac_amd/csrc/msac_score.hip", "differentiable_ransac_amd/csrc/dr_common.hpp"]
 
 
 def main():
