@@ -305,9 +305,9 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
         del gstep
         # launch-bound steps (config 1: 0.05 ms of device time in six launches) gain from the replay, device-bound ones lose a
         # few per cent to the graph's inter-node barriers.  The sub-record always carries BOTH figures, labelled; which one
-        # `ms_per_step` quotes is fixed per config (not the minimum of the two): the replay for the launch-bound c1, the eager
-        # issue for the device-bound others
-        if key == "c1":
+        # `ms_per_step` quotes is fixed per config (not the minimum of the two): the replay for the launch-bound c1 and for
+        # one-pair calls, the eager issue for the device-bound others
+        if key == "c1" or w["pairs"] == 1:
             seg_ms, issue = graph_ms, "HIP graph replay of the whole step (differentiable_ransac_amd.graphs.GraphedStep)"
     el, steps = sorted(seg_ms)[1] * 1e-3 * seg, seg
     calls = per_call_breakdown(step)
@@ -329,6 +329,119 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
                                    "algorithmic_bytes_per_launch": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
     return rec
+
+
+def _median3_ms(fn, seg):
+    out = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run_bounded(lambda i: fn() and None, seg)
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / seg * 1e3)
+    return sorted(out)[1], out
+
+
+def train_record(dev, steps=150, pairs=32):
+    """BASELINE configs[4]'s per-GPU share as a sub-record of the default line: the train step (sampler -> solver -> best-of-10
+    vs GT -> MatchLoss -> backward to the logits) on 32 pairs x 2000 points x 1024 hypotheses, eager and replayed as one HIP
+    graph, with the device time of every libdransac launch of the eager step (forward and backward entries)."""
+    from differentiable_ransac_amd.graphs import GraphedStep
+    w = dict(WORKLOADS["c2"], pairs=pairs)
+    step, _ = make_step(w, dev, mode="train")
+    for _ in range(20):
+        out = step()
+    torch.cuda.synchronize()
+    eager_ms, eager_all = _median3_ms(step, steps)
+    calls = per_call_breakdown(step)
+    gstep = GraphedStep(make_step(w, dev, mode="train", device_seeds=True)[0])
+    for _ in range(5):
+        gout = gstep()
+    torch.cuda.synchronize()
+    graph_ms, graph_all = _median3_ms(gstep, steps)
+    B = w["hyps"]
+    return {"baseline_config_index": 4,
+            "workload": f"nister train step (sample, solve, best-of-10 vs GT, MatchLoss, backward to the logits), {w['points']} pts x "
+                        f"{B} hyps per pair, {pairs} pairs = one GPU's share of 256 pairs over 8 GPUs (no collective at N = 1)",
+            "issue": "HIP graph replay of forward + loss + backward (one launch per step)",
+            "steps": steps, "ms_per_step": graph_ms, "hypotheses_per_s": pairs * B / (graph_ms * 1e-3),
+            "pairs_per_s": pairs / (graph_ms * 1e-3), "graph_replay_segments_ms": [round(x, 5) for x in graph_all],
+            "eager_ms_per_step": eager_ms, "eager_segments_ms": [round(x, 5) for x in eager_all],
+            "launch_ms": {k: round(v, 5) for k, v in sorted(calls.items(), key=lambda kv: -kv[1])},
+            "device_ms_sum_of_launches": sum(calls.values()),
+            "grad_finite": bool(torch.isfinite(out["grad"]).all() and torch.isfinite(gout["grad"]).all())}
+
+
+def fused_driver_record(dev, steps=100):
+    """The driver as a user runs it: BatchedRANSAC's default keep_masks=False -- scores + ONE best mask per pair, no [M,N] mask
+    tensor.  Its own byte accounting (16N + 40M + N per pair), never mixed with the masks-on accounting of the
+    headline; the scoring launch is priced against BOTH roofs."""
+    w = dict(WORKLOADS["c2"])
+    step, info = make_step(w, dev, keep_masks=False)
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    ms, all_ms = _median3_ms(step, steps)
+    calls = per_call_breakdown(step)
+    P, N, B = w["pairs"], w["points"], w["hyps"]
+    M = B * info["S"]
+    with torch.no_grad():
+        _, v_, _ = info["rn"].hypotheses(info["matches"], info["logits"])
+    vf = float(v_.float().mean())
+    k4 = calls.get("dr_msac_score_f32")
+    nbytes = P * (16 * N + 40 * M + N)
+    rec = {"workload": f"{w['text'].replace(' with masks', '')}, keep_masks=False (scores + one best mask per pair), {P} pairs per step",
+           "steps": steps, "ms_per_step": ms, "segments_ms_per_step": [round(x, 5) for x in all_ms],
+           "hypotheses_per_s": P * B / (ms * 1e-3), "pairs_per_s": P / (ms * 1e-3),
+           "launch_ms": {k: round(v, 5) for k, v in sorted(calls.items(), key=lambda kv: -kv[1])}}
+    if k4:
+        fl = 39.0 * P * M * N * vf
+        rec["scoring_roofline"] = {"bound": "valu_f32", "launch": "dr_msac_score_f32 (masks == NULL)", "avg_launch_ms": k4,
+                                   "algorithmic_bytes_per_launch": nbytes, "bytes_formula": "P (16 N + 40 M + N)",
+                                   "hbm_achieved_GBs": nbytes / (k4 * 1e-3) / 1e9, "hbm_frac": nbytes / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "valid_slot_fraction": vf, "valu_tflops": fl / (k4 * 1e-3) / 1e12,
+                                   "valu_frac_of_157.3": fl / (k4 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                   "note": "without the mask stream the launch moves 0.5 MB per pair: the HBM roof is irrelevant, "
+                                           "the f32 vector ALU is the only roof (39 flop per evaluated (model, point))"}
+    return rec
+
+
+def k4_all_valid_record(dev, launches=30):
+    """The scoring kernel's intrinsic rate: the headline shape with EVERY slot evaluated (valid == NULL: the identity fillers of
+    the non-real roots are scored like any model), next to the same launch with the solver's validity flags.  The headline's
+    roofline fraction counts the mask bytes of skipped slots too (55 % of the rows are zero rows at this workload)."""
+    from differentiable_ransac_amd import ops
+    w = dict(WORKLOADS["c2"])
+    _, info = make_step(w, dev)
+    P, N, B = w["pairs"], w["points"], w["hyps"]
+    with torch.no_grad():
+        models, valid, _ = info["rn"].hypotheses(info["matches"], info["logits"])
+    flat = models.reshape(P, -1, 3, 3).contiguous()
+    vflat = valid.reshape(P, -1).contiguous()
+    thr = torch.full((P,), 7.5e-4, device=dev)
+    M = flat.shape[1]
+    nbytes = k4_bytes(P, N, M)
+
+    def t(v):
+        for _ in range(5):
+            ops.msac_score(info["matches"], flat, thr, True, v)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for a, b in ev:
+            a.record()
+            ops.msac_score(info["matches"], flat, thr, True, v)
+            b.record()
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in ev)[launches // 2]
+    ms_all, ms_flag = t(None), t(vflat)
+    vf = float(vflat.float().mean())
+    out = {}
+    for key, ms, frac_eval in (("all_slots_valid", ms_all, 1.0), ("solver_validity_flags", ms_flag, vf)):
+        fl = 39.0 * P * M * N * frac_eval
+        out[key] = {"avg_launch_ms": ms, "evaluated_slot_fraction": frac_eval, "algorithmic_bytes_per_launch": nbytes,
+                    "hbm_achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "valu_tflops": fl / (ms * 1e-3) / 1e12, "valu_frac_of_157.3": fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+    out["workload"] = f"scoring launch alone, {P} pairs x {M} slots x {N} points, masks on, median of {launches} launches (HIP events)"
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -745,7 +858,12 @@ def main():
                    "issue": f"{len(streams)} batch(es) in flight, round-robin over {len(streams)} HIP stream(s), "
                             + ("HIP graph replay" if use_graph else "eager launches (HIP events around the scoring launch)")},
         "pairs_per_s": (1 if split_h else world) * P * args.steps / elapsed,
-        "roofline": {"bound": "hbm", "kernel": kernel_name, "valid_slot_fraction": valid_frac, "achieved": achieved,
+        "roofline": {"bound": "hbm", "binding_unit": None if rigid else "valu_f32",
+                     "bound_note": ("`bound` names the roof `frac` is priced against (BASELINE's target is stated against HBM: the mask "
+                                    "stream is the launch's only large transfer); the unit that saturates first is the f32 vector ALU "
+                                    "(`binding_unit`, `what_bounds_it`, `valu_frac_of_157.3`): 38 flop/B against a machine balance of "
+                                    "19.7.  `k4_all_valid` is the same launch with every slot evaluated"),
+                     "kernel": kernel_name, "valid_slot_fraction": valid_frac, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "segments_avg_launch_ms": [round(x, 5) for x in seg_k4],
@@ -774,6 +892,12 @@ def main():
         result["configs"] = {k: config_record(k, dev, n_cfg[k], 5, graph=g_) for k in sorted(WORKLOADS) if k != args.workload}
         if args.workload == "c2" and P != 32:
             result["configs"]["c2_p32"] = config_record("c2", dev, 300, 5, pairs=32, graph=g_)   # round 1's batch size
+        if args.workload == "c2":
+            # SURVEY's literal C2: ONE pair per call (test.py:38, model_cl.py:488-490), eager and replayed as one graph
+            result["configs"]["c2_p1"] = config_record("c2", dev, 600, 5, pairs=1, graph=True)
+            result["configs"]["c5_train_p32"] = train_record(dev)
+            result["fused_driver"] = fused_driver_record(dev)
+            result["k4_all_valid"] = k4_all_valid_record(dev)
         if not args.logits_fixture and os.path.exists(os.path.join(ROOT, "tests", "golden", "clnet_logits.npz")):
             # the c2 workload on reader-produced pairs with the reference network's scores instead of synthetic logits
             fstep, finfo = make_step(dict(WORKLOADS["c2"], pairs=32), dev, fixture=True)

@@ -792,7 +792,11 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
   // exponential and its scale of the general form (y = exp((l + G) - lse)) are gone; per row and thread one exponential.
   // lref = the thread's largest logit: lref - lse <= -G <= 3.2, no overflow; rows far above the thread's points flush to 0.
   const bool race = sizeof(T) == 4 && !a.gumbel && unit_tau;
-  const float lref = fmaxf(fmaxf((float)l[0], (float)l[1]), fmaxf((float)l[2], (float)l[3]));
+  // (over the group's REAL points only: the padding value 0 of a tail group with N % 4 != 0 and logits far below zero would put
+  //  lref above the row's lse by more than the bound and overflow the exponential -- round-3 advice)
+  float lref = (float)l[0];   // 4 q < N for every thread that accumulates (q < groups)
+#pragma unroll
+  for (int j = 1; j < 4; ++j) lref = (4 * q + j < a.N) ? fmaxf(lref, (float)l[j]) : lref;
   float racc[4] = {0.f, 0.f, 0.f, 0.f};
 #endif
   for (int b0 = b_lo; b0 < b_hi; b0 += 256) {

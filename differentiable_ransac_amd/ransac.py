@@ -149,6 +149,7 @@ class RANSAC(object):
 
     def __call__(self, matches, logits, K1, K2, gt_model, gumbels=None):
         """`gumbels` (optional, list of [B,N] tensors, one per batch) replaces the in-kernel noise: parity runs."""
+        self._soft0 = None       # the weighted refit only ever uses soft weights drawn in THIS call
         solver = self._fused_solver() if self.fused else None
         if solver is not None and matches.is_cuda:
             cfg = (solver, self.ransac_batch_size, self.threshold, self.confidence, self.max_iterations, self.sampler.tau,
@@ -375,15 +376,20 @@ class BatchedRANSAC(object):
         return self
 
     def hypotheses(self, matches, logits, gumbels=None):
-        """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S] (differentiable w.r.t. logits)."""
+        """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S], idx [P,B,k] (differentiable w.r.t. logits)."""
+        return self._hypotheses(matches, logits, gumbels)[:3]
+
+    def _hypotheses(self, matches, logits, gumbels=None):
+        """hypotheses() + the (seed, noise) pair of the draw when the weighted refit will need row 0's soft weights again
+        (returned, not stashed on self: two rounds are in flight on two streams when `pipeline` is on), else None."""
         if self.weighted and self.solver == "f8" and not self.train and self.refit:
-            # the weighted LSQ refit (ransac.py:151-153) needs y_soft of hypothesis 0 of the LAST batch a pair ran: take the seed
-            # here so that __call__ can re-draw that one row (ops.soft_weights_row0)
+            # the weighted LSQ refit (ransac.py:151-153) needs y_soft of hypothesis 0 of the LAST batch a pair ran: the seed is
+            # handed back so that __call__ can re-draw that one row (ops.soft_weights_row0).  weighted=1 implies the Gumbel
+            # sampler (__init__ refuses it with 'uniform' / 'topdown')
             seed = self._next_seed()
             samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, seed)
-            self._row0 = (seed, gumbels)
             F, v = ops.solve_fundamental8(samples, w)
-            return F.unsqueeze(2), v.unsqueeze(2), idx
+            return F.unsqueeze(2), v.unsqueeze(2), idx, (seed, gumbels)
         if self.sampling == "uniform" and gumbels is None:
             idx = ops.uniform_sample(matches.shape[0], self.B, self.k, matches.shape[1], self._next_seed(), matches.device)
             samples, w = ops.gather(matches, idx), None
@@ -409,7 +415,7 @@ class BatchedRANSAC(object):
             models, valid = F.unsqueeze(2), v.unsqueeze(2)
         else:
             models, valid = ops.solve_f7(samples)
-        return models, valid, idx
+        return models, valid, idx, None
 
     def __call__(self, matches, logits, K1=None, K2=None, gt_model=None, gumbels=None):
         P, N, _ = matches.shape
@@ -421,7 +427,8 @@ class BatchedRANSAC(object):
                 g = None if gumbels is None else gumbels[r]
                 if (self.solver == "nister" and self.k == 5 and not self.weighted and matches.dtype == torch.float32
                         and logits.dtype == torch.float32 and logits.requires_grad):
-                    # the training path proper: sampler + gather, then solver + best-of-ten as ONE autograd node whose backward
+                    # the training path proper (train mode implies the Gumbel sampler: __init__ refuses the index-only samplings):
+                    # sampler + gather, then solver + best-of-ten as ONE autograd node whose backward
                     # takes the gradient of the chosen model in sparse form (ops.solve_select_essential)
                     samples, _, _ = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, g, self._next_seed())
                     chosen, _, keep, _, _ = ops.solve_select_essential(samples, gt_model)
@@ -476,7 +483,8 @@ class BatchedRANSAC(object):
                 pre = issue_refit()
             ahead = None
             if have_round(0):
-                ahead = self.hypotheses(matches, logits, noise_of(0))[:2] + (getattr(self, "_row0", None),)
+                h = self._hypotheses(matches, logits, noise_of(0))
+                ahead = (h[0], h[1], h[3])
             r = 0
             want_w = bool(self.weighted and self.solver == "f8" and self.refit)   # (the 7-point solver takes no weights)
             last_w = torch.zeros((P, N), device=dev, dtype=dt) if want_w else None
@@ -488,7 +496,8 @@ class BatchedRANSAC(object):
                         self._pipe = torch.cuda.Stream(device=dev)
                     self._pipe.wait_stream(main)          # inputs (and, for explicit noise, the caller's tensors) are ready
                     with torch.cuda.stream(self._pipe):
-                        ahead = self.hypotheses(matches, logits, noise_of(r + 1))[:2] + (getattr(self, "_row0", None),)
+                        h = self._hypotheses(matches, logits, noise_of(r + 1))
+                        ahead = (h[0], h[1], h[3])
                 if want_w:
                     # pairs still iterating in this round take this round's row-0 soft weights; terminated pairs keep theirs
                     # ("the last batch sampled", per pair)
@@ -510,7 +519,8 @@ class BatchedRANSAC(object):
                 if r % self.sync_every == 0 and not bool((st.iters.double() < st.max_iters).any()):
                     break
                 if ahead is None:
-                    ahead = self.hypotheses(matches, logits, noise_of(r))[:2] + (getattr(self, "_row0", None),)
+                    h = self._hypotheses(matches, logits, noise_of(r))
+                    ahead = (h[0], h[1], h[3])
                 else:
                     main.wait_stream(self._pipe)
                     for t_ in ahead[:2]:
