@@ -17,9 +17,10 @@ The other BASELINE configs are measured after the headline region (N = 1 only) a
   c3  Stewenius 5-point, 2000 points, 4096 hypotheses, 32 pairs
   c4  rigid SVD, 50 000 points, 2048 hypotheses, one pair
 `--workload c1|c3|c4` makes one of them the timed region instead (for profiling).
-`--mode train`: sampler -> solver -> best-of-10 vs GT -> MatchLoss -> backward to the logits; with N > 1 every step ends
-with the training step's one collective (train.py:150-175): a flat RCCL all-reduce of the scores network's gradient
-bucket (622 616 f32, the reference's CLNet) + the logits gradient.  `--split hypotheses`: fewer pairs than GPUs -- every
+`--mode train`: sampler -> solver -> best-of-10 vs GT -> MatchLoss -> backward to the logits; with N > 1 every step carries
+the training step's one collective (train.py:150-175): a flat RCCL all-reduce of the scores network's gradient bucket
+(622 616 f32, the reference's CLNet; the per-pair logits gradient stays on its rank), issued asynchronously and waited for
+after the next step's launches have been enqueued (`collective_ms` / `collective_exposed_ms`).  `--split hypotheses`: fewer pairs than GPUs -- every
 rank draws B / N hypotheses for the SAME pairs and the per-pair winners are merged (strong scaling).
 """
 from __future__ import annotations
@@ -236,7 +237,8 @@ class CallTimer:
 
 
 def per_call_breakdown(step, reps=10):
-    """Average device time of every libdransac entry point of one step (events around each ctypes call; one stream)."""
+    """Device time of every libdransac entry point of one step (events around each ctypes call; one stream): per entry the sum
+    over its calls within a step, MEDIAN over `reps` steps (a host hiccup between an event and its launch lands in the mean)."""
     from differentiable_ransac_amd import _lib as L
     orig = L.call
     rec = []
@@ -246,21 +248,25 @@ def per_call_breakdown(step, reps=10):
         e0.record()
         orig(name, *a)
         e1.record()
-        rec.append((name, e0, e1))
+        rec[-1].append((name, e0, e1))
 
     step()
     torch.cuda.synchronize()
     L.call = call
     try:
         for _ in range(reps):
+            rec.append([])
             step()
         torch.cuda.synchronize()
     finally:
         L.call = orig
-    out = {}
-    for name, a, b in rec:
-        out[name] = out.get(name, 0.0) + a.elapsed_time(b) / reps
-    return out
+    per_rep = []
+    for calls in rec:
+        d = {}
+        for name, a, b in calls:
+            d[name] = d.get(name, 0.0) + a.elapsed_time(b)
+        per_rep.append(d)
+    return {name: sorted(d.get(name, 0.0) for d in per_rep)[len(per_rep) // 2] for name in per_rep[0]}
 
 
 def k4_bytes(P, N, M):
@@ -622,22 +628,16 @@ def main():
     timer = CallTimer((score_prefix,), args.steps * n_seg)
 
     # the training step's collective: one flat bucket = the scores network's gradient (random stand-in of the reference
-    # CLNet's size: the network itself is out of scope) + the logits gradient
-    coll_ev, net_grad = [], None
-    if args.mode == "train" and world > 1:
-        net_grad = torch.randn(CLNET_PARAMS, device=dev)
+    # CLNet's size: the network itself is out of scope).  Ranks own different pairs: the per-pair logits gradient continues into
+    # each rank's own backward through the scores network; what the ranks average is that network's parameter gradient
+    # (train.py:150-175), nothing else.  It is issued ASYNCHRONOUSLY (sharding.AsyncGradientBucket): step i's bucket is handed to
+    # RCCL right after step i's backward has been enqueued, and the compute stream waits for it only after step i + 1's forward
+    # + backward have been enqueued (where the optimizer would read it) -- the collective runs under the next step's kernels.
+    bucket = None
     base_step = step
     if args.mode == "train" and world > 1:
-        def step():
-            out = base_step()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            # ranks own different pairs: the per-pair logits gradient continues into each rank's own backward through the
-            # scores network; what the ranks average is that network's parameter gradient (train.py:150-175), nothing else
-            sharding.allreduce_mean_([net_grad], dist)
-            e1.record()
-            coll_ev.append((e0, e1))
-            return out
+        bucket = sharding.AsyncGradientBucket(CLNET_PARAMS, dev, dist, fill=torch.randn(CLNET_PARAMS, device=dev))
+        step = sharding.OverlappedStep(base_step, bucket)
     elif split_h:
         def step():
             out = base_step()
@@ -696,7 +696,10 @@ def main():
     # rate of a segment = sum of hypotheses over ranks / max elapsed over ranks; the line reports the MEDIAN segment
     seg_elapsed, seg_rate, seg_k4, seg_coll = [], [], [], []
     for sgi in range(n_seg):
-        coll_ev.clear()
+        if bucket is not None:
+            bucket.drain()
+            bucket.exposed_events.clear()
+            bucket.trace.clear()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -705,6 +708,8 @@ def main():
             timer.i = sgi * args.steps + i
             issue_bounded(i, n_issued)
             n_issued += 1
+        if bucket is not None:
+            bucket.drain()               # the last step's collective belongs to the timed region
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -714,8 +719,8 @@ def main():
         rate, el = sharding.job_throughput(P * w["hyps"] * args.steps, el, dist, dev)
         seg_elapsed.append(el)
         seg_rate.append(rate)
-        if coll_ev:
-            seg_coll.append(sum(a.elapsed_time(b) for a, b in coll_ev) / len(coll_ev))
+        if bucket is not None and bucket.exposed_events:
+            seg_coll.append(sum(a.elapsed_time(b) for a, b in bucket.exposed_events) / len(bucket.exposed_events))
     out = outs[(args.steps - 1) % len(streams)]
     med = sorted(range(n_seg), key=lambda i: seg_elapsed[i])[n_seg // 2]
     elapsed, job_hyps_per_s = seg_elapsed[med], seg_rate[med]
@@ -724,12 +729,26 @@ def main():
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         n_ranks_seen = int(one.item())
-    collective_ms = sorted(seg_coll)[len(seg_coll) // 2] if seg_coll else (0.0 if world > 1 else None)
+    # exposed = what the compute stream waited at the optimizer's read (median segment); collective_ms = the same all-reduce
+    # issued BLOCKING on an idle device after the timed region (its own duration, nothing to hide behind)
+    collective_exposed_ms = sorted(seg_coll)[len(seg_coll) // 2] if seg_coll else (0.0 if world > 1 else None)
+    collective_ms = 0.0 if world > 1 else None
+    if bucket is not None:
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sharding.allreduce_mean_([bucket.buf[0]], dist)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        collective_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
 
     common = {"unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
               "scaling": "strong" if split_h else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-              "n_ranks_seen": n_ranks_seen, "collective_ms": collective_ms,
+              "n_ranks_seen": n_ranks_seen, "collective_ms": collective_ms, "collective_exposed_ms": collective_exposed_ms,
               "prewarm_s": round(prewarm_s, 3), "prewarm_steps": prewarm_steps,
               "segments": {"n": n_seg, "steps_each": args.steps, "reported": "median segment",
                            "ms_per_step": [round(e / args.steps * 1e3, 5) for e in seg_elapsed],
@@ -747,7 +766,10 @@ def main():
                                                    if use_graph else "eager: one Python call per launch, autograd backward"),
                                          "parallelism": f"pairs sharded over {world} GPU(s); one flat RCCL all-reduce of "
                                                         f"{CLNET_PARAMS} f32 (the scores network's gradient) per step" if world > 1 else "single GPU"},
-                              "collective_share_of_step": (collective_ms / (elapsed / args.steps * 1e3)) if collective_ms else None,
+                              "collective_issue": ("asynchronous: bucket i is all-reduced under the kernels of step i + 1, waited for "
+                                                   "where the optimizer reads it (sharding.AsyncGradientBucket)" if world > 1 else None),
+                              "collective_exposed_share_of_step": (collective_exposed_ms / (elapsed / args.steps * 1e3))
+                              if collective_exposed_ms else None,
                               "collective_bytes": 4 * CLNET_PARAMS if world > 1 else 0,
                               "grad_finite": bool(torch.isfinite(out["grad"]).all())}))
         timer.close()

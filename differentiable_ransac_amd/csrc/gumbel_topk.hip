@@ -523,6 +523,53 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   if (kSoft && lane == 0) lse_out[row] = lse;
 }
 
+// ---- screening words for the long-row kernel, index-only mode (round 4) -----------------------------------------------------
+// The k winners of a row are its k largest logit_n + G_n, and G_n is a monotone function of the Philox word w_n: "score >= T" is
+// "w_n >= tb_n" with a per-point word tb_n that depends on the pair's logits only.  T = logsumexp(logits) - ln(lambda) puts
+// Poisson(lambda) such points into a row.  tb_n is rounded DOWN (score >= T - margin, four roundings of the 24-bit conversion),
+// so no point that reaches T is ever missed; T itself only sets the expected count -- it may be approximate, but every block
+// must derive the SAME value (same reduction order), because the sampler compares exactly evaluated scores with it.
+// One launch: every block re-derives T from the whole row of logits (L2 hits) and writes the words of its own 1024 points.
+constexpr float kScreenMargin = 1e-3f;   // the device logarithms are good to ~1e-6
+__global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restrict__ logits, int N, float lambda,
+                                                           uint32_t *__restrict__ tb, float *__restrict__ T_out) {
+  __shared__ float s_red[256];
+  const int p = blockIdx.y, tid = threadIdx.x;
+  const float *l = logits + (size_t)p * N;
+  float mx = -INFINITY;
+  for (int n = tid; n < N; n += 256) mx = fmaxf(mx, l[n]);
+  s_red[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]);
+    __syncthreads();
+  }
+  mx = s_red[0];
+  __syncthreads();
+  float sm = 0.f;
+  for (int n = tid; n < N; n += 256) sm += __expf(l[n] - mx);
+  s_red[tid] = sm;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_red[tid] += s_red[tid + o];
+    __syncthreads();
+  }
+  float Tf = mx + __logf(s_red[0]) - __logf(lambda);
+  if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY) Tf = INFINITY;   // non-finite logits: no point passes, every row takes the full pass
+  if (blockIdx.x == 0 && tid == 0) T_out[p] = Tf;
+  constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);
+  for (int n = blockIdx.x * 1024 + tid; n < min(N, (int)(blockIdx.x + 1) * 1024); n += 256) {
+    // G >= a  <=>  u >= exp(-exp(-a)),  u = fl(fl24(w) * 2^-32 c + tiny)  (gumbel_from_bits),  a = T - margin - logit_n
+    const double a = ((double)Tf - (double)kScreenMargin) - (double)l[n];
+    const double e = exp(-a);
+    const double us = (e < 745.0) ? exp(-e) : 0.0;
+    double w = floor((us - kTiny) / kScale) - 1024.0;
+    if (!(w == w)) w = 0.0;
+    w = fmin(fmax(w, 0.0), 4294967295.0);
+    tb[(size_t)p * N + n] = (Tf == INFINITY) ? 0xffffffffu : (uint32_t)w;
+  }
+}
+
 // ---- rows longer than the register kernel holds (N > 2048): ONE pass ----------------------------------------------------
 // The general kernel above makes two passes over a row that does not fit its LDS cache -- lane maxima first, then the
 // candidates above the k-th largest lane maximum -- and generates the Philox noise of every element twice.  Here a lane keeps
@@ -546,7 +593,16 @@ template <int K, bool kSoft, int kW>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(const float *__restrict__ logits, uint64_t seed, int B,
                                                                                int N, int k, int32_t *__restrict__ idx,
                                                                                float *__restrict__ y_sel, float *__restrict__ lse_out,
-                                                                               const uint64_t *__restrict__ seed_ptr) {
+                                                                               const uint64_t *__restrict__ seed_ptr,
+                                                                               const uint32_t *__restrict__ screen_tb = nullptr,
+                                                                               const float *__restrict__ screen_T = nullptr) {
+  // screen_tb / screen_T (index-only mode): per point the smallest Philox word that can still lift the point to the score T
+  // (gumbel_screen_kernel).  A step of the wave whose 256 words all stay below their thresholds is skipped after Philox + four
+  // integer compares: no logits, no logarithms, no insertion.  Steps with a candidate are evaluated in full, for every lane, so
+  // the lists hold exactly computed scores only; the row counts the evaluated scores >= T and, if fewer than k reach it
+  // (3e-8 of the rows at lambda = 20 + k), repeats itself without the screen.  Otherwise the k winners are all >= T, hence all
+  // evaluated: the index sets are those of the unscreened kernel, bit for bit.
+  __shared__ int s_cnt[kRowsPerBlock];
   __shared__ float s_cv[kW > 1 ? kRowsPerBlock * kMaxK : 1];
   __shared__ int s_ci[kW > 1 ? kRowsPerBlock * kMaxK : 1];
   __shared__ float s_mx[kRowsPerBlock], s_sm[kRowsPerBlock];
@@ -560,40 +616,63 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
   const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
   float tv[K];
   int ti[K];
-#pragma unroll
-  for (int s = 0; s < K; ++s) { tv[s] = -INFINITY; ti[s] = 0x7fffffff; }
   float mx = -INFINITY, sm = 0.f;
-  for (int q = lane + 64 * part; q < groups; q += 64 * kW) {
-    uint32_t r[4];
-    Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
-    const float4 l = lg[q];
-    const float g[4] = {l.x + gumbel_from_bits(r[0]), l.y + gumbel_from_bits(r[1]), l.z + gumbel_from_bits(r[2]),
-                        l.w + gumbel_from_bits(r[3])};
-    const float gm = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
-    if (kSoft) {
-      if (gm > mx) { sm *= exp_t<float>(mx - gm); mx = gm; }
+  const uint4 *tb4 = (!kSoft && screen_tb) ? reinterpret_cast<const uint4 *>(screen_tb + (size_t)p * N) : nullptr;
+  const float Tscr = tb4 ? screen_T[p] : 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool screen = tb4 != nullptr && pass == 0;   // block-uniform
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sm += exp_t<float>(g[j] - mx);
-    }
-    // a lane's elements arrive in ascending index order, so a new element displaces only strictly smaller values
-    if (!__ballot(gm > tv[K - 1])) continue;
+    for (int s = 0; s < K; ++s) { tv[s] = -INFINITY; ti[s] = 0x7fffffff; }
+    int cnt = 0;
+    for (int q = lane + 64 * part; q < groups; q += 64 * kW) {
+      uint32_t r[4];
+      Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+      if (screen) {
+        const uint4 t = tb4[q];
+        if (!__ballot(r[0] >= t.x || r[1] >= t.y || r[2] >= t.z || r[3] >= t.w)) continue;
+      }
+      const float4 l = lg[q];
+      const float g[4] = {l.x + gumbel_from_bits(r[0]), l.y + gumbel_from_bits(r[1]), l.z + gumbel_from_bits(r[2]),
+                          l.w + gumbel_from_bits(r[3])};
+      const float gm = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
+      if (kSoft) {
+        if (gm > mx) { sm *= exp_t<float>(mx - gm); mx = gm; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = g[j];
-      const int n = 4 * q + j;
-      bool prev = false;   // v > tv[s - 1]
-      float pv = 0.f;      // tv[s - 1] before the update
-      int pi = 0;
+        for (int j = 0; j < 4; ++j) sm += exp_t<float>(g[j] - mx);
+      }
+      if (screen) cnt += (int)(g[0] >= Tscr) + (int)(g[1] >= Tscr) + (int)(g[2] >= Tscr) + (int)(g[3] >= Tscr);
+      // a lane's elements arrive in ascending index order, so a new element displaces only strictly smaller values
+      if (!__ballot(gm > tv[K - 1])) continue;
 #pragma unroll
-      for (int s = 0; s < K; ++s) {
-        const bool c = v > tv[s];
-        const float ov = tv[s];
-        const int oi = ti[s];
-        tv[s] = c ? (prev ? pv : v) : ov;
-        ti[s] = c ? (prev ? pi : n) : oi;
-        prev = c; pv = ov; pi = oi;
+      for (int j = 0; j < 4; ++j) {
+        const float v = g[j];
+        const int n = 4 * q + j;
+        bool prev = false;   // v > tv[s - 1]
+        float pv = 0.f;      // tv[s - 1] before the update
+        int pi = 0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          const bool c = v > tv[s];
+          const float ov = tv[s];
+          const int oi = ti[s];
+          tv[s] = c ? (prev ? pv : v) : ov;
+          ti[s] = c ? (prev ? pi : n) : oi;
+          prev = c; pv = ov; pi = oi;
+        }
       }
     }
+    if (!screen) break;
+    // did k evaluated scores of the ROW reach T?  (kW > 1: the row's four waves agree through LDS)
+    cnt = wave_sum(cnt);
+    if (kW > 1) {
+      if (lane == 0) s_cnt[wv] = cnt;
+      __syncthreads();
+      cnt = 0;
+#pragma unroll
+      for (int w = 0; w < kRowsPerBlock; ++w) cnt += s_cnt[w];
+      __syncthreads();
+    }
+    if (cnt >= k) break;
   }
   float wmx = 0.f, lse = 0.f, inv_sm = 0.f;
   if (kSoft) {
@@ -686,24 +765,25 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
 
 template <int K>
 static void stream_launch(bool soft, dim3 grid, dim3 block, hipStream_t st, const float *logits, uint64_t seed, int B, int N, int k,
-                          int32_t *idx, float *y_sel, float *lse, const uint64_t *seed_ptr) {
+                          int32_t *idx, float *y_sel, float *lse, const uint64_t *seed_ptr, const uint32_t *tb = nullptr,
+                          const float *Tp = nullptr) {
   // few rows: four waves per row (one row per block) -- the wave-per-row grid would leave the SIMDs at <= 4 waves each
   const long rows = (long)grid.y * B;
   if (DR_K1_STREAM_SPLIT && rows <= 4096 && N >= 4 * 64 * 4 * 4) {
     const dim3 g2(B, grid.y);
     if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
-    else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+    else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr, tb, Tp);
     return;
   }
   if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
-  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
+  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr, tb, Tp);
 }
 
 template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
                       const uint64_t *seed_ptr = nullptr, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr,
-                      bool *gathered = nullptr) {
+                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr) {
   if (gathered) *gathered = false;
   GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
   const int groups = (N + 3) / 4;
@@ -729,8 +809,18 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
     // k = 8 lists cost what the second pass costs (256 vs 250 us at N = 20 000) -> the general kernel keeps k > 5
     if (DR_K1_STREAM && logits && !gumbel && tau == T(1) && (N & 3) == 0 && N > 4 * 64 * kFastGroups && k <= 5 && !y_soft && !ret &&
         !gumbel_out) {
-      if (k <= 3) stream_launch<3>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr);
-      else stream_launch<5>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr);
+      const uint32_t *tb = nullptr;
+      const float *Tp = nullptr;
+      if (screen_ws && !soft) {
+        // workspace: P x N words + P scores; lambda = 20 + k: P(fewer than k of a row's points reach T) < 1e-7
+        float *Tw = reinterpret_cast<float *>(screen_ws + (size_t)P * N);
+        hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 1023) / 1024, P), dim3(256), 0, st, (const float *)logits, N, (float)(20 + k),
+                           screen_ws, Tw);
+        tb = screen_ws;
+        Tp = Tw;
+      }
+      if (k <= 3) stream_launch<3>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr, tb, Tp);
+      else stream_launch<5>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr, tb, Tp);
       return check_launch("gumbel_topk_stream_kernel");
     }
   }
@@ -1045,13 +1135,14 @@ __global__ void gather_bwd_kernel(const T *__restrict__ matches, const int32_t *
 
 }  // namespace dr
 
-static int gumbel_bwd_f32_impl(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_ptr, float tau,
-                               int P, int B, int N, int k, const int32_t *idx, const float *lse, const float *a_sel,
-                               float *grad_logits, void *stream) {
+template <typename T>
+static int gumbel_bwd_impl(const T *logits, const T *gumbel, uint64_t seed, const uint64_t *seed_ptr, T tau,
+                           int P, int B, int N, int k, const int32_t *idx, const T *lse, const T *a_sel,
+                           T *grad_logits, void *stream) {
   DR_REQUIRE(idx && lse && a_sel && grad_logits, "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
-  dr::GumbelArgs<float> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
-  const size_t smem = sizeof(float) * 256 * 2;
+  dr::GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
+  const size_t smem = sizeof(T) * 256 * 2;
   const int gx = ((N + 3) / 4 + 255) / 256;
   // enough row chunks to put >= ~2048 blocks on the chip, at least 32 rows each
 #ifndef DR_K1_BWD_BLOCKS
@@ -1064,11 +1155,16 @@ static int gumbel_bwd_f32_impl(const float *logits, const float *gumbel, uint64_
                                    std::max<long>(1, DR_K1_BWD_BLOCKS / std::max<long>(1, (long)gx * P)));
   const int rows_per_block = (B + chunks - 1) / chunks;
   chunks = (B + rows_per_block - 1) / rows_per_block;
-  if (hipMemsetAsync(grad_logits, 0, sizeof(float) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
+  if (hipMemsetAsync(grad_logits, 0, sizeof(T) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
     return dr::check_launch("memset");
-  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<float>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
+  hipLaunchKernelGGL((dr::gumbel_bwd_kernel<T>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
                      lse, a_sel, grad_logits, rows_per_block);
   return dr::check_launch("gumbel_bwd_kernel");
+}
+static int gumbel_bwd_f32_impl(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_ptr, float tau,
+                               int P, int B, int N, int k, const int32_t *idx, const float *lse, const float *a_sel,
+                               float *grad_logits, void *stream) {
+  return gumbel_bwd_impl<float>(logits, gumbel, seed, seed_ptr, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
 }
 
 template <typename T>
@@ -1121,6 +1217,13 @@ int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t se
                            int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
                            void *stream) {
   return gumbel_bwd_f32_impl(logits, gumbel, seed, nullptr, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
+}
+
+// f64 (`-pr 2 -tr 1`, model_cl.py:164-169): the same kernel in double (general form: two logarithms + an exponential per element)
+int dr_gumbel_topk_bwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B, int N,
+                           int k, const int32_t *idx, const double *lse, const double *a_sel, double *grad_logits,
+                           void *stream) {
+  return gumbel_bwd_impl<double>(logits, gumbel, seed, nullptr, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
 }
 
 int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
@@ -1199,6 +1302,18 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
   return dr::check_launch("gather_fwd_kernel");
 }
 
+// K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 1) * P words, 16-byte aligned): long rows
+// (N > 2048, N % 4 == 0, tau == 1, k <= 5) then skip the Gumbel transform of every step of a wave that holds no candidate
+int dr_gumbel_topk_index_f32(const float *logits, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
+                             int32_t *idx, uint32_t *screen_ws, void *stream) {
+  const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
+  DR_REQUIRE(logits, "null pointer");
+  DR_REQUIRE((reinterpret_cast<uintptr_t>(screen_ws) & 15) == 0, "workspace alignment");
+  DR_GUMBEL_CHECK();
+  return dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      (hipStream_t)stream, seed_dev, nullptr, nullptr, nullptr, screen_ws);
+}
+
 int dr_gather_fwd_f32(const float *matches, const int32_t *idx, const float *y_sel, int P, int N, int B, int k,
                       int c, float *samples, void *stream) {
   DR_REQUIRE(matches && idx && samples, "null pointer");
@@ -1223,6 +1338,16 @@ int dr_gather_bwd_f32(const float *matches, const int32_t *idx, const float *y_s
   DR_REQUIRE(matches && idx && grad_samples && a_sel, "null pointer");
   DR_REQUIRE(P > 0 && N > 0 && B > 0 && k > 0 && c > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::gather_bwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
+                     matches, idx, y_sel, grad_samples, grad_w, N, B * k, c, a_sel, grad_matches);
+  return dr::check_launch("gather_bwd_kernel");
+}
+
+int dr_gather_bwd_f64(const double *matches, const int32_t *idx, const double *y_sel, const double *grad_samples,
+                      const double *grad_w, int P, int N, int B, int k, int c, double *a_sel, double *grad_matches,
+                      void *stream) {
+  DR_REQUIRE(matches && idx && grad_samples && a_sel, "null pointer");
+  DR_REQUIRE(P > 0 && N > 0 && B > 0 && k > 0 && c > 0 && P <= 65535, "bad sizes");
+  hipLaunchKernelGGL((dr::gather_bwd_kernel<double>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
                      matches, idx, y_sel, grad_samples, grad_w, N, B * k, c, a_sel, grad_matches);
   return dr::check_launch("gather_bwd_kernel");
 }

@@ -233,7 +233,15 @@ __global__ __launch_bounds__(kRThreads) void rigid_residual_kernel(const T *__re
 constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts, kR16MaxTile = 64;
 typedef float v2r __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2r rsplat(float a) { return (v2r){a, a}; }
-__global__ __launch_bounds__(kR16Threads) void rigid_residual_kernel_f32_16(const float *__restrict__ pts, const float *__restrict__ models,
+#ifndef DR_K4R_WAVES
+#define DR_K4R_WAVES 0   // > 0: register budget pinned to that many waves per SIMD (A/B builds; 4 spills two point registers)
+#endif
+#if DR_K4R_WAVES > 0
+#define DR_K4R_OCC __attribute__((amdgpu_waves_per_eu(DR_K4R_WAVES, DR_K4R_WAVES)))
+#else
+#define DR_K4R_OCC
+#endif
+__global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_f32_16(const float *__restrict__ pts, const float *__restrict__ models,
                                                                            float threshold, int M, int N, float *__restrict__ res_sum,
                                                                            uint8_t *__restrict__ masks, int chunks_per_block,
                                                                            int use_atomic, int tile) {
@@ -353,7 +361,7 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
       if (!resident) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident = 6 * max(cus, 1);
+        resident = (DR_K4R_WAVES == 4 ? 8 : 6) * max(cus, 1);
       }
       const int chunks = (N + kR16Chunk - 1) / kR16Chunk;
       int ny = chunks;                      // one chunk per block whenever the row is longer than a chunk (atomics across them)

@@ -145,13 +145,16 @@ def _dev_seed(seed):
 
 def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0,
                 gumbel: Optional[torch.Tensor] = None, seed: int = 0, N: Optional[int] = None,
-                dense: bool = False, want_noise: bool = False, device=None, dtype=torch.float32, soft: bool = True):
+                dense: bool = False, want_noise: bool = False, device=None, dtype=torch.float32, soft: bool = True,
+                screen: Optional[bool] = None):
     """K1 forward.  logits [P,N] (or None = all-ones, then pass N/device/dtype); gumbel [P,B,N] explicit
     noise or None (in-kernel Philox keyed by `seed`).
 
     Returns dict(idx [P,B,k] int32 ascending, y_sel [P,B,k], lse [P,B]) plus, when `dense`,
     y_soft / ret [P,B,N], and when `want_noise`, gumbel [P,B,N] (the noise the kernel used).
-    soft=False: index sets only (y_sel = lse = None) -- what test mode consumes; the same idx, a cheaper kernel."""
+    soft=False: index sets only (y_sel = lse = None) -- what test mode consumes; the same idx, a cheaper kernel.
+    screen (index-only mode, rows longer than 2048 points): None = on when it can pay (B >= 64 rows per pair), False = off
+    (A/B and tests: the index sets are the same either way)."""
     if not soft and dense:
         raise ValueError("the dense outputs need the soft-max statistics (soft=True)")
     if logits is not None:
@@ -165,6 +168,14 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
         gumbel = gumbel.contiguous()
         assert gumbel.shape == (P, B, N) and gumbel.dtype == dtype
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
+    if (not soft and logits is not None and gumbel is None and not want_noise and dtype == torch.float32 and tau == 1.0
+            and N > 2048 and N % 4 == 0 and k <= 5 and (B >= 64 if screen is None else screen)):
+        # long rows, index sets only: the screened one-pass kernel (dr_gumbel_topk_index_f32; same index sets, bit for bit)
+        ws = torch.empty(((N + 1) * P,), device=device, dtype=torch.int32)
+        ds = _dev_seed(seed)
+        L.call("dr_gumbel_topk_index_f32", ptr(logits), c_uint64(0 if ds else seed & (2 ** 64 - 1)), ptr(seed if ds else None),
+               L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(ws), stream())
+        return dict(idx=idx, y_sel=None, lse=None)
     y_sel = torch.empty((P, B, k), device=device, dtype=dtype) if soft else None
     lse = torch.empty((P, B), device=device, dtype=dtype) if soft else None
     y_soft = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
@@ -204,10 +215,17 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
 
 
 def gumbel_topk_bwd(logits, gumbel, seed, tau, idx, lse, a_sel):
-    """grad_logits [P,N] from a_sel [P,B,k] (f32 only)."""
+    """grad_logits [P,N] from a_sel [P,B,k] (f32; f64 with a by-value seed or explicit noise)."""
     P, B, k = idx.shape
     N = logits.shape[1]
     grad = torch.empty_like(logits)
+    if logits.dtype == torch.float64:
+        if _dev_seed(seed):
+            raise L.DransacError("gumbel_topk_bwd: device seeds serve f32 only")
+        L.call("dr_gumbel_topk_bwd_f64", ptr(logits.contiguous()), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
+               L.c_double(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(lse.contiguous()),
+               ptr(a_sel.to(torch.float64).contiguous()), ptr(grad), stream())
+        return grad
     if _dev_seed(seed):
         L.call("dr_gumbel_topk_bwd_f32_dseed", ptr(logits.contiguous()), ptr(seed), L.c_float(tau), c_int(P), c_int(B), c_int(N),
                c_int(k), ptr(idx), ptr(lse), ptr(a_sel.contiguous()), ptr(grad), stream())
@@ -270,8 +288,9 @@ def gather_bwd(matches, idx, y_sel, grad_samples, grad_w=None, want_grad_matches
     _, B, k = idx.shape
     a_sel = torch.empty((P, B, k), device=matches.device, dtype=matches.dtype)
     gm = torch.zeros_like(matches) if want_grad_matches else None
-    L.call("dr_gather_bwd_f32", ptr(matches.contiguous()), ptr(idx), ptr(y_sel), ptr(grad_samples.contiguous()),
-           ptr(None if grad_w is None else grad_w.contiguous()), c_int(P), c_int(N), c_int(B), c_int(k), c_int(c),
+    dt = matches.dtype
+    L.call(f"dr_gather_bwd_{L.suffix(dt)}", ptr(matches.contiguous()), ptr(idx), ptr(y_sel), ptr(grad_samples.to(dt).contiguous()),
+           ptr(None if grad_w is None else grad_w.to(dt).contiguous()), c_int(P), c_int(N), c_int(B), c_int(k), c_int(c),
            ptr(a_sel), ptr(gm), stream())
     return a_sel, gm
 
@@ -280,7 +299,7 @@ class SampleGather(torch.autograd.Function):
     """K1+K2 fused at the autograd level: (matches [P,N,c], logits [P,N]) -> samples [P,B,k,c], weights [P,B,k].
 
     Forward: dr_gumbel_topk_fwd + dr_gather_fwd (no [B,N] tensor is materialised).
-    Backward: dr_gather_bwd -> a_sel, dr_gumbel_topk_bwd -> grad_logits (f32)."""
+    Backward: dr_gather_bwd -> a_sel, dr_gumbel_topk_bwd -> grad_logits (f32 and f64)."""
 
     @staticmethod
     def forward(ctx, matches, logits, B, k, tau, gumbel, seed):
@@ -301,8 +320,6 @@ class SampleGather(torch.autograd.Function):
         if g_samples is None:
             g_samples = torch.zeros(idx.shape + (matches.shape[-1],), device=matches.device, dtype=matches.dtype)
         tau, seed, has_noise = ctx.cfg
-        if logits.dtype != torch.float32:
-            raise L.DransacError("backward is implemented for f32 only")
         a_sel, gm = gather_bwd(matches, idx, y_sel, g_samples, g_w, want_grad_matches=ctx.needs_input_grad[0])
         gl = gumbel_topk_bwd(logits, gumbel if has_noise else None, seed, tau, idx, lse, a_sel)
         return gm, gl, None, None, None, None, None
@@ -531,8 +548,11 @@ class _SolveEssential(torch.autograd.Function):
         if g_models is None:
             return None, None, None
         samples, models, m64, valid = ctx.saved_tensors
-        if samples.dtype != torch.float32:
-            raise L.DransacError("backward is implemented for f32 only")
+        f64 = samples.dtype == torch.float64
+        if f64:
+            # `-pr 2 -tr 1`: the forward ran in f64; the backward kernels read f32 samples / gradients but take the f64 models and
+            # compute in f64 (their tangent-space system is what needs the precision): inputs rounded once, gradient returned as f64
+            m64, models, samples, g_models = models, models.float(), samples.float(), g_models.float()
         s, Bt, n = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
         if not ctx.minimal:
@@ -544,10 +564,12 @@ class _SolveEssential(torch.autograd.Function):
                    ptr(models.contiguous()), ptr(m64.contiguous() if m64.numel() else None),
                    ptr(valid.contiguous().view(torch.uint8)), ptr(g_models.contiguous()), c_int(Bt), c_int(n), ptr(gs), ptr(gw),
                    stream())
-            return gs.reshape(samples.shape), (None if gw is None else gw.reshape(w.shape).to(w.dtype)), None
+            gs = gs.reshape(samples.shape)
+            return (gs.double() if f64 else gs), (None if gw is None else gw.reshape(w.shape).to(w.dtype)), None
         L.call("dr_solve_nister5_bwd_f32", ptr(s), ptr(models.contiguous()), ptr(m64.contiguous() if m64.numel() else None),
                ptr(valid.contiguous().view(torch.uint8)), ptr(g_models.contiguous()), c_int(Bt), ptr(gs), stream())
-        return gs.reshape(samples.shape), None, None
+        gs = gs.reshape(samples.shape)
+        return (gs.double() if f64 else gs), None, None
 
 
 def solve_essential(samples, weights=None, which="nister"):
@@ -612,15 +634,19 @@ class _SolveF8(torch.autograd.Function):
         if gF is None:
             return None, None
         samples, weights, F = ctx.saved_tensors
-        if samples.dtype != torch.float32:
-            raise L.DransacError("backward is implemented for f32 only")
+        dt = samples.dtype
+        if dt == torch.float64:
+            # `-pr 2 -tr 1`: f64 forward; the backward kernel has f32 I/O (f64 arithmetic inside): inputs rounded once to f32,
+            # gradients returned as f64 (precision table)
+            samples, F, gF = samples.float(), F.float(), gF.float()
+            weights = weights.float()
         s, Bt, n = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
         w = weights.reshape(Bt, n).contiguous() if ctx.has_w else None
         gw = torch.empty_like(w) if ctx.has_w else None
         L.call("dr_solve_f8_bwd_f32", ptr(s), ptr(w), ptr(F.contiguous()), ptr(gF.contiguous()), c_int(Bt), c_int(n),
                ptr(gs), ptr(gw), stream())
-        return gs.reshape(samples.shape), (gw.reshape(weights.shape) if ctx.has_w else None)
+        return gs.reshape(samples.shape).to(dt), (gw.reshape(weights.shape).to(dt) if ctx.has_w else None)
 
 
 def solve_fundamental8(samples, weights=None):

@@ -65,6 +65,85 @@ def allreduce_mean_(grads, dist=None) -> None:
         off += g.numel()
 
 
+class AsyncGradientBucket:
+    """The training step's collective, issued asynchronously (what DDP does under train.py:150-175, per-pair loop
+    model_cl.py:488): one flat gradient bucket, all-reduced SUM -> mean over the ranks.
+
+    `launch()` -- called right after the backward of step i has been enqueued -- hands the bucket to the process group with
+    `async_op=True` and returns at once: with the nccl backend (= RCCL) the collective runs on the communicator's own stream
+    behind the compute stream's work, the compute stream is NOT blocked.  `wait()` -- called where the optimizer would consume
+    the averaged gradient, i.e. AFTER step i + 1's forward + backward have been enqueued -- makes the compute stream (gloo: the
+    host) wait for it, so the collective of step i runs under the kernels of step i + 1.  Two buffers alternate: step i + 1's
+    backward may fill its bucket while step i's is still in flight.  `trace` records ("launch", i) / ("wait", i) in program
+    order (OverlappedStep adds ("enqueued", i)); `exposed_events` holds (start, end) CUDA events around every wait on the
+    compute stream: their elapsed time is the part of the collective the step could not hide."""
+
+    def __init__(self, numel: int, device, dist=None, dtype=torch.float32, fill=None):
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.buf = [torch.zeros(numel, device=device, dtype=dtype) for _ in range(2)]
+        if fill is not None:
+            for b in self.buf:
+                b.copy_(fill)
+        self.work = [None, None]
+        self.issued = 0          # buckets handed to the process group so far
+        self.waited = 0
+        self.trace = []
+        self.exposed_events = []
+        self._cuda = self.buf[0].is_cuda
+
+    def bucket(self) -> torch.Tensor:
+        """The buffer the NEXT launch() will reduce (the backward of the current step writes its gradients here)."""
+        return self.buf[self.issued % 2]
+
+    def launch(self) -> None:
+        i = self.issued
+        if self.dist is not None:
+            self.work[i % 2] = self.dist.all_reduce(self.buf[i % 2], op=self.dist.ReduceOp.SUM, async_op=True)
+        self.trace.append(("launch", i))
+        self.issued += 1
+
+    def wait(self):
+        """Wait for the oldest bucket in flight (no-op when none is); returns the averaged bucket or None."""
+        if self.waited >= self.issued:
+            return None
+        i = self.waited
+        ev = None
+        if self._cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if self.work[i % 2] is not None:
+            self.work[i % 2].wait()
+            self.work[i % 2] = None
+            self.buf[i % 2] /= self.dist.get_world_size()
+        if ev is not None:
+            ev[1].record()
+            self.exposed_events.append(ev)
+        self.trace.append(("wait", i))
+        self.waited += 1
+        return self.buf[i % 2]
+
+    def drain(self) -> None:
+        while self.waited < self.issued:
+            self.wait()
+
+
+class OverlappedStep:
+    """step i = [enqueue forward + backward of step i] -> [wait for bucket i - 1: the optimizer's read] -> [launch bucket i].
+    The first launch of step i + 1 is therefore enqueued BEFORE the wait on bucket i (tests/test_sharding_gloo.py asserts the
+    order on `bucket.trace`)."""
+
+    def __init__(self, step_fn, bucket: AsyncGradientBucket):
+        self.step_fn, self.bucket, self.n = step_fn, bucket, 0
+
+    def __call__(self):
+        out = self.step_fn()
+        self.bucket.trace.append(("enqueued", self.n))
+        self.bucket.wait()
+        self.bucket.launch()
+        self.n += 1
+        return out
+
+
 def hypothesis_seed(seed: int, rank: int) -> int:
     """Sampler seed of `rank` when the HYPOTHESES of one pair are split over ranks (P < G): every rank must draw a
     different stream.  The in-kernel Philox is keyed by the seed, so distinct seeds are independent streams."""

@@ -69,6 +69,10 @@ int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t 
 int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
                            int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
                            void *stream);
+/* the same in double: `-pr 2 -tr 1` (model_cl.py:164-169; f64 works end to end upstream) */
+int dr_gumbel_topk_bwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B, int N,
+                           int k, const int32_t *idx, const double *lse, const double *a_sel, double *grad_logits,
+                           void *stream);
 
 /* K1, inference variant: the index SET of the Gumbel top-k sampler by top-down (Plackett-Luce) sampling -- k sequential
  * draws without replacement from softmax(logits), which is the distribution of the top-k of logits + iid Gumbel noise
@@ -109,6 +113,19 @@ int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N
 int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
                               int B, int N, int k, int32_t *idx, float *samples, void *stream);
 
+/* K1, index sets only, in-kernel noise, with an optional screening workspace (round 4; GumbelSoftmaxSampler.sample,
+ * samplers/gumbel_sampler.py:25-42, as test mode consumes it: `points[samples != 0]`, ransac.py:65).
+ * screen_ws: (N + 1) * P 32-bit words of device memory, 16-byte aligned, or NULL (then = dr_gumbel_topk_fwd_f32 with
+ * y_sel = lse = NULL).  With a workspace, rows longer than the register kernel holds (N > 2048, N % 4 == 0, tau == 1, k <= 5)
+ * are SCREENED: one pass over the pair's logits writes, per point, the smallest Philox word that can still lift the point to the
+ * score T = logsumexp(logits) - ln(20 + k) (rounded down); a step of a wave (256 points) in which no word reaches its
+ * threshold is skipped after Philox + four integer compares -- no Gumbel transform, no logits, no list update.  Steps with a
+ * candidate are evaluated in full, so every listed score is exact; a row in which fewer than k evaluated scores reach T
+ * (probability < 1e-7) repeats itself unscreened.  The index sets are those of dr_gumbel_topk_fwd_f32 for the same seed, bit
+ * for bit (tests/test_gpu_round4.py).  seed_dev != NULL: the Philox key is read from device memory (captured graphs). */
+int dr_gumbel_topk_index_f32(const float *logits, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
+                             int32_t *idx, uint32_t *screen_ws, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  straight-through gather          RANSAC.__call__, ransac.py:58-65 (+ :73 weighted)
  *   samples[p,b,j,:] = matches[p, idx[p,b,j], :] * st[p,b,j],  st = (1 - y_sel) + y_sel  (f32 rounding
@@ -123,6 +140,9 @@ int dr_gather_fwd_f64(const double *matches, const int32_t *idx, const double *y
  * grad_matches [P,N,c] (may be NULL) += grad_samples * st  (atomic; caller zeroes it). */
 int dr_gather_bwd_f32(const float *matches, const int32_t *idx, const float *y_sel, const float *grad_samples,
                       const float *grad_w, int P, int N, int B, int k, int c, float *a_sel, float *grad_matches,
+                      void *stream);
+int dr_gather_bwd_f64(const double *matches, const int32_t *idx, const double *y_sel, const double *grad_samples,
+                      const double *grad_w, int P, int N, int B, int k, int c, double *a_sel, double *grad_matches,
                       void *stream);
 
 /* ------------------------------------------------------------------------------------------

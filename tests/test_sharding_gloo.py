@@ -60,11 +60,28 @@ def _worker(rank, world, port, q):
         assert torch.equal(m[:, 0, 0], w.float())
         assert sharding.hypothesis_seed(7, 0) == 7 and sharding.hypothesis_seed(7, 1) != sharding.hypothesis_seed(7, 2)
         # the training step's collective as bench.py --mode train issues it (N > 1): ONE flat bucket = the scores network's
-        # gradient (622 616 f32, the reference CLNet) + the logits gradient of the rank's 32 pairs x 2000 points
+        # gradient (622 616 f32, the reference CLNet).  The per-pair logits gradient is NOT in it: ranks own different pairs, it
+        # continues into each rank's own backward through the network
         net = torch.full((622616,), float(rank + 1))
-        lgrad = torch.full((32, 2000), 3.0 * (rank + 1))
-        sharding.allreduce_mean_([net, lgrad], dist)
-        assert float(net[0]) == 1.5 and float(net[-1]) == 1.5 and float(lgrad[31, 1999]) == 4.5
+        sharding.allreduce_mean_([net], dist)
+        assert float(net[0]) == 1.5 and float(net[-1]) == 1.5
+        # ... and asynchronously, overlapped with the next step: step i + 1's launches are enqueued BEFORE the wait on bucket i
+        bucket = sharding.AsyncGradientBucket(622616, "cpu", dist)
+        seen = []
+
+        def fake_step():                       # stands for the graph replay of forward + backward: fills the bucket to be reduced
+            bucket.bucket().fill_(float((rank + 1) * (len(seen) + 1)))
+            seen.append(len(seen))
+        step = sharding.OverlappedStep(fake_step, bucket)
+        for _ in range(4):
+            step()
+        bucket.drain()
+        tr = bucket.trace
+        for i in range(3):
+            assert tr.index(("enqueued", i + 1)) < tr.index(("wait", i)) < tr.index(("launch", i + 1)), tr
+        assert tr.index(("launch", 0)) < tr.index(("enqueued", 1)) and ("wait", 3) in tr
+        # the averaged values: bucket i held (rank + 1) * (i + 1) -> mean over two ranks = 1.5 (i + 1); buffers alternate
+        assert float(bucket.buf[1][0]) == 1.5 * 4 and float(bucket.buf[0][-1]) == 1.5 * 3
         one = torch.ones(1)
         dist.all_reduce(one)                       # bench.py's n_ranks_seen
         assert int(one.item()) == world
