@@ -527,47 +527,63 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 // The k winners of a row are its k largest logit_n + G_n, and G_n is a monotone function of the Philox word w_n: "score >= T" is
 // "w_n >= tb_n" with a per-point word tb_n that depends on the pair's logits only.  T = logsumexp(logits) - ln(lambda) puts
 // Poisson(lambda) such points into a row.  tb_n is rounded DOWN (score >= T - margin, four roundings of the 24-bit conversion),
-// so no point that reaches T is ever missed; T itself only sets the expected count -- it may be approximate, but every block
-// must derive the SAME value (same reduction order), because the sampler compares exactly evaluated scores with it.
-// One launch: every block re-derives T from the whole row of logits (L2 hits) and writes the words of its own 1024 points.
+// so no point that reaches T is ever missed; T itself only sets the expected count -- it may be approximate (f32 log-sum-exp),
+// but words and sampler must use the SAME value: it is computed once per pair and read back by both.
 constexpr float kScreenMargin = 1e-3f;   // the device logarithms are good to ~1e-6
-__global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restrict__ logits, int N, float lambda,
-                                                           uint32_t *__restrict__ tb, float *__restrict__ T_out) {
-  __shared__ float s_red[256];
-  const int p = blockIdx.y, tid = threadIdx.x;
-  const float *l = logits + (size_t)p * N;
-  float mx = -INFINITY;
-  for (int n = tid; n < N; n += 256) mx = fmaxf(mx, l[n]);
-  s_red[tid] = mx;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]);
-    __syncthreads();
+// (a) T per pair: one 1024-thread block, ONE pass (online max / sum), four logits per load, every load of a thread in flight at
+//     once for rows up to 64 K points -- the pass is one memory round trip + a block reduction (first version: every block of
+//     the word kernel re-derived T from the whole row, 40 us at 50 000 points)
+__global__ __launch_bounds__(1024) void gumbel_screen_T_kernel(const float *__restrict__ logits, int N, float lambda,
+                                                               float *__restrict__ T_out) {
+  __shared__ float s_mx[16], s_sm[16];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float4 *l4 = reinterpret_cast<const float4 *>(logits + (size_t)p * N);   // N % 4 == 0 (the long-row kernel's condition)
+  const int groups = N >> 2;
+  float mx = -INFINITY, sm = 0.f;
+  for (int q0 = tid; q0 < groups; q0 += 16 * 1024) {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int q = q0 + u * 1024;
+      v[u] = q < groups ? l4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float m4 = fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w));
+      if (m4 > mx) { sm *= __expf(mx - m4); mx = m4; }
+      if (mx > -INFINITY) sm += (__expf(v[u].x - mx) + __expf(v[u].y - mx)) + (__expf(v[u].z - mx) + __expf(v[u].w - mx));
+    }
   }
-  mx = s_red[0];
+  const float wmx = row_max(mx);
+  sm *= (mx == -INFINITY) ? 0.f : __expf(mx - wmx);
+  sm = row_sum(sm);
+  if (lane == 0) { s_mx[wv] = wmx; s_sm[wv] = sm; }
   __syncthreads();
-  float sm = 0.f;
-  for (int n = tid; n < N; n += 256) sm += __expf(l[n] - mx);
-  s_red[tid] = sm;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) s_red[tid] += s_red[tid + o];
-    __syncthreads();
+  if (tid == 0) {
+    float bm = s_mx[0];
+    for (int w = 1; w < 16; ++w) bm = fmaxf(bm, s_mx[w]);
+    float bs = 0.f;
+    for (int w = 0; w < 16; ++w) bs += (s_mx[w] == -INFINITY) ? 0.f : s_sm[w] * __expf(s_mx[w] - bm);
+    float Tf = bm + __logf(bs) - __logf(lambda);
+    if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY) Tf = INFINITY;   // non-finite logits: no point passes, every row takes the full pass
+    T_out[p] = Tf;
   }
-  float Tf = mx + __logf(s_red[0]) - __logf(lambda);
-  if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY) Tf = INFINITY;   // non-finite logits: no point passes, every row takes the full pass
-  if (blockIdx.x == 0 && tid == 0) T_out[p] = Tf;
+}
+// (b) the words: one point per thread
+__global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restrict__ logits, int N, const float *__restrict__ T_in,
+                                                           uint32_t *__restrict__ tb) {
+  const int p = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float Tf = T_in[p];
   constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);
-  for (int n = blockIdx.x * 1024 + tid; n < min(N, (int)(blockIdx.x + 1) * 1024); n += 256) {
-    // G >= a  <=>  u >= exp(-exp(-a)),  u = fl(fl24(w) * 2^-32 c + tiny)  (gumbel_from_bits),  a = T - margin - logit_n
-    const double a = ((double)Tf - (double)kScreenMargin) - (double)l[n];
-    const double e = exp(-a);
-    const double us = (e < 745.0) ? exp(-e) : 0.0;
-    double w = floor((us - kTiny) / kScale) - 1024.0;
-    if (!(w == w)) w = 0.0;
-    w = fmin(fmax(w, 0.0), 4294967295.0);
-    tb[(size_t)p * N + n] = (Tf == INFINITY) ? 0xffffffffu : (uint32_t)w;
-  }
+  // G >= a  <=>  u >= exp(-exp(-a)),  u = fl(fl24(w) * 2^-32 c + tiny)  (gumbel_from_bits),  a = T - margin - logit_n
+  const double a = ((double)Tf - (double)kScreenMargin) - (double)logits[(size_t)p * N + n];
+  const double e = exp(-a);
+  const double us = (e < 745.0) ? exp(-e) : 0.0;
+  double w = floor((us - kTiny) / kScale) - 1024.0;
+  if (!(w == w)) w = 0.0;
+  w = fmin(fmax(w, 0.0), 4294967295.0);
+  tb[(size_t)p * N + n] = (Tf == INFINITY) ? 0xffffffffu : (uint32_t)w;
 }
 
 // ---- rows longer than the register kernel holds (N > 2048): ONE pass ----------------------------------------------------
@@ -814,8 +830,8 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
       if (screen_ws && !soft) {
         // workspace: P x N words + P scores; lambda = 20 + k: P(fewer than k of a row's points reach T) < 1e-7
         float *Tw = reinterpret_cast<float *>(screen_ws + (size_t)P * N);
-        hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 1023) / 1024, P), dim3(256), 0, st, (const float *)logits, N, (float)(20 + k),
-                           screen_ws, Tw);
+        hipLaunchKernelGGL(gumbel_screen_T_kernel, dim3(P), dim3(1024), 0, st, (const float *)logits, N, (float)(20 + k), Tw);
+        hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 255) / 256, P), dim3(256), 0, st, (const float *)logits, N, Tw, screen_ws);
         tb = screen_ws;
         Tp = Tw;
       }

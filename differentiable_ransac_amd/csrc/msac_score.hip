@@ -395,7 +395,10 @@ __device__ __forceinline__ uint4 msac_eval16(const v2f (&x1)[8], const v2f (&y1)
 // bound with 8-byte stores.  Requires N % 16 == 0 (otherwise the 8-point kernel above is used).
 // A 256-thread block is two independent 128-thread halves, each with its own 64-slot model tile (nothing shared but the
 // workgroup slot): a CU holds at most 8 workgroups, i.e. 16 waves of 128-thread blocks = 4 waves per SIMD.
-constexpr int kH16 = 128, kHalves = 2, kT16 = kH16 * kHalves, kP16 = 16, kChunk16 = kH16 * kP16;
+// tile_slots = model slots per half: 64 when the (pair x tile) grid fills the chip; 16 for calls with few pairs (the reference calls the
+// path ONE pair at a time, model_cl.py:488-490: 10 240 slots are 80 workgroups of 64-slot halves on 256 CUs -- 34.6 us per
+// launch, each wave alone on its SIMD with the scalar-cache round trip of every model exposed; 16-slot halves are 320 workgroups)
+constexpr int kH16 = 128, kHalves = 2, kT16 = kH16 * kHalves, kP16 = 16, kChunk16 = kH16 * kP16, kSmallGridTile = 16;
 
 __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float *__restrict__ matches,
                                                                      const float *__restrict__ models,
@@ -403,16 +406,18 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
                                                                      const float *__restrict__ thr, int M, int N,
                                                                      float *__restrict__ scores,
                                                                      uint8_t *__restrict__ masks, int write_masks,
-                                                                     int chunks_per_block, int use_atomic) {
-  constexpr int kTile = kFastTile;
+                                                                     int chunks_per_block, int use_atomic, int tile_slots) {
+  // tile_slots <= kTile: the slots a half actually owns (64, or 16 for grids that would not fill the chip); the kernel is the
+  // same either way -- a 16-slot half simply has an empty second validity word
+  constexpr int kTile = kFastTile, kWords = kTile / 32;
   __shared__ float part[kT16 / kWave][kTile];
   const int p = blockIdx.z;
   // wave-uniform BY CONSTRUCTION (a half is two whole waves) -- and it must look so to the compiler: with `half` in a VGPR the
   // tile's model coefficients stop being scalar loads and the kernel is 40 % slower
   const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kH16));
-  const int m0 = (blockIdx.x * kHalves + half) * kTile;
+  const int m0 = (blockIdx.x * kHalves + half) * tile_slots;
   const int tid = threadIdx.x % kH16, lane = tid & 63, wv = threadIdx.x >> 6;
-  const int mcount = max(0, min(kTile, M - m0));
+  const int mcount = max(0, min(tile_slots, M - m0));
   const float t = 1.5f * thr[p];
   const float inv_thr2 = 1.0f / (t * t);
   const float *mt = matches + (size_t)p * N * 4;
@@ -433,9 +438,9 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
   }
   // non-finite / all-zero models of the tile are found here, once (lane l looks at slot l), instead of in every wave of
   // every chunk: they leave the evaluated set (empty mask row like an invalid slot) and their score is NaN
-  uint32_t vword[kTile / 32], nanword[kTile / 32];
+  uint32_t vword[kWords], nanword[kWords];
 #pragma unroll
-  for (int w = 0; w < kTile / 32; ++w) {
+  for (int w = 0; w < kWords; ++w) {
     const int ml = 32 * w + (lane & 31);
     const bool v = (ml < mcount) && (!valid || valid[(size_t)p * M + m0 + ml] != 0);
     uint32_t ex = 0, anybit = 0;
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
   __syncthreads();
   if ((wv & 1) == 0 && lane < 32) {
 #pragma unroll
-    for (int w = 0; w < kTile / 32; ++w)
+    for (int w = 0; w < kWords; ++w)
       if ((nanword[w] >> lane) & 1u) part[wv][32 * w + lane] = NAN;
   }
 
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
     }
 
 #pragma unroll 1
-    for (int wd = 0; wd < kTile / 32; ++wd) {
+    for (int wd = 0; wd < kWords; ++wd) {
       uint32_t live = vword[wd];
       if (!live) continue;
       int ml = 32 * wd + __builtin_ctz(live);
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
     // empty mask rows of the invalid slots (store-only)
     if (write_masks && have) {
 #pragma unroll
-      for (int wd = 0; wd < kTile / 32; ++wd) {
+      for (int wd = 0; wd < kWords; ++wd) {
         uint32_t inv = ~vword[wd];
         if (32 * wd + 32 > mcount) inv &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
         while (inv) {
@@ -839,7 +844,9 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
   }
   // (16-byte mask stores: whole rows and a 16-byte aligned base -- a caller may pass a slice of a larger buffer)
   const bool fast16 = kFast && (N % 16 == 0) && (reinterpret_cast<uintptr_t>(masks) % 16 == 0);
-  const int tile = fast16 ? kFastTile * kHalves : (kFast ? kFastTile : kModelsPerBlock);
+  // few pairs: 16-slot halves so that the grid covers the chip (one-pair calls)
+  const bool small_grid = fast16 && (long)P * ((M + kFastTile * kHalves - 1) / (kFastTile * kHalves)) < 512;   // measured: 10.6 us per pair at 3 pairs (16-slot) against 12.4 at 4 pairs (64-slot)
+  const int tile = fast16 ? (small_grid ? kSmallGridTile : kFastTile) * kHalves : (kFast ? kFastTile : kModelsPerBlock);
   const int tiles = (M + tile - 1) / tile;
   const int chunks = (N + kChunk - 1) / kChunk;   // kChunk16 == kChunk
   // split the point range over blocks only when the (pair x model-tile) grid cannot fill the chip
@@ -857,7 +864,7 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
     if (fast16) {
       hipLaunchKernelGGL(msac_score_kernel_f32_fast16, grid, dim3(kT16), 0, st, (const float *)matches,
                          (const float *)models, valid, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0,
-                         cpb, use_atomic);
+                         cpb, use_atomic, small_grid ? kSmallGridTile : kFastTile);
       return check_launch("msac_score_kernel");
     }
     hipLaunchKernelGGL(msac_score_kernel_f32_fast, grid, dim3(kThreads), 0, st, (const float *)matches,

@@ -233,6 +233,9 @@ __global__ __launch_bounds__(kRThreads) void rigid_residual_kernel(const T *__re
 constexpr int kR16Threads = 128, kR16Pts = 16, kR16Chunk = kR16Threads * kR16Pts, kR16MaxTile = 64;
 typedef float v2r __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2r rsplat(float a) { return (v2r){a, a}; }
+#ifndef DR_K4R_GROUP
+#define DR_K4R_GROUP 4   // models whose coefficients are requested from the scalar cache together
+#endif
 #ifndef DR_K4R_WAVES
 #define DR_K4R_WAVES 0   // > 0: register budget pinned to that many waves per SIMD (A/B builds; 4 spills two point registers)
 #endif
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
     // models in groups of kGroup: the 12 coefficients of all of them are requested from the scalar cache together (one
     // round trip per group instead of one per model: the compiler puts `s_waitcnt lgkmcnt(0)` right behind any s_load whose
     // destination shares an SGPR pair with a live splat operand, so a hand-written "prefetch the next model" is not one)
-    constexpr int kGroup = 4;
+    constexpr int kGroup = DR_K4R_GROUP;
 #pragma unroll 1
     for (int mg = 0; mg < mcount; mg += kGroup) {
       float mm[kGroup][12];
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
         float acc = acc2[0] + acc2[1];
         if (have && live) *reinterpret_cast<uint4 *>(mrow + (size_t)ml * N + (uint32_t)n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
         acc = wave_sum_lane63(have ? acc : 0.f);
-        if (lane == 63 && live) part[wv][ml] += acc;     // wave-private slot: plain read-modify-write
+        if (lane == 63 && live) atomicAdd(&part[wv][ml], acc);   // ds_add_f32, no return: the wave does not wait for its own LDS round trip (the plain += was a ds_read + s_waitcnt + ds_write per model)
       }
     }
   }
