@@ -312,8 +312,8 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
         # launch-bound steps (config 1: 0.05 ms of device time in six launches) gain from the replay, device-bound ones lose a
         # few per cent to the graph's inter-node barriers.  The sub-record always carries BOTH figures, labelled; which one
         # `ms_per_step` quotes is fixed per config (not the minimum of the two): the replay for the launch-bound c1 and for
-        # one-pair calls, the eager issue for the device-bound others
-        if key == "c1" or w["pairs"] == 1:
+        # the one-pair call of c2, the eager issue for the device-bound others
+        if key == "c1" or (key == "c2" and w["pairs"] == 1):
             seg_ms, issue = graph_ms, "HIP graph replay of the whole step (differentiable_ransac_amd.graphs.GraphedStep)"
     el, steps = sorted(seg_ms)[1] * 1e-3 * seg, seg
     calls = per_call_breakdown(step)
@@ -894,10 +894,12 @@ def main():
                                   "frac": bytes_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "note": "same launch, one stream, nothing else resident"},
                      "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                     "what_bounds_it": ("vector ALU issue: SQ_ACTIVE_INST_VALU = 0.83-0.87 of the kernel's cycles on every SIMD at "
-                                        "this shape, 211 vector instructions per (model, 16 points per lane) of which 152 are the "
-                                        "residual's packed FMAs / multiplies; the write path is not backed up "
-                                        "(profiles/r3_k4_counters_p128.md: counters + ISA budget of the shipped library)"
+                     "what_bounds_it": ("the f32 vector ALU under the chip's power budget: SQ_ACTIVE_INST_VALU = 0.84-0.88 of the "
+                                        "kernel's cycles at 1.87-2.15 GHz effective (2.4 nominal), 211 vector instructions per (model, 16 "
+                                        "points per lane) of which 152 are the residual's packed FMAs / multiplies; the write path is not "
+                                        "backed up.  A variant with the points streamed from LDS at 6-8 waves per SIMD issues 0.89 of the "
+                                        "cycles, needs 9 % fewer of them and is 12 % SLOWER in the step: the chip clocks 7 % lower under it "
+                                        "(profiles/r4_k4_lds_variants.md; counters + ISA budget: profiles/r3_k4_counters_p128.md)"
                                         if (not rigid and P >= 64) else None),
                      "valu_tflops": flops_per_launch / (iso_ms * 1e-3) / 1e12,
                      "valu_frac_of_157.3": flops_per_launch / (iso_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
