@@ -45,7 +45,9 @@ const char *dr_last_error(void);
  *
  *   g[p,b,n] = (logits[p,n] + gumbel[p,b,n]) / tau ; y = softmax_n(g) ; idx = top-k_n(g).
  *   gumbel == NULL  -> noise generated in-kernel: Philox4x32-7(key = seed, counter = (n/4, b, p, 0)),
- *                      lane n%4, u = tiny + u24*(1-eps-tiny), gumbel = -log(-log u);
+ *                      word n%4 of the call = w; u = fl(float(w) * 2^-32 (1-eps-tiny) + tiny) (the u32 -> f32 conversion rounds
+ *                      w to 24 significant bits: torch's tiny + rand * (1-eps-tiny) with rand on the 2^-24 grid),
+ *                      gumbel = -ln2 * log2(-log2 u) - ln ln 2 = -log(-log u), rounded to an f32 VALUE before it meets the logit;
  *   gumbel != NULL  -> explicit noise [P,B,N] (parity mode: index sets are bit-exact w.r.t. the reference).
  *   Outputs: idx [P,B,k] int32, ASCENDING point index (= the order `points[samples != 0]` yields,
  *   ransac.py:65); y_sel [P,B,k] = y at idx; lse [P,B] = log-sum-exp of g (so y = exp(g - lse));
