@@ -130,3 +130,25 @@ def test_philox_restatement_known_answers():
     w = R.philox4x32(77, np.arange(1 << 14, dtype=np.uint32), 3, 1, 0)
     u = np.concatenate([(x >> np.uint32(8)).astype(np.float64) for x in w]) / 2.0 ** 24
     assert abs(u.mean() - 0.5) < 0.005 and abs(u.var() - 1 / 12) < 0.002
+
+
+def test_async_gradient_bucket_without_a_process_group_is_a_no_op_pipeline():
+    """single process (N = 1): the bucket does no collective but keeps the same program order -- step i + 1 is enqueued before
+    the wait on bucket i, buffers alternate, drain() empties the pipeline"""
+    import torch
+    from differentiable_ransac_amd import sharding
+    b = sharding.AsyncGradientBucket(8, "cpu", None)
+    seen = []
+
+    def step():
+        b.bucket().fill_(float(len(seen) + 1))
+        seen.append(len(seen))
+    s = sharding.OverlappedStep(step, b)
+    for _ in range(3):
+        s()
+    b.drain()
+    tr = b.trace
+    assert tr == [("enqueued", 0), ("launch", 0), ("enqueued", 1), ("wait", 0), ("launch", 1), ("enqueued", 2), ("wait", 1),
+                  ("launch", 2), ("wait", 2)]
+    assert float(b.buf[0][0]) == 3.0 and float(b.buf[1][0]) == 2.0 and b.exposed_events == []
+    assert b.wait() is None
