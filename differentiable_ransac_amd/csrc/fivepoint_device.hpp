@@ -924,6 +924,11 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
   }
   double roots[10];
   int nroots;
+  if (!active) {   // a lane pair without a sample (partial block, or fewer samples per block): 1 + z^10 -- no real root in either
+                   // half of the search, hence no bracket in the wave's task queues
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) cs[i] = (i == 0 || i == 10) ? 1.0 : 0.0;
+  }
   DR_STAGE_BEGIN();
 #if DR_K3_WAVE_ROOTS
 #if DR_K3_STURM

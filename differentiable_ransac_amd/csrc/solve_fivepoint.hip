@@ -58,11 +58,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void nister5_pair_kernel(
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models,
-    uint8_t *__restrict__ valid, double *__restrict__ models64) {
+    uint8_t *__restrict__ valid, double *__restrict__ models64, int spb) {
+  // spb = samples per block: 32 when the grid fills the chip.  Calls with few samples (one pair = 1024 samples = 32 blocks on
+  // 1024 SIMDs) run 16 / 8 / 4 samples per block instead: the lane pairs beyond spb hold no sample, queue no bracket and no
+  // candidate, so the wave's task rounds (refine, polish, verification) shrink with spb while the per-lane stages cost what they
+  // cost -- the block's latency is what a one-pair call waits for (round 4)
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
-  const int s = blockIdx.x * 32 + (lane >> 1);
-  const bool active = s < Bt;
+  const int s = blockIdx.x * spb + (lane >> 1);
+  const bool active = (lane >> 1) < spb && s < Bt;
   const int sc = active ? s : Bt - 1;
   LaneWs w{lds + (lane >> 1), 32};
   const T *pts = samples + (size_t)sc * 20;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
   const bool ok = constraints_reduce<NisterOrder, 4, DR_K3_BALANCED != 0>(e, w, 1.0, X, lane & 1);
   DR_STAGE(2);
 #if DR_K3_BALANCED
-  nister_finish_pair<T>(nb, X, ok, lds, lane, (size_t)blockIdx.x * 32, active, models, valid, models64);
+  nister_finish_pair<T>(nb, X, ok, lds, lane, (size_t)blockIdx.x * spb, active, models, valid, models64);
 #else
   nister_finish<T, true>(nb, X, ok, models + (size_t)sc * 90, valid + (size_t)sc * 10, active, lane & 1,
                          models64 ? models64 + (size_t)sc * 90 : nullptr);
@@ -95,12 +99,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
 // lanes share one sample and each takes one half of the root search.
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void stewenius5_pair_kernel(
-    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid) {
+    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, int spb) {
+  // spb = samples per block (32, or 16 / 8 / 4 on small grids): see nister5_pair_kernel
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   const int half = lane & 1;
-  const int s = blockIdx.x * 32 + (lane >> 1);
-  const bool active = s < Bt;
+  const int s = blockIdx.x * spb + (lane >> 1);
+  const bool active = (lane >> 1) < spb && s < Bt;
   const int sc = active ? s : Bt - 1;
   LaneWs w{lds + (lane >> 1), 32};
   double nb[4][9];
@@ -193,6 +198,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
   }
   double roots[10];
   int nroots;
+  if (!active) {   // no sample in this lane pair: 1 + z^10, no real root in either half of the search, no bracket in the queues
+#pragma unroll
+    for (int t = 0; t <= 10; ++t) cs[t] = (t == 0 || t == 10) ? 1.0 : 0.0;
+  }
 #if DR_K3_WAVE_ROOTS
 #if DR_K3_STURM
   real_roots_half_sturm<10>(cs, half != 0, roots, nroots, lds, lane);   // the right block's LDS is free again
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
     xs[i] = x; ys[i] = y; zs[i] = z;
     if (has && solvable && is_finite(y) && is_finite(z)) cand |= 1u << i;
   }
-  balanced_finish<T>(fq, lane, nroots, xs, ys, zs, cand, (size_t)blockIdx.x * 32, active, models, valid, nullptr);
+  balanced_finish<T>(fq, lane, nroots, xs, ys, zs, cand, (size_t)blockIdx.x * spb, active, models, valid, nullptr);
 #else
     const int dst_slot = half ? 9 - slot : slot;
     const bool good = finish_solution<T>(nb, x, y, z, has && solvable && is_finite(y) && is_finite(z) && slot < 10,
@@ -305,6 +314,22 @@ static inline bool aligned_out(const void *models, const void *valid) {
   return !DR_K3_STAGE_OUT || ((reinterpret_cast<uintptr_t>(models) & 15u) == 0 && (reinterpret_cast<uintptr_t>(valid) & 3u) == 0);
 }
 
+// samples per 64-lane block of the two-lanes-per-sample kernels: 32, or fewer (down to 4) while the grid stays within one block
+// per SIMD -- a one-pair call (1024 samples) is 256 blocks of 4 samples instead of 32 blocks of 32 on 1024 SIMDs
+static inline int samples_per_block(int Bt) {
+  int spb = 32;
+#if DR_K3_BALANCED
+  static int simds = 0;
+  if (!simds) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    simds = 4 * (cus > 0 ? cus : 256);
+  }
+  while (spb > 4 && (long)(Bt + spb / 2 - 1) / (spb / 2) <= simds) spb /= 2;
+#endif
+  return spb;
+}
+
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st,
                   double *models64 = nullptr) {
@@ -320,8 +345,9 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
     // minimal samples: two lanes per sample; LDS per 32-sample block: 100 doubles per sample for the constraint solve,
     // later basis + B(z) / candidate queue + root-search workspace (36.5 KiB => four blocks per CU, one per SIMD)
     const size_t smem = sizeof(double) * (DR_K3_BALANCED ? kNisterPairDoubles : 100 * 32);
-    hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, weights, Bt, models,
-                       valid, models64);
+    const int spb = samples_per_block(Bt);
+    hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, weights, Bt, models,
+                       valid, models64, spb);
     return check_launch("nister5_pair_kernel");
   }
   // n > 5 fallback (refit): one lane per sample, A^T A + eigenvectors in LDS (162 doubles)
@@ -337,7 +363,8 @@ int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStr
   constexpr int kDoubles = (DR_K3_BALANCED && FinishQueue::kDoubles > 100 * 32) ? FinishQueue::kDoubles : 100 * 32;
   static_assert(!DR_K3_WAVE_ROOTS || (RootWs<10>::kDoubles <= kDoubles && SturmWs<10>::kDoubles <= kDoubles), "root-search workspace");
   const size_t smem = sizeof(double) * kDoubles;
-  hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + 31) / 32), dim3(64), smem, st, samples, Bt, models, valid);
+  const int spb = samples_per_block(Bt);
+  hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, Bt, models, valid, spb);
   return check_launch("stewenius5_pair_kernel");
 }
 

@@ -195,3 +195,25 @@ def test_f64_five_point_backward_equals_the_f32_path_to_rounding(dev):
     assert torch.isfinite(b).all()
     # the same tangent-space solve on f32-rounded inputs either way: agreement to a few 1e-4 of the gradient's scale
     assert (a - b).abs().max() <= 5e-3 * max(1.0, float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------- K3, few samples per block on small grids
+@pytest.mark.parametrize("nsmp", [1024, 100, 4096, 3])
+def test_five_point_solver_with_few_samples_per_block_equals_the_full_blocks(dev, nsmp):
+    """calls with few samples run 16 / 8 / 4 samples per 64-lane block (latency of a one-pair call); a sample's solutions do not
+    depend on the block it shares: the same samples inside a large batch (32 per block) come out bit-identical, f32 and f64 models"""
+    from differentiable_ransac_amd import ops, synth
+    d = synth.batch_two_view(1, 2000, seed0=9)
+    r = ops.gumbel_topk(d["logits"].to(dev), nsmp, 5, 1.0, None, seed=3, soft=False)
+    smp = ops.gather(d["matches"].to(dev), r["idx"])[0]                 # [nsmp, 5, 4]
+    m_s, v_s = ops.solve_nister5(smp)
+    big = torch.cat([smp, smp.flip(0).repeat(1 + 40000 // nsmp, 1, 1)])
+    m_b, v_b = ops.solve_nister5(big)
+    assert torch.equal(v_s, v_b[:nsmp]) and torch.equal(m_s, m_b[:nsmp])
+    assert int(v_s.sum()) > 2 * nsmp or nsmp < 10
+    mh, m64, vh = ops.solve_nister5_hp(smp)
+    mhb, m64b, vhb = ops.solve_nister5_hp(big)
+    assert torch.equal(mh, mhb[:nsmp]) and torch.equal(m64, m64b[:nsmp]) and torch.equal(vh, vhb[:nsmp])
+    ms, vs = ops.solve_stewenius5(smp)
+    msb, vsb = ops.solve_stewenius5(big)
+    assert torch.equal(ms, msb[:nsmp]) and torch.equal(vs, vsb[:nsmp])
