@@ -49,3 +49,31 @@ def test_algorithmic_bytes_match_the_survey():
     # K4r (C4): 24 N + 48 M + 4 M + 4 + M N = 103.7 MB
     assert abs(bench.k4r_bytes(1, 50000, 2048) / 1e6 - 103.7) < 0.1
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_committed_bench_line_carries_the_contract_fields_and_the_round4_records():
+    """the line the end-of-round script stored (profiles/r4_bench_line.json = `python bench.py` on the GPU box): every field the
+    driver's contract names, the roofline / cpu_baseline objects, and the sub-records the round-3 review asked the driver to see"""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "hypotheses/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None and r["binding_unit"] == "valu_f32"
+    # achieved = algorithmic bytes per launch / the launch's HIP-event duration; the duration fits inside the step
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert r["avg_launch_ms"] < d["ms_per_step"] and 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    cfg = d["configs"]
+    for k in ("c1", "c3", "c4", "c2_p32", "c2_p1", "c5_train_p32"):
+        assert k in cfg and cfg[k]["ms_per_step"] > 0, k
+    assert cfg["c2_p1"]["ms_per_step"] <= 0.12                      # the review's bar for the one-pair call
+    assert {"dr_gumbel_topk_bwd_f32", "dr_episym_bwd_mean_f32", "dr_solve_nister5_bwd_sel_f32"} <= set(cfg["c5_train_p32"]["launch_ms"])
+    f = d["fused_driver"]["scoring_roofline"]
+    assert f["bytes_formula"] == "P (16 N + 40 M + N)" and f["algorithmic_bytes_per_launch"] == 128 * (16 * 2000 + 40 * 10240 + 2000)
+    a = d["k4_all_valid"]
+    assert a["all_slots_valid"]["evaluated_slot_fraction"] == 1.0 and a["all_slots_valid"]["hbm_frac"] < r["frac"]
