@@ -10,25 +10,35 @@ template <typename T>
 __global__ __launch_bounds__(64) void rigid_kernel(const T *__restrict__ samples, const T *__restrict__ weights,
                                                    int Bt, int n, int flag, T *__restrict__ models,
                                                    T *__restrict__ Rout, T *__restrict__ tout, T *__restrict__ sout,
-                                                   uint8_t *__restrict__ valid) {
+                                                   uint8_t *__restrict__ valid, const int32_t *__restrict__ gidx = nullptr,
+                                                   int gB = 0, int gN = 0, T *__restrict__ zero_sums = nullptr) {
+  // gidx != NULL (round 4, K2 fused): `samples` is the pair's correspondence array [P, gN, 6] and row r of sample s is
+  // matches[s / gB, gidx[s n + r]] -- the gather launch and the [Bt, n, 6] tensor disappear.  zero_sums != NULL: entry s of the
+  // residual sums is cleared here, so that the residual kernel that follows can accumulate without a memset launch.
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= Bt) return;
-  const T *pts = samples + (size_t)s * n * 6;
+  if (zero_sums) zero_sums[s] = T(0);
+  const T *base = gidx ? samples + (size_t)(s / gB) * gN * 6 : samples + (size_t)s * n * 6;
+  const int32_t *gi = gidx ? gidx + (size_t)s * n : nullptr;
+  auto rowp = [&](int r) -> const T * { return gi ? base + (size_t)gi[r] * 6 : base + 6 * r; };
   const T *wts = weights ? weights + (size_t)s * n : nullptr;
   double c[6] = {0, 0, 0, 0, 0, 0};
-  for (int r = 0; r < n; ++r)
+  for (int r = 0; r < n; ++r) {
+    const T *pts = rowp(r);
 #pragma unroll
-    for (int d = 0; d < 6; ++d) c[d] += (double)pts[6 * r + d];
+    for (int d = 0; d < 6; ++d) c[d] += (double)pts[d];
+  }
 #pragma unroll
   for (int d = 0; d < 6; ++d) c[d] /= (double)n;
   double a0 = 0, a1 = 0;
   double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   for (int r = 0; r < n; ++r) {
+    const T *pts = rowp(r);
     double dp[3], dq[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      dp[d] = (double)pts[6 * r + d] - c[d];
-      dq[d] = (double)pts[6 * r + 3 + d] - c[3 + d];
+      dp[d] = (double)pts[d] - c[d];
+      dq[d] = (double)pts[3 + d] - c[3 + d];
     }
     a0 += sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
     a1 += sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
 
 template <typename T>
 int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int M, int N, T *res_sum, uint8_t *masks,
-                          hipStream_t st) {
+                          hipStream_t st, bool sums_zeroed = false) {
   if constexpr (sizeof(T) == 4) {
     // (thresholds below 1e-12 would put `thr - d2` near the bit-6 exponent test's blind spot: general kernel)
     if (DR_K4R_16 && masks && N % 16 == 0 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0 && threshold > T(1e-12)) {
@@ -379,8 +389,8 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
       }
       const int tiles = (M + tile - 1) / tile;
       const int cpb = 1;
-      const int use_atomic = ny > 1;
-      if (use_atomic && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
+      const int use_atomic = ny > 1 || sums_zeroed;   // (pre-zeroed sums are added to, never stored over)
+      if (use_atomic && !sums_zeroed && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
       hipLaunchKernelGGL(rigid_residual_kernel_f32_16, dim3(tiles, ny, P), dim3(kR16Threads), 0, st, (const float *)pts,
                          (const float *)models, (float)threshold, M, N, (float *)res_sum, masks, cpb, use_atomic, tile);
       return check_launch("rigid_residual_kernel_f32_16");
@@ -393,8 +403,8 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
   if (chunks > 1 && base < 2048) ny = (int)min((long)chunks, (2048 + base - 1) / base);
   const int cpb = (chunks + ny - 1) / ny;
   ny = (chunks + cpb - 1) / cpb;
-  const int use_atomic = ny > 1;
-  if (use_atomic && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess)
+  const int use_atomic = ny > 1 || sums_zeroed;
+  if (use_atomic && !sums_zeroed && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess)
     return check_launch("memset");
   dim3 grid(tiles, ny, P);
   if (masks)
@@ -581,6 +591,26 @@ int dr_solve_rigid_f64(const double *samples, const double *weights, int Bt, int
   hipLaunchKernelGGL((dr::rigid_kernel<double>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, samples,
                      weights, Bt, n, flag, models, R, t, scale, valid);
   return dr::check_launch("rigid_kernel");
+}
+
+// K2 + K3r in one launch (test mode of the 3-D driver): samples are read through the index sets, and (optionally) the residual
+// sums of the round are cleared on the way, so that dr_rigid_residual_acc_f32 needs no memset launch
+int dr_solve_rigid_gather_f32(const float *matches, const int32_t *idx, int P, int B, int N, int k, int flag, float *models,
+                              float *R, float *t, float *scale, uint8_t *valid, float *zero_sums, void *stream) {
+  DR_REQUIRE(matches && idx && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && N > 0 && k >= 3 && (long)P * B < (1l << 31), "need P, B, N > 0 and k >= 3 correspondences per sample");
+  const int Bt = P * B;
+  hipLaunchKernelGGL((dr::rigid_kernel<float>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, matches,
+                     (const float *)nullptr, Bt, k, flag, models, R, t, scale, valid, idx, B, N, zero_sums);
+  return dr::check_launch("rigid_kernel");
+}
+
+// dr_rigid_residual_f32 with the sums ADDED to res_sum, which the caller (or dr_solve_rigid_gather_f32) has cleared
+int dr_rigid_residual_acc_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
+                              float *res_sum, uint8_t *masks, void *stream) {
+  DR_REQUIRE(pts && models && res_sum, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  return dr::rigid_residual_launch<float>(pts, models, threshold, P, M, N, res_sum, masks, (hipStream_t)stream, true);
 }
 
 int dr_rigid_residual_f32(const float *pts, const float *models, float threshold, int P, int M, int N,

@@ -418,12 +418,35 @@ def solve_rigid(samples: torch.Tensor, weights: Optional[torch.Tensor] = None, f
             valid.reshape(lead))
 
 
-def rigid_residual(pts: torch.Tensor, models: torch.Tensor, threshold: float = 0.03, want_masks: bool = True):
-    """pts [P,N,6], models [P,M,4,4] -> res_sum [P,M], masks [P,M,N] bool | None."""
+def solve_rigid_gather(matches: torch.Tensor, idx: torch.Tensor, flag: bool = True, zero_sums: Optional[torch.Tensor] = None):
+    """K2 + K3r in one launch (f32): matches [P,N,6], idx [P,B,k] int32 -> (model [P,B,4,4], valid [P,B] bool), the samples read
+    through the index sets; zero_sums [P,B] (optional) is cleared by the same launch (the residual sums of the round:
+    rigid_residual(..., res=zero_sums) then needs no memset)."""
+    if matches.dtype != torch.float32 or matches.shape[-1] != 6:
+        raise L.DransacError("solve_rigid_gather: f32 correspondences [P,N,6]")
+    P, N, _ = matches.shape
+    _, B, k = idx.shape
+    model = torch.empty((P, B, 4, 4), device=matches.device, dtype=torch.float32)
+    valid = torch.empty((P, B), device=matches.device, dtype=torch.bool)
+    L.call("dr_solve_rigid_gather_f32", ptr(matches.contiguous()), ptr(idx.contiguous()), c_int(P), c_int(B), c_int(N), c_int(k),
+           c_int(1 if flag else 0), ptr(model), ptr(None), ptr(None), ptr(None), ptr(valid), ptr(zero_sums), stream())
+    return model, valid
+
+
+def rigid_residual(pts: torch.Tensor, models: torch.Tensor, threshold: float = 0.03, want_masks: bool = True,
+                   res: Optional[torch.Tensor] = None):
+    """pts [P,N,6], models [P,M,4,4] -> res_sum [P,M], masks [P,M,N] bool | None.
+    res (f32, optional): a [P,M] tensor of ZEROS to add the sums to (no memset launch): solve_rigid_gather(..., zero_sums=res)."""
     P, N, _ = pts.shape
     M = models.shape[1]
-    res = torch.empty((P, M), device=pts.device, dtype=pts.dtype)
     masks = torch.empty((P, M, N), device=pts.device, dtype=torch.bool) if want_masks else None
+    if res is not None:
+        if pts.dtype != torch.float32 or res.shape != (P, M) or res.dtype != torch.float32:
+            raise L.DransacError("rigid_residual: res must be an f32 [P,M] tensor of zeros")
+        L.call("dr_rigid_residual_acc_f32", ptr(pts.contiguous()), ptr(models.contiguous()), L.c_float(threshold), c_int(P),
+               c_int(M), c_int(N), ptr(res), ptr(masks), stream())
+        return res, masks
+    res = torch.empty((P, M), device=pts.device, dtype=pts.dtype)
     L.call(f"dr_rigid_residual_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()),
            L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(res), ptr(masks), stream())
     return res, masks

@@ -602,10 +602,16 @@ class BatchedRANSAC3D(object):
             for r in range(rounds):
                 g = None if gumbels is None else gumbels[r]
                 idx = ops.gumbel_topk(logits, self.B, 3, self.tau, g, self._next_seed(), soft=False)["idx"]
-                samples = ops.gather(matches, idx)
-                model, R, t, scale, valid = ops.solve_rigid(samples.reshape(P * self.B, 3, 6), None, self.flag)
-                model = model.reshape(P, self.B, 4, 4)
-                res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks)
+                if matches.dtype == torch.float32:
+                    # K2 + K3r in one launch (samples read through the index sets), the round's residual sums cleared on the way
+                    res = torch.empty((P, self.B), device=matches.device, dtype=torch.float32)
+                    model, valid = ops.solve_rigid_gather(matches, idx, self.flag, zero_sums=res)
+                    res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks, res=res)
+                else:
+                    samples = ops.gather(matches, idx)
+                    model, R, t, scale, valid = ops.solve_rigid(samples.reshape(P * self.B, 3, 6), None, self.flag)
+                    model = model.reshape(P, self.B, 4, 4)
+                    res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks)
                 # K6 of the 3-D path on the device: arg-min over the valid models, strict "better" test, best model and mask
                 # (one launch; was where / min / gather / where x3: ten torch kernels per round)
                 best, best_model, _ = ops.ransac3d_update(matches, model, valid.reshape(P, self.B), res, self.threshold, best,

@@ -250,6 +250,16 @@ int dr_rigid_residual_f32(const float *pts, const float *models, float threshold
                           float *res_sum, uint8_t *masks, void *stream);
 int dr_rigid_residual_f64(const double *pts, const double *models, double threshold, int P, int M, int N,
                           double *res_sum, uint8_t *masks, void *stream);
+/* Round 4, test mode of the 3-D driver (RANSAC3D.__call__, ransac.py:355-367,380): K2 + K3r in one launch and K4r without its
+ * memset launch.
+ *   dr_solve_rigid_gather_f32: samples are read straight through the index sets -- matches [P,N,6], idx [P,B,k] ->
+ *     models [P*B,16], R / t / scale (may be NULL), valid [P*B]; zero_sums [P*B] (may be NULL) is cleared on the way;
+ *   dr_rigid_residual_acc_f32: dr_rigid_residual_f32 with the sums ADDED to res_sum [P,M], which must hold zeros
+ *     (dr_solve_rigid_gather_f32 with zero_sums = res_sum, M = B, leaves it so). */
+int dr_solve_rigid_gather_f32(const float *matches, const int32_t *idx, int P, int B, int N, int k, int flag, float *models,
+                              float *R, float *t, float *scale, uint8_t *valid, float *zero_sums, void *stream);
+int dr_rigid_residual_acc_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
+                              float *res_sum, uint8_t *masks, void *stream);
 int dr_rigid_residual_bwd_f32(const float *pts, const float *models, const float *grad_res, int P, int M, int N,
                               float *grad_models, void *stream);
 

@@ -217,3 +217,26 @@ def test_five_point_solver_with_few_samples_per_block_equals_the_full_blocks(dev
     ms, vs = ops.solve_stewenius5(smp)
     msb, vsb = ops.solve_stewenius5(big)
     assert torch.equal(ms, msb[:nsmp]) and torch.equal(vs, vsb[:nsmp])
+
+
+# ------------------------------------------------------------------------------------- 3-D driver: fused gather + solve, sums without a memset
+@pytest.mark.parametrize("N", [4096, 1024, 1000])     # rows over two chunks / one chunk / the general residual kernel (N % 16 != 0)
+def test_rigid_gather_solve_and_accumulated_sums_equal_the_separate_launches(dev, N):
+    from differentiable_ransac_amd import ops, synth
+    P, B = 2, 300
+    items = [synth.rigid_pair(p, N) for p in range(P)]
+    m = torch.stack([it["matches"] for it in items]).float().to(dev)
+    lg = torch.stack([it["logits"] for it in items]).to(dev)
+    idx = ops.gumbel_topk(lg, B, 3, 1.0, None, 5, soft=False)["idx"]
+    for flag in (True, False):
+        smp = ops.gather(m, idx)
+        model, R, t, sc, valid = ops.solve_rigid(smp.reshape(P * B, 3, 6), None, flag)
+        res0, mk0 = ops.rigid_residual(m, model.reshape(P, B, 4, 4), 0.03, True)
+        sums = torch.full((P, B), 7.0, device=dev)                      # garbage on entry: cleared by the solve
+        model2, valid2 = ops.solve_rigid_gather(m, idx, flag, zero_sums=sums)
+        assert torch.equal(model2.reshape(P * B, 4, 4), model) and torch.equal(valid2.reshape(-1), valid)
+        assert float(sums.abs().max()) == 0.0
+        res1, mk1 = ops.rigid_residual(m, model2, 0.03, True, res=sums)
+        assert torch.equal(mk0, mk1) and torch.allclose(res0, res1, rtol=1e-5, atol=1e-6)   # float atomics: order of the chunks
+        res2, none = ops.rigid_residual(m, model2, 0.03, False, res=torch.zeros(P, B, device=dev))
+        assert none is None and torch.allclose(res2, res0, rtol=1e-5, atol=1e-6)
