@@ -530,25 +530,25 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 // so no point that reaches T is ever missed; T itself only sets the expected count -- it may be approximate (f32 log-sum-exp),
 // but words and sampler must use the SAME value: it is computed once per pair and read back by both.
 constexpr float kScreenMargin = 1e-3f;   // the device logarithms are good to ~1e-6
-// (a) T per pair: one 1024-thread block, ONE pass (online max / sum), four logits per load, every load of a thread in flight at
-//     once for rows up to 64 K points -- the pass is one memory round trip + a block reduction (first version: every block of
-//     the word kernel re-derived T from the whole row, 40 us at 50 000 points)
-__global__ __launch_bounds__(1024) void gumbel_screen_T_kernel(const float *__restrict__ logits, int N, float lambda,
-                                                               float *__restrict__ T_out) {
-  __shared__ float s_mx[16], s_sm[16];
-  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// (a) per pair and eighth of the row: running (max, sum of exp) of its slice -- kScreenParts blocks of 256 threads, ONE pass, four
+//     logits per load, every load of a thread in flight at once (first version: every block of the word kernel re-derived T from
+//     the whole row, 40 us at 50 000 points; second: one 1024-thread block per pair, 6.9 us)
+constexpr int kScreenParts = 8;
+__global__ __launch_bounds__(256) void gumbel_screen_part_kernel(const float *__restrict__ logits, int N, float *__restrict__ part) {
+  __shared__ float s_mx[4], s_sm[4];
+  const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float4 *l4 = reinterpret_cast<const float4 *>(logits + (size_t)p * N);   // N % 4 == 0 (the long-row kernel's condition)
   const int groups = N >> 2;
   float mx = -INFINITY, sm = 0.f;
-  for (int q0 = tid; q0 < groups; q0 += 16 * 1024) {
-    float4 v[16];
+  for (int q0 = blockIdx.x * 256 + tid; q0 < groups; q0 += 8 * kScreenParts * 256) {
+    float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int q = q0 + u * 1024;
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * kScreenParts * 256;
       v[u] = q < groups ? l4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const float m4 = fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w));
       if (m4 > mx) { sm *= __expf(mx - m4); mx = m4; }
       if (mx > -INFINITY) sm += (__expf(v[u].x - mx) + __expf(v[u].y - mx)) + (__expf(v[u].z - mx) + __expf(v[u].w - mx));
@@ -560,21 +560,32 @@ __global__ __launch_bounds__(1024) void gumbel_screen_T_kernel(const float *__re
   if (lane == 0) { s_mx[wv] = wmx; s_sm[wv] = sm; }
   __syncthreads();
   if (tid == 0) {
-    float bm = s_mx[0];
-    for (int w = 1; w < 16; ++w) bm = fmaxf(bm, s_mx[w]);
+    float bm = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
     float bs = 0.f;
-    for (int w = 0; w < 16; ++w) bs += (s_mx[w] == -INFINITY) ? 0.f : s_sm[w] * __expf(s_mx[w] - bm);
-    float Tf = bm + __logf(bs) - __logf(lambda);
-    if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY) Tf = INFINITY;   // non-finite logits: no point passes, every row takes the full pass
-    T_out[p] = Tf;
+    for (int w = 0; w < 4; ++w) bs += (s_mx[w] == -INFINITY) ? 0.f : s_sm[w] * __expf(s_mx[w] - bm);
+    part[((size_t)p * kScreenParts + blockIdx.x) * 2] = bm;
+    part[((size_t)p * kScreenParts + blockIdx.x) * 2 + 1] = bs;
   }
 }
-// (b) the words: one point per thread
-__global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restrict__ logits, int N, const float *__restrict__ T_in,
+// (b) the words, one point per thread.  Every block combines the pair's eight partial sums itself -- the same values in the same
+//     order, hence the same T in every block; block 0 publishes it for the sampler
+__global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restrict__ logits, int N, float lambda,
+                                                           const float *__restrict__ part, float *__restrict__ T_out,
                                                            uint32_t *__restrict__ tb) {
   const int p = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  float bm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kScreenParts; ++i) bm = fmaxf(bm, part[((size_t)p * kScreenParts + i) * 2]);
+  float bs = 0.f;
+#pragma unroll
+  for (int i = 0; i < kScreenParts; ++i) {
+    const float m = part[((size_t)p * kScreenParts + i) * 2], v = part[((size_t)p * kScreenParts + i) * 2 + 1];
+    bs += (m == -INFINITY) ? 0.f : v * __expf(m - bm);
+  }
+  float Tf = bm + __logf(bs) - __logf(lambda);
+  if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY) Tf = INFINITY;   // non-finite logits: no point passes, every row takes the full pass
+  if (blockIdx.x == 0 && threadIdx.x == 0) T_out[p] = Tf;
   if (n >= N) return;
-  const float Tf = T_in[p];
   constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);
   // G >= a  <=>  u >= exp(-exp(-a)),  u = fl(fl24(w) * 2^-32 c + tiny)  (gumbel_from_bits),  a = T - margin - logit_n
   const double a = ((double)Tf - (double)kScreenMargin) - (double)logits[(size_t)p * N + n];
@@ -828,10 +839,12 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
       const uint32_t *tb = nullptr;
       const float *Tp = nullptr;
       if (screen_ws && !soft) {
-        // workspace: P x N words + P scores; lambda = 20 + k: P(fewer than k of a row's points reach T) < 1e-7
+        // workspace: P x N words + P scores + P x 16 partial sums; lambda = 20 + k: P(fewer than k of a row's points reach T) < 1e-7
         float *Tw = reinterpret_cast<float *>(screen_ws + (size_t)P * N);
-        hipLaunchKernelGGL(gumbel_screen_T_kernel, dim3(P), dim3(1024), 0, st, (const float *)logits, N, (float)(20 + k), Tw);
-        hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 255) / 256, P), dim3(256), 0, st, (const float *)logits, N, Tw, screen_ws);
+        float *part = Tw + P;
+        hipLaunchKernelGGL(gumbel_screen_part_kernel, dim3(kScreenParts, P), dim3(256), 0, st, (const float *)logits, N, part);
+        hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 255) / 256, P), dim3(256), 0, st, (const float *)logits, N, (float)(20 + k),
+                           part, Tw, screen_ws);
         tb = screen_ws;
         Tp = Tw;
       }
@@ -1318,7 +1331,7 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
   return dr::check_launch("gather_fwd_kernel");
 }
 
-// K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 1) * P words, 16-byte aligned): long rows
+// K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 32) * P words, 16-byte aligned): long rows
 // (N > 2048, N % 4 == 0, tau == 1, k <= 5) then skip the Gumbel transform of every step of a wave that holds no candidate
 int dr_gumbel_topk_index_f32(const float *logits, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
                              int32_t *idx, uint32_t *screen_ws, void *stream) {

@@ -171,7 +171,7 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
     if (not soft and logits is not None and gumbel is None and not want_noise and dtype == torch.float32 and tau == 1.0
             and N > 2048 and N % 4 == 0 and k <= 5 and (B >= 64 if screen is None else screen)):
         # long rows, index sets only: the screened one-pass kernel (dr_gumbel_topk_index_f32; same index sets, bit for bit)
-        ws = torch.empty(((N + 1) * P,), device=device, dtype=torch.int32)
+        ws = torch.empty(((N + 32) * P,), device=device, dtype=torch.int32)
         ds = _dev_seed(seed)
         L.call("dr_gumbel_topk_index_f32", ptr(logits), c_uint64(0 if ds else seed & (2 ** 64 - 1)), ptr(seed if ds else None),
                L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(ws), stream())

@@ -117,7 +117,7 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
 
 /* K1, index sets only, in-kernel noise, with an optional screening workspace (round 4; GumbelSoftmaxSampler.sample,
  * samplers/gumbel_sampler.py:25-42, as test mode consumes it: `points[samples != 0]`, ransac.py:65).
- * screen_ws: (N + 1) * P 32-bit words of device memory, 16-byte aligned, or NULL (then = dr_gumbel_topk_fwd_f32 with
+ * screen_ws: (N + 32) * P 32-bit words of device memory, 16-byte aligned, or NULL (then = dr_gumbel_topk_fwd_f32 with
  * y_sel = lse = NULL).  With a workspace, rows longer than the register kernel holds (N > 2048, N % 4 == 0, tau == 1, k <= 5)
  * are SCREENED: one pass over the pair's logits writes, per point, the smallest Philox word that can still lift the point to the
  * score T = logsumexp(logits) - ln(20 + k) (rounded down); a step of a wave (256 points) in which no word reaches its
