@@ -12,27 +12,54 @@ namespace dr {
 
 constexpr int kF8Ws = 162;  // A^T A (81) + eigenvectors (81)
 
-template <typename T>
+// kUniform (round 4): K1u + K2 + K3f8 in ONE launch for the minimal 8-point sample -- the lane draws its eight indices itself
+// (the Philox counters of uniform_sample_kernel: element j, hypothesis b, pair p, stream 1), reads the eight correspondences
+// straight from matches [P,N,4] and writes the index set next to the model.  BASELINE configs[0] is launch-bound (six launches
+// of a few microseconds): two of them disappear.
+template <typename T, bool kUniform>
 __global__ __launch_bounds__(64) void f8_kernel(const T *__restrict__ samples, const T *__restrict__ weights, int Bt,
-                                                int n, T *__restrict__ models, uint8_t *__restrict__ valid) {
+                                                int n_rt, T *__restrict__ models, uint8_t *__restrict__ valid, uint64_t seed = 0,
+                                                const uint64_t *__restrict__ seed_ptr = nullptr, int B = 0, int N = 0,
+                                                int32_t *__restrict__ idx_out = nullptr) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   const int s = blockIdx.x * 64 + lane;
   const bool active = s < Bt;
   const int sc = active ? s : Bt - 1;
-  const T *pts = samples + (size_t)sc * n * 4;
+  const int n = kUniform ? 8 : n_rt;
+  const T *pts = kUniform ? nullptr : samples + (size_t)sc * n * 4;
   const T *wts = weights ? weights + (size_t)sc * n : nullptr;
+  T loc[kUniform ? 8 : 1][4];
+  if constexpr (kUniform) {
+    if (seed_ptr) seed = *seed_ptr;
+    const int p = sc / B, b = sc % B;
+    const uint32_t span = (uint32_t)max(N - 1, 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t r[4];
+      Philox::gen(seed, (uint32_t)j, (uint32_t)b, (uint32_t)p, 1u, r);
+      const int32_t i = (int32_t)(((uint64_t)r[0] * span) >> 32);
+      if (active && idx_out) idx_out[(size_t)sc * 8 + j] = i;
+      const T *row = samples + ((size_t)p * N + i) * 4;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) loc[j][d] = row[d];
+    }
+  }
+  constexpr int kUn = kUniform ? 8 : 1;   // the fused instantiation indexes registers: its row loops are unrolled
+  auto P = [&](int r, int d) -> double { return kUniform ? (double)loc[kUniform ? r : 0][d] : (double)pts[4 * r + d]; };
   // Hartley normalisation (fundamental…:177-217): centroid, mean distance sqrt(2) per image
   double mu[4] = {0, 0, 0, 0};
+#pragma unroll kUn
   for (int r = 0; r < n; ++r)
 #pragma unroll
-    for (int d = 0; d < 4; ++d) mu[d] += (double)pts[4 * r + d];
+    for (int d = 0; d < 4; ++d) mu[d] += P(r, d);
 #pragma unroll
   for (int d = 0; d < 4; ++d) mu[d] /= (double)n;
   double d1 = 0, d2 = 0;
+#pragma unroll kUn
   for (int r = 0; r < n; ++r) {
-    const double a = (double)pts[4 * r] - mu[0], b = (double)pts[4 * r + 1] - mu[1];
-    const double c = (double)pts[4 * r + 2] - mu[2], d = (double)pts[4 * r + 3] - mu[3];
+    const double a = P(r, 0) - mu[0], b = P(r, 1) - mu[1];
+    const double c = P(r, 2) - mu[2], d = P(r, 3) - mu[3];
     d1 += sqrt(a * a + b * b);
     d2 += sqrt(c * c + d * d);
   }
@@ -43,14 +70,13 @@ __global__ __launch_bounds__(64) void f8_kernel(const T *__restrict__ samples, c
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const double w = wts ? (double)wts[r] : 1.0;
-      epipolar_row_f(((double)pts[4 * r] - mu[0]) * r1, ((double)pts[4 * r + 1] - mu[1]) * r1,
-                     ((double)pts[4 * r + 2] - mu[2]) * r2, ((double)pts[4 * r + 3] - mu[3]) * r2, w, A[r]);
+      epipolar_row_f((P(r, 0) - mu[0]) * r1, (P(r, 1) - mu[1]) * r1, (P(r, 2) - mu[2]) * r2, (P(r, 3) - mu[3]) * r2, w, A[r]);
     }
     double nb[1][9];
     null_space_qr<8>(A, nb);
 #pragma unroll
     for (int q = 0; q < 9; ++q) f[q] = nb[0][q];
-  } else {
+  } else if constexpr (!kUniform) {
     LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
     for (int e = 0; e < 81; ++e) A[e] = 0.0;
     for (int r = 0; r < n; ++r) {
@@ -169,11 +195,11 @@ int f8_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f8_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&f8_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(double) * kF8Ws * 64));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((f8_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, n, models, valid);
+  hipLaunchKernelGGL((f8_kernel<T, false>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, n, models, valid);
   return check_launch("f8_kernel");
 }
 
@@ -193,6 +219,18 @@ int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n,
   DR_REQUIRE(Bt > 0 && n >= 8, "need Bt > 0 and n >= 8 points per sample");
   return dr::f8_launch<double>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
 }
+// K1u + K2 + K3f8 in one launch: P x B minimal samples of eight correspondences drawn by UniformSampler's rule (indices in
+// [0, N - 2]: the same index sets dr_uniform_sample draws for this seed), solved by the 8-point kernel; idx [P,B,8] may be NULL
+int dr_solve_f8_uniform_f32(const float *matches, uint64_t seed, const uint64_t *seed_dev, int P, int B, int N, int32_t *idx,
+                            float *models, uint8_t *valid, void *stream) {
+  DR_REQUIRE(matches && models && valid, "null pointer");
+  DR_REQUIRE(P > 0 && B > 0 && N > 1 && (long)P * B < (1l << 31), "bad sizes");
+  const int Bt = P * B;
+  hipLaunchKernelGGL((dr::f8_kernel<float, true>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, matches,
+                     (const float *)nullptr, Bt, 8, models, valid, seed, seed_dev, B, N, idx);
+  return dr::check_launch("f8_kernel");
+}
+
 int dr_solve_f7_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(Bt > 0, "need Bt > 0");

@@ -390,6 +390,21 @@ def solve_f8(samples: torch.Tensor, weights: Optional[torch.Tensor] = None):
     return models.reshape(*lead, 3, 3), valid.reshape(lead)
 
 
+def solve_f8_uniform(matches: torch.Tensor, B: int, seed):
+    """K1u + K2 + K3f8 in one launch (f32): matches [P,N,4] -> (idx [P,B,8] int32, F [P,B,3,3], valid [P,B] bool); the index sets
+    are those of uniform_sample(P, B, 8, N, seed), the models those of solve_f8(gather(matches, idx))."""
+    if matches.dtype != torch.float32 or matches.shape[-1] != 4:
+        raise L.DransacError("solve_f8_uniform: f32 correspondences [P,N,4]")
+    P, N, _ = matches.shape
+    idx = torch.empty((P, B, 8), device=matches.device, dtype=torch.int32)
+    models = torch.empty((P, B, 3, 3), device=matches.device, dtype=torch.float32)
+    valid = torch.empty((P, B), device=matches.device, dtype=torch.bool)
+    ds = _dev_seed(seed)
+    L.call("dr_solve_f8_uniform_f32", ptr(matches.contiguous()), c_uint64(0 if ds else seed & (2 ** 64 - 1)), ptr(seed if ds else None),
+           c_int(P), c_int(B), c_int(N), ptr(idx), ptr(models), ptr(valid), stream())
+    return idx, models, valid
+
+
 def solve_f7(samples: torch.Tensor):
     s, Bt, n = _flat_samples(samples, 4)
     if n != 7:

@@ -390,6 +390,11 @@ class BatchedRANSAC(object):
             samples, w, idx = ops.SampleGather.apply(matches, logits, self.B, self.k, self.tau, gumbels, seed)
             F, v = ops.solve_fundamental8(samples, w)
             return F.unsqueeze(2), v.unsqueeze(2), idx, (seed, gumbels)
+        if (self.sampling == "uniform" and gumbels is None and self.solver == "f8" and self.k == 8
+                and matches.dtype == torch.float32 and matches.shape[-1] == 4):
+            # sampler + gather + 8-point solve in ONE launch (BASELINE configs[0] is launch-bound: six launches -> four)
+            idx, F, v = ops.solve_f8_uniform(matches, self.B, self._next_seed())
+            return F.unsqueeze(2), v.unsqueeze(2), idx, None
         if self.sampling == "uniform" and gumbels is None:
             idx = ops.uniform_sample(matches.shape[0], self.B, self.k, matches.shape[1], self._next_seed(), matches.device)
             samples, w = ops.gather(matches, idx), None

@@ -185,6 +185,12 @@ int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n,
  * |z| > 1 (found as roots w of the reversed polynomial, ascending in w, returned as 1/w) -- and counts [n,2].
  * method 0 = derivative chain (rounds 1-2), 1 = Sturm-sequence isolation (round 3, what the kernels run). */
 int dr_debug_real_roots10(const double *coef, int n, int method, double *roots, int32_t *counts, void *stream);
+/* K1u + K2 + K3f8 in one launch (round 4; UniformSampler.batch_generate, uniform_sampler.py:15-19 -> `matches[idx]`, ransac.py:60
+ * -> FundamentalMatrixEstimatorNew.estimate_model on the minimal sample): matches [P,N,4]; every one of the P x B samples draws
+ * its eight indices in [0, N - 2] itself -- the index sets dr_uniform_sample(seed, P, B, 8, N) draws -- and is solved by the
+ * 8-point kernel: idx [P,B,8] (may be NULL), models [P*B,9], valid [P*B].  seed_dev != NULL: the key is read from device memory. */
+int dr_solve_f8_uniform_f32(const float *matches, uint64_t seed, const uint64_t *seed_dev, int P, int B, int N, int32_t *idx,
+                            float *models, uint8_t *valid, void *stream);
 int dr_solve_f7_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
 int dr_solve_f7_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
 int dr_solve_rigid_f32(const float *samples, const float *weights, int Bt, int n, int flag, float *models, float *R,

@@ -240,3 +240,20 @@ def test_rigid_gather_solve_and_accumulated_sums_equal_the_separate_launches(dev
         assert torch.equal(mk0, mk1) and torch.allclose(res0, res1, rtol=1e-5, atol=1e-6)   # float atomics: order of the chunks
         res2, none = ops.rigid_residual(m, model2, 0.03, False, res=torch.zeros(P, B, device=dev))
         assert none is None and torch.allclose(res2, res0, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_uniform_sampler_gather_eight_point_solve_equals_the_three_launches(dev):
+    from differentiable_ransac_amd import ops, synth
+    P, N, B = 5, 128, 64
+    d = synth.batch_two_view(P, N, seed0=12, pixel=True)
+    m = d["matches"].to(dev)
+    for seed in (0, 99, 2 ** 40 + 7):
+        idx0 = ops.uniform_sample(P, B, 8, N, seed, dev)
+        F0, v0 = ops.solve_f8(ops.gather(m, idx0))
+        idx1, F1, v1 = ops.solve_f8_uniform(m, B, seed)
+        assert torch.equal(idx0, idx1) and torch.equal(F0, F1) and torch.equal(v0, v1)
+        assert int(idx1.max()) <= N - 2 and int(idx1.min()) >= 0
+    ds = ops.DeviceSeed(3, dev, 0)
+    a = ops.solve_f8_uniform(m, B, ds.next())
+    b = ops.solve_f8_uniform(m, B, (3 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
