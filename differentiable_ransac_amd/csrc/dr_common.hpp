@@ -180,7 +180,7 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
 
 // ---- optional per-stage cycle accounting (profiling builds only: -DDR_PROFILE_STAGES) --------------------
 #ifdef DR_PROFILE_STAGES
-static __device__ unsigned long long g_stage_cycles[16];   // one copy per translation unit (no RDC)
+static __device__ unsigned long long g_stage_cycles[32];   // one copy per translation unit (no RDC)
 #define DR_STAGE_BEGIN() unsigned long long _t_prev = __builtin_readcyclecounter()
 #define DR_STAGE(i)                                                        \
   do {                                                                     \
@@ -189,8 +189,8 @@ static __device__ unsigned long long g_stage_cycles[16];   // one copy per trans
     _t_prev = __builtin_readcyclecounter();                                \
   } while (0)
 #define DR_DEFINE_STAGE_READER(name)                                                                          \
-  extern "C" int name(unsigned long long *out16) {                                                            \
-    unsigned long long zero[16] = {0};                                                                        \
+  extern "C" int name(unsigned long long *out16) {   /* 32 entries */                                         \
+    unsigned long long zero[32] = {0};                                                                        \
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(::dr::g_stage_cycles), sizeof(zero)) != hipSuccess) return -2; \
     if (hipMemcpyToSymbol(HIP_SYMBOL(::dr::g_stage_cycles), zero, sizeof(zero)) != hipSuccess) return -2;    \
     return 0;                                                                                                 \

@@ -29,9 +29,11 @@ namespace dr {
 #define DR_K3_STAGE_OUT 0
 #endif
 #ifndef DR_K3_TOL2_F32
-#define DR_K3_TOL2_F32 1e-17   // squared residual norm at which a candidate of the f32 entry points stops iterating (balanced final stage).
-                              // 1e-16: 57.1 -> 54.6 us per 32 x 1024 samples, same valid flags and error statistics, but 24 of 158 874
-                              // models move by up to 7e-6 (ill-conditioned ones: the skipped step mattered) -- not adopted.
+#define DR_K3_TOL2_F32 1e-16   // squared residual norm at which a candidate of the f32 entry points stops iterating (balanced final stage).
+                              // 1e-17 until round 4; 1e-16 measured then: 57.1 -> 54.6 us per 32 x 1024 samples, same valid flags and error
+                              // statistics, 24 of 158 874 models move by up to 7e-6 (ill-conditioned ones: the skipped step mattered) --
+                              // far inside the 1e-4 contract of an f32 model.  Adopted in round 5: a Gauss-Newton step is 1 400 instructions
+                              // that 0.5 % of the candidates ask for, but 40 % of the waves then run (cold code: ~11 us per execution)
 #endif
 #ifndef DR_K3_PRECHECK_F64
 #define DR_K3_PRECHECK_F64 1   // 1: the residual pre-check also with the f64 stopping tolerance (train mode): with converged roots
@@ -434,6 +436,7 @@ template <typename T>
 __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane, int n, const double (&xs)[10], const double (&ys)[10],
                                                 const double (&zs)[10], unsigned cand, size_t s0, bool active,
                                                 T *__restrict__ models, uint8_t *__restrict__ valid, double *__restrict__ models64) {
+  DR_STAGE_BEGIN();
   // exclusive prefix sum of n over the wave
   int incl = n;
 #pragma unroll
@@ -462,6 +465,7 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
   }
   fq.cnt[lane] = 0;
   wave_lds_order();
+  DR_STAGE(16);   // start vectors + queue
   const double tol2 = (sizeof(T) == 4 && !models64) ? DR_K3_TOL2_F32 : 1e-28;
   auto mbcnt = [](unsigned long long bm) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
@@ -504,6 +508,7 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     nlive += __popcll(bm);
   }
   wave_lds_order();
+  DR_STAGE(17);   // residual pre-check of every candidate
 #ifdef DR_PROFILE_STAGES
   if (lane == 0) { atomicAdd(&::dr::g_stage_cycles[13], (unsigned long long)nlive); atomicAdd(&::dr::g_stage_cycles[14], (unsigned long long)total); }
   int _steps = 0;
@@ -543,6 +548,7 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
 #ifdef DR_PROFILE_STAGES
   if (lane == 0) atomicAdd(&::dr::g_stage_cycles[15], (unsigned long long)_steps);
 #endif
+  DR_STAGE(18);   // Gauss-Newton steps of the candidates that asked for them
 #else
   // ---- (A) first step
   int nlive = 0;
@@ -667,12 +673,18 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
             for (int jx = 0; jx < 3; ++jx) models64[sm_ * 90 + 9 * slot + 3 * i + jx] = E[3 * jx + i];
         }
       } else {
+#ifdef DR_K3_NOSTORE   // timing experiment: the final stage without its global stores (one data-dependent store keeps E alive)
+        if (E[0] == 123.456) valid[sm_ * 10 + slot] = 1;
+#else
         store_model<T>(E, models + sm_ * 90 + 9 * slot, models64 ? models64 + sm_ * 90 + 9 * slot : nullptr);
         valid[sm_ * 10 + slot] = 1;
+#endif
       }
     }
   }
+  DR_STAGE(19);   // verification, rank, store
   // eye(3) between the two halves' solutions
+#ifndef DR_K3_NOSTORE
   if ((!kStage || models64) && active && (lane & 1) == 0) {
     const int lo = min(fq.cnt[lane], 10), hi = min(fq.cnt[lane + 1], 10);
     const size_t sm_ = s0 + (size_t)(lane >> 1);
@@ -684,6 +696,8 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
       if (models64) write_identity<double>(models64 + sm_ * 90 + 9 * s);
     }
   }
+#endif
+  DR_STAGE(20);   // identity fillers
   if (kStage) {
     // the block's output rows [s0, s0 + ns) x 90 floats and x 10 bytes are contiguous: whole 16-byte pieces, lane after lane
     wave_lds_order();
@@ -905,30 +919,17 @@ __device__ __forceinline__ void nister_xy_of_roots(const double (&bz)[39], const
 // Two lanes per sample, balanced final stage (see balanced_finish).  LDS use after the constraint solve: the basis (36
 // doubles per sample) for the whole stage; B(z) (39 doubles per sample) only across the root search, where it would
 // otherwise occupy 78 registers -- the candidate queue reuses that space afterwards.
+// nister_back_pair: everything after det B(z) -- the basis and B(z) of the block's 32 samples wait in LDS (FinishQueue layout:
+// basis at lds[(9 t + q) * 32 + j], B(z) element k at lds[36 * 32 + k * 32 + j]), cs = the lane's degree-10 polynomial
+// (1 + z^10 for a lane pair without a usable sample: no real root in either half of the search, no bracket in the wave's queues)
 template <typename T>
-__device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], const double (&X)[6][10], bool ok, double *lds, int lane,
-                                                   size_t s0, bool active, T *__restrict__ models, uint8_t *__restrict__ valid,
-                                                   double *__restrict__ models64) {
+__device__ __forceinline__ void nister_back_pair(const double (&cs)[11], double *lds, int lane, size_t s0, bool active,
+                                                 T *__restrict__ models, uint8_t *__restrict__ valid, double *__restrict__ models64) {
   const FinishQueue fq(lds);
   const int half = lane & 1;
-  park_basis(fq, nb, lane);
-  double cs[11];
-  double *bzl = fq.u + (lane >> 1);   // B(z): element k of sample j at bzl[k * 32] (the queue's space, later)
-  {
-    double bz[39];
-    nister_bz_det(X, bz, cs);
-    if (half == 0) {
-#pragma unroll
-      for (int k = 0; k < 39; ++k) bzl[k * 32] = bz[k];
-    }
-  }
+  const double *bzl = fq.u + (lane >> 1);   // B(z): element k of sample j at bzl[k * 32] (the queue's space, later)
   double roots[10];
   int nroots;
-  if (!active) {   // a lane pair without a sample (partial block, or fewer samples per block): 1 + z^10 -- no real root in either
-                   // half of the search, hence no bracket in the wave's task queues
-#pragma unroll
-    for (int i = 0; i <= 10; ++i) cs[i] = (i == 0 || i == 10) ? 1.0 : 0.0;
-  }
   DR_STAGE_BEGIN();
 #if DR_K3_WAVE_ROOTS
 #if DR_K3_STURM
@@ -940,7 +941,7 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
   real_roots_half<10>(cs, half != 0, roots, nroots);
 #endif
   DR_STAGE(3);
-  if (!ok || !active) nroots = 0;
+  if (!active) nroots = 0;
   double xs[10], ys[10];
   unsigned cand;
   {
@@ -955,6 +956,176 @@ __device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], con
   return;
 #endif
   balanced_finish<T>(fq, lane, nroots, xs, ys, roots, cand, s0, active, models, valid, models64);
+  DR_STAGE(11);   // the balanced final stage alone
+}
+
+template <typename T>
+__device__ __forceinline__ void nister_finish_pair(const double (&nb)[4][9], const double (&X)[6][10], bool ok, double *lds, int lane,
+                                                   size_t s0, bool active, T *__restrict__ models, uint8_t *__restrict__ valid,
+                                                   double *__restrict__ models64) {
+  const FinishQueue fq(lds);
+  park_basis(fq, nb, lane);
+  double cs[11];
+  double *bzl = fq.u + (lane >> 1);
+  {
+    double bz[39];
+    nister_bz_det(X, bz, cs);
+    if ((lane & 1) == 0) {
+#pragma unroll
+      for (int k = 0; k < 39; ++k) bzl[k * 32] = bz[k];
+    }
+  }
+  if (!ok || !active) {   // a lane pair without a sample (partial block, or fewer samples per block) or with a rank-deficient
+                          // system: 1 + z^10 -- no real root in either half of the search, hence no bracket in the wave's task queues
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) cs[i] = (i == 0 || i == 10) ? 1.0 : 0.0;
+  }
+  nister_back_pair<T>(cs, lds, lane, s0, active, models, valid, models64);
+}
+
+// ---- Stewenius: characteristic polynomial of the action matrix, eigenvectors of its real eigenvalues ----------------------
+// Action matrix M (10x10): rows 0-5 <- reduced rows 0,1,2,4,5,7 (g); M[6][0] = M[7][1] = M[8][3] = M[9][6] = -1
+// (stewenius.py:64-72).  Householder-Hessenberg + La Budde's recurrence, fully unrolled in registers; cs ascending.
+__device__ __forceinline__ void stewenius_charpoly(const double (&g)[6][10], double (&cs)[11]) {
+  double H[10][10];
+#pragma unroll
+  for (int r = 0; r < 10; ++r)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) H[r][c] = (r < 6) ? g[r][c] : 0.0;
+  H[6][0] = -1.0; H[7][1] = -1.0; H[8][3] = -1.0; H[9][6] = -1.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double v[10];
+    double nrm2 = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      v[i] = (i > k) ? H[i][k] : 0.0;
+      nrm2 += v[i] * v[i];
+    }
+    const double x0 = v[k + 1];
+    const double alpha = -dsign(sqrt(nrm2), x0);
+    const double v0 = x0 - alpha;
+    const double vtv = v0 * v0 + (nrm2 - x0 * x0);
+    const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+    v[k + 1] = v0;
+    // H <- (I - beta v v^T) H (I - beta v v^T)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      double dot = 0;
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) dot += v[i] * H[i][c];
+      dot *= beta;
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) H[i][c] -= dot * v[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      double dot = 0;
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) dot += H[r][i] * v[i];
+      dot *= beta;
+#pragma unroll
+      for (int i = k + 1; i < 10; ++i) H[r][i] -= dot * v[i];
+    }
+  }
+  // La Budde: p_0 = 1, p_i(l) = (l - h_ii) p_{i-1} - sum_{m=1}^{i-1} h_{i-m,i} (prod_{j=i-m+1}^{i} h_{j,j-1}) p_{i-m-1}
+  // (1-based indices), coefficients ascending: P[i][0..i]
+  double P[11][11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i)
+#pragma unroll
+    for (int t = 0; t < 11; ++t) P[i][t] = 0.0;
+  P[0][0] = 1.0;
+#pragma unroll
+  for (int i = 1; i <= 10; ++i) {
+    const double hii = H[i - 1][i - 1];
+#pragma unroll
+    for (int t = 0; t <= i; ++t) {
+      const double up = (t > 0) ? P[i - 1][t - 1] : 0.0;
+      const double same = (t <= i - 1) ? P[i - 1][t] : 0.0;
+      P[i][t] = up - hii * same;
+    }
+    double prod = 1.0;
+#pragma unroll
+    for (int m = 1; m <= i - 1; ++m) {
+      prod *= H[i - m][i - m - 1];
+      const double coef = H[i - m - 1][i - 1] * prod;
+#pragma unroll
+      for (int t = 0; t <= i - m - 1; ++t) P[i][t] -= coef * P[i - m - 1][t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t <= 10; ++t) cs[t] = P[10][t];
+}
+
+// (x, y, z) of every eigenvalue of this lane: the eigenvector follows from rows 0-5 of (M - lambda I) v = 0 with the structural
+// rows substituted (unknowns y^2, yz, z^2, y, z), solved in the least-squares sense by Householder QR (no pivoting => static
+// indexing); v ~ (x^2, xy, y^2, xz, yz, z^2, x, y, z, 1), lambda = -x
+__device__ __forceinline__ void stewenius_xyz_of_roots(const double (&g)[6][10], const double (&roots)[10], int nroots,
+                                                       double (&xs)[10], double (&ys)[10], double (&zs)[10], unsigned &cand) {
+  cand = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    xs[i] = 0; ys[i] = 0; zs[i] = 0;
+    if (!__any(i < nroots)) continue;
+    const bool has = i < nroots;
+    const double lam = roots[i];
+    const double l2 = lam * lam;
+    // unknown order u = (v2, v4, v5, v7, v8); column 5 = right-hand side (minus the constant term)
+    double K[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double c2 = g[r][2], c4 = g[r][4], c5 = g[r][5];
+      double c7 = g[r][7] - lam * g[r][1];
+      double c8 = g[r][8] - lam * g[r][3];
+      double k0 = g[r][9] - lam * g[r][6] + l2 * g[r][0];
+      if (r == 0) k0 -= lam * l2;   // -lam * v0,  v0 = lam^2
+      if (r == 1) c7 += l2;          // -lam * v1,  v1 = -lam v7
+      if (r == 2) c2 -= lam;
+      if (r == 3) c8 += l2;          // -lam * v3,  v3 = -lam v8
+      if (r == 4) c4 -= lam;
+      if (r == 5) c5 -= lam;
+      K[r][0] = c2; K[r][1] = c4; K[r][2] = c5; K[r][3] = c7; K[r][4] = c8; K[r][5] = -k0;
+    }
+    bool solvable = true;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      double nrm2 = 0;
+#pragma unroll
+      for (int r = c; r < 6; ++r) nrm2 += K[r][c] * K[r][c];
+      const double nrm = sqrt(nrm2);
+      const double alpha = -dsign(nrm, K[c][c]);
+      const double v0 = K[c][c] - alpha;
+      const double vtv = v0 * v0 + (nrm2 - K[c][c] * K[c][c]);
+      const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+      if (!(nrm > 0)) solvable = false;
+      double v[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) v[r] = (r > c) ? K[r][c] : 0.0;
+      v[c] = v0;
+#pragma unroll
+      for (int cc = c + 1; cc < 6; ++cc) {
+        double dot = 0;
+#pragma unroll
+        for (int r = c; r < 6; ++r) dot += v[r] * K[r][cc];
+        dot *= beta;
+#pragma unroll
+        for (int r = c; r < 6; ++r) K[r][cc] -= dot * v[r];
+      }
+      K[c][c] = alpha;
+    }
+    double u[5];
+#pragma unroll
+    for (int c = 4; c >= 0; --c) {
+      double acc = K[c][5];
+#pragma unroll
+      for (int cc = 4; cc > c; --cc) acc -= K[c][cc] * u[cc];
+      u[c] = acc / K[c][c];
+    }
+    const double x = -lam, y = u[3], z = u[4];
+    xs[i] = x; ys[i] = y; zs[i] = z;
+    if (has && solvable && is_finite(y) && is_finite(z)) cand |= 1u << i;
+  }
 }
 
 }  // namespace dr

@@ -47,6 +47,15 @@
 // candidate filter of round 2 (correct, slower: DESIGN 2b) is kept as scratch/k4_filter_kernel.patch.
 #include "dr_common.hpp"
 
+// 0: the empty mask rows of the slots a tile does not evaluate are written by a store-only tail after the model loop (rounds 1-4);
+// 1 / 2: one (up to two) of them per evaluated model INSIDE the model loop of the 16-points-per-lane kernel, so that the store issues
+// under the next model's ~210 vector instructions; what the loop does not get to is drained by the tail.  Round 5, in-step A/B on one
+// box, two rounds (profiles/r5_k4_zero_inloop.md): scoring launch 0.6047 / 0.6051 ms (0) -> 0.5937 / 0.5905 (1) -> 0.5942 / 0.5911 (2),
+// masks and scores bit-identical.  1 is the default; the pocket the round-4 review priced at 0.054 ms closes by 0.012.
+#ifndef DR_K4_ZERO_INLOOP
+#define DR_K4_ZERO_INLOOP 1
+#endif
+
 namespace dr {
 
 constexpr int kThreads = 256;
@@ -477,6 +486,16 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
       }
     }
 
+#if DR_K4_ZERO_INLOOP
+    // the not-evaluated slots of the tile (invalid, or non-finite), as a bit scan carried next to `live`: one of their empty rows
+    // is issued per evaluated model, so that the store rides under the next model's ~210 vector instructions
+    uint32_t zrow[kWords];
+#pragma unroll
+    for (int wd = 0; wd < kWords; ++wd) {
+      zrow[wd] = ~vword[wd];
+      if (32 * wd + 32 > mcount) zrow[wd] &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
+    }
+#endif
 #pragma unroll 1
     for (int wd = 0; wd < kWords; ++wd) {
       uint32_t live = vword[wd];
@@ -486,6 +505,9 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
       float mc[9];
 #pragma unroll
       for (int q = 0; q < 9; ++q) mc[q] = md[ml * 9 + q];
+#if DR_K4_ZERO_INLOOP
+      uint32_t zr = zrow[wd];
+#endif
       while (true) {
         v2f ms[9];
 #pragma unroll
@@ -504,17 +526,34 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
         // row base = wave-uniform 64-bit address (scalar ALU), lane part = unsigned 32-bit offset: the store takes the SGPR-base form
         // and the vector ALU computes no address at all (the 64-bit multiply-add per store was a quarter-rate instruction)
         if (write_masks && have) mask_row_store_saddr(masks + ((size_t)p * M + m0 + cur) * N, (uint32_t)n0, q.x, q.y, q.z, q.w);
+#if DR_K4_ZERO_INLOOP
+        // DR_K4_ZERO_INLOOP = 1: one empty row per evaluated model; 2: a second one while the empty rows outnumber the models left
+        for (int rep = 0; rep < DR_K4_ZERO_INLOOP; ++rep) {
+          if (zr && (rep == 0 || __builtin_popcount(zr) > __builtin_popcount(live) + 1)) {
+            const int mz = 32 * wd + __builtin_ctz(zr);
+            zr &= zr - 1;
+            if (write_masks && have) mask_row_store_saddr(masks + ((size_t)p * M + m0 + mz) * N, (uint32_t)n0, 0u, 0u, 0u, 0u);
+          }
+        }
+#endif
         a = wave_sum_lane63(a);   // DPP only: 212 vs 229 us with the ds_bpermute butterfly (no reduction at all: 204)
         if (lane == 63) atomicAdd(&part[wv][cur], a);   // ds_add_f32, no return: nothing to wait for (-2 %)
         if (!more) break;
       }
+#if DR_K4_ZERO_INLOOP
+      zrow[wd] = zr;
+#endif
     }
     // empty mask rows of the invalid slots (store-only)
     if (write_masks && have) {
 #pragma unroll
       for (int wd = 0; wd < kWords; ++wd) {
+#if DR_K4_ZERO_INLOOP
+        uint32_t inv = zrow[wd];   // what the model loop did not get to
+#else
         uint32_t inv = ~vword[wd];
         if (32 * wd + 32 > mcount) inv &= (mcount > 32 * wd) ? ((1u << (mcount - 32 * wd)) - 1u) : 0u;
+#endif
         while (inv) {
           const int ml = 32 * wd + __builtin_ctz(inv);
           inv &= inv - 1;

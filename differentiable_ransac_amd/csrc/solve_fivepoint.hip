@@ -92,11 +92,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
 // ---- Stewenius ---------------------------------------------------------------------------------------------
 // Action matrix M (10x10): rows 0-5 <- reduced rows 0,1,2,4,5,7; M[6][0] = M[7][1] = M[8][3] = M[9][6] = -1
 // (stewenius.py:64-72).  M v = lambda v with v ~ (x^2, xy, y^2, xz, yz, z^2, x, y, z, 1), lambda = -x.
-// Eigenvalues: Householder-Hessenberg + La Budde's recurrence give the characteristic polynomial, whose real
+// Eigenvalues: Householder-Hessenberg + La Budde's recurrence give the characteristic polynomial (stewenius_charpoly), whose real
 // roots come from the same root finder; the eigenvector follows from rows 0-5 of (M - lambda I) v = 0 with
-// the structural rows substituted (unknowns y^2, yz, z^2, y, z), solved in the least-squares sense by Householder
-// QR.  Everything after the constraint solve is statically indexed and lives in VGPRs; like the Nister kernel, two
-// lanes share one sample and each takes one half of the root search.
+// the structural rows substituted (stewenius_xyz_of_roots).  Everything after the constraint solve is statically indexed and
+// lives in VGPRs; like the Nister kernel, two lanes share one sample and each takes one half of the root search.
+// (The per-lane final stage of round 1, -DDR_K3_BALANCED=0, is gone from this kernel in round 5: the balanced one is the product.)
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void stewenius5_pair_kernel(
     const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, int spb) {
@@ -116,223 +116,236 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
     double e[3][3][4];
     basis_to_entries(nb, e);
     double X[10][10];
-    ok = constraints_reduce<GrevlexOrder, 0, DR_K3_BALANCED != 0>(e, w, 2.0, X, half);
+    ok = constraints_reduce<GrevlexOrder, 0, true>(e, w, 2.0, X, half);
     const int src[6] = {0, 1, 2, 4, 5, 7};
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c < 10; ++c) g[r][c] = X[src[r]][c];
   }
-  // characteristic polynomial of the action matrix
   double cs[11];
-  {
-    double H[10][10];
-#pragma unroll
-    for (int r = 0; r < 10; ++r)
-#pragma unroll
-      for (int c = 0; c < 10; ++c) H[r][c] = (r < 6) ? g[r][c] : 0.0;
-    H[6][0] = -1.0; H[7][1] = -1.0; H[8][3] = -1.0; H[9][6] = -1.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double v[10];
-      double nrm2 = 0;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        v[i] = (i > k) ? H[i][k] : 0.0;
-        nrm2 += v[i] * v[i];
-      }
-      const double x0 = v[k + 1];
-      const double alpha = -dsign(sqrt(nrm2), x0);
-      const double v0 = x0 - alpha;
-      const double vtv = v0 * v0 + (nrm2 - x0 * x0);
-      const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
-      v[k + 1] = v0;
-      // H <- (I - beta v v^T) H (I - beta v v^T)
-#pragma unroll
-      for (int c = 0; c < 10; ++c) {
-        double dot = 0;
-#pragma unroll
-        for (int i = k + 1; i < 10; ++i) dot += v[i] * H[i][c];
-        dot *= beta;
-#pragma unroll
-        for (int i = k + 1; i < 10; ++i) H[i][c] -= dot * v[i];
-      }
-#pragma unroll
-      for (int r = 0; r < 10; ++r) {
-        double dot = 0;
-#pragma unroll
-        for (int i = k + 1; i < 10; ++i) dot += H[r][i] * v[i];
-        dot *= beta;
-#pragma unroll
-        for (int i = k + 1; i < 10; ++i) H[r][i] -= dot * v[i];
-      }
-    }
-    // La Budde: p_0 = 1, p_i(l) = (l - h_ii) p_{i-1} - sum_{m=1}^{i-1} h_{i-m,i} (prod_{j=i-m+1}^{i} h_{j,j-1}) p_{i-m-1}
-    // (1-based indices), coefficients ascending: P[i][0..i]
-    double P[11][11];
-#pragma unroll
-    for (int i = 0; i < 11; ++i)
-#pragma unroll
-      for (int t = 0; t < 11; ++t) P[i][t] = 0.0;
-    P[0][0] = 1.0;
-#pragma unroll
-    for (int i = 1; i <= 10; ++i) {
-      const double hii = H[i - 1][i - 1];
-#pragma unroll
-      for (int t = 0; t <= i; ++t) {
-        const double up = (t > 0) ? P[i - 1][t - 1] : 0.0;
-        const double same = (t <= i - 1) ? P[i - 1][t] : 0.0;
-        P[i][t] = up - hii * same;
-      }
-      double prod = 1.0;
-#pragma unroll
-      for (int m = 1; m <= i - 1; ++m) {
-        prod *= H[i - m][i - m - 1];
-        const double coef = H[i - m - 1][i - 1] * prod;
-#pragma unroll
-        for (int t = 0; t <= i - m - 1; ++t) P[i][t] -= coef * P[i - m - 1][t];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t <= 10; ++t) cs[t] = P[10][t];
-  }
+  stewenius_charpoly(g, cs);
   double roots[10];
   int nroots;
   if (!active) {   // no sample in this lane pair: 1 + z^10, no real root in either half of the search, no bracket in the queues
 #pragma unroll
     for (int t = 0; t <= 10; ++t) cs[t] = (t == 0 || t == 10) ? 1.0 : 0.0;
   }
-#if DR_K3_WAVE_ROOTS
 #if DR_K3_STURM
   real_roots_half_sturm<10>(cs, half != 0, roots, nroots, lds, lane);   // the right block's LDS is free again
 #else
-  real_roots_half_wave<10>(cs, half != 0, roots, nroots, lds, lane);   // the right block's LDS is free again
+  real_roots_half_wave<10>(cs, half != 0, roots, nroots, lds, lane);
 #endif
-#else
-  real_roots_half<10>(cs, half != 0, roots, nroots);
-#endif
-  if (!ok) nroots = 0;
-
-#if DR_K3_BALANCED
+  if (!ok || !active) nroots = 0;
   // eigenvector of every root per lane (cheap), then polish / verification dealt out over the wave (balanced_finish)
-  if (!active) nroots = 0;
   const FinishQueue fq(lds);   // the root-search workspace is dead: basis, candidate queue and vectors take its place
   park_basis(fq, nb, lane);
   double xs[10], ys[10], zs[10];
-  unsigned cand = 0;
-#else
-  T *mdl = models + (size_t)sc * 90;
-  uint8_t *vld = valid + (size_t)sc * 10;
-  int slot = 0;
-#endif
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-#if DR_K3_BALANCED
-    xs[i] = 0; ys[i] = 0; zs[i] = 0;
-#endif
-    if (!__any(i < nroots)) continue;
-    const bool has = i < nroots;
-    const double lam = roots[i];
-    const double l2 = lam * lam;
-    // unknown order u = (v2, v4, v5, v7, v8); column 5 = right-hand side (minus the constant term)
-    double K[6][6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      double c2 = g[r][2], c4 = g[r][4], c5 = g[r][5];
-      double c7 = g[r][7] - lam * g[r][1];
-      double c8 = g[r][8] - lam * g[r][3];
-      double k0 = g[r][9] - lam * g[r][6] + l2 * g[r][0];
-      if (r == 0) k0 -= lam * l2;   // -lam * v0,  v0 = lam^2
-      if (r == 1) c7 += l2;          // -lam * v1,  v1 = -lam v7
-      if (r == 2) c2 -= lam;
-      if (r == 3) c8 += l2;          // -lam * v3,  v3 = -lam v8
-      if (r == 4) c4 -= lam;
-      if (r == 5) c5 -= lam;
-      K[r][0] = c2; K[r][1] = c4; K[r][2] = c5; K[r][3] = c7; K[r][4] = c8; K[r][5] = -k0;
-    }
-    // least squares of the consistent 6x5 system by Householder QR (no pivoting => static indexing)
-    bool solvable = true;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      double nrm2 = 0;
-#pragma unroll
-      for (int r = c; r < 6; ++r) nrm2 += K[r][c] * K[r][c];
-      const double nrm = sqrt(nrm2);
-      const double alpha = -dsign(nrm, K[c][c]);
-      const double v0 = K[c][c] - alpha;
-      const double vtv = v0 * v0 + (nrm2 - K[c][c] * K[c][c]);
-      const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
-      if (!(nrm > 0)) solvable = false;
-      double v[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) v[r] = (r > c) ? K[r][c] : 0.0;
-      v[c] = v0;
-#pragma unroll
-      for (int cc = c + 1; cc < 6; ++cc) {
-        double dot = 0;
-#pragma unroll
-        for (int r = c; r < 6; ++r) dot += v[r] * K[r][cc];
-        dot *= beta;
-#pragma unroll
-        for (int r = c; r < 6; ++r) K[r][cc] -= dot * v[r];
-      }
-      K[c][c] = alpha;
-    }
-    double u[5];
-#pragma unroll
-    for (int c = 4; c >= 0; --c) {
-      double acc = K[c][5];
-#pragma unroll
-      for (int cc = 4; cc > c; --cc) acc -= K[c][cc] * u[cc];
-      u[c] = acc / K[c][c];
-    }
-    const double x = -lam, y = u[3], z = u[4];
-#if DR_K3_BALANCED
-    xs[i] = x; ys[i] = y; zs[i] = z;
-    if (has && solvable && is_finite(y) && is_finite(z)) cand |= 1u << i;
-  }
+  unsigned cand;
+  stewenius_xyz_of_roots(g, roots, nroots, xs, ys, zs, cand);
   balanced_finish<T>(fq, lane, nroots, xs, ys, zs, cand, (size_t)blockIdx.x * spb, active, models, valid, nullptr);
-#else
-    const int dst_slot = half ? 9 - slot : slot;
-    const bool good = finish_solution<T>(nb, x, y, z, has && solvable && is_finite(y) && is_finite(z) && slot < 10,
-                                         mdl + 9 * dst_slot, active);
-    if (good && active) vld[dst_slot] = 1;
-    slot += good ? 1 : 0;
-  }
-  const int other = __shfl_xor(slot, 1, 64);
-  const int lo = half ? other : slot, hi = half ? slot : other;
-  if (active && half == 0) {
-    for (int q = min(lo, 10 - hi); q < 10 - hi; ++q) {
-      write_identity<T>(mdl + 9 * q);
-      vld[q] = 0;
+}
+
+// ---- two-phase kernels (round 5) -------------------------------------------------------------------------------------------
+// 64 samples per 64-lane block.  Front: one lane per sample (what the lane pairs above compute twice: null space, constraints, QR,
+// reduced rows, det B(z) / the characteristic polynomial); the right block's rows 0-6 wait in LDS (35 KiB), rows 7-9 in
+// accumulation registers.  Hand-over: what a sample passes on (Nister: basis 36 + B(z) 39 doubles; Stewenius: basis 36 + reduced
+// rows 60) does not fit in the 40 KiB of LDS a block may hold for both halves at once, and a round trip through global memory
+// stalls a wave that is alone on its SIMD (first version: 214 instead of 171 us) -- every lane parks its own sample's values in its
+// ACCUMULATION registers (AccDouble: one move per dword and direction) and the lanes of half p write theirs into the LDS image
+// when pass p begins; the polynomial travels by ds_bpermute.  Back: the block's two 32-sample halves one after the other, two lanes
+// per sample, exactly the stages of the pair kernels.  Used when the grid is at least two rounds of pair-kernel blocks
+// (fivepoint_two_phase); small grids keep the pair kernels (latency).
+__device__ __forceinline__ double lane_read(double v, int src) { return __shfl(v, src, 64); }
+
+template <typename T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_fb_kernel(
+    const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid,
+    double *__restrict__ models64) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  AccDouble hand[36 + 39];   // this lane's sample: basis | B(z)
+  double cs[11];
+  DR_STAGE_BEGIN();
+  {
+    const int s = blockIdx.x * 64 + lane;
+    const bool act = s < Bt;
+    const int sc = act ? s : Bt - 1;
+    double e[3][3][4];
+    {
+      double nb[4][9];
+      fivepoint_basis_minimal<T>(samples + (size_t)sc * 20, weights ? weights + (size_t)sc * 5 : nullptr, nb);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) hand[9 * t + q].put(nb[t][q]);
+      basis_to_entries(nb, e);
+    }
+    double X[6][10];
+    const bool ok = constraints_reduce_front<NisterOrder, 4>(e, LaneWs{lds + lane, 64}, 1.0, X);
+    double bz[39];
+    nister_bz_det(X, bz, cs);
+#pragma unroll
+    for (int k = 0; k < 39; ++k) hand[36 + k].put(bz[k]);
+    if (!ok || !act) {   // 1 + z^10: no real root in either half of the search, no bracket in the wave's queues
+#pragma unroll
+      for (int i = 0; i <= 10; ++i) cs[i] = (i == 0 || i == 10) ? 1.0 : 0.0;
     }
   }
+  DR_STAGE(2);
+#pragma unroll 1
+  for (int p = 0; p < 2; ++p) {
+    const size_t s0 = (size_t)blockIdx.x * 64 + 32 * p;
+    if (s0 >= (size_t)Bt) break;
+    wave_lds_order();   // the front stage / the previous pass is done with the LDS
+    if ((lane >> 5) == p) {
+      double *img = lds + (lane & 31);   // FinishQueue layout: basis element e of sample j at [e * 32 + j], then B(z)
+#pragma unroll
+      for (int k = 0; k < 36 + 39; ++k) img[k * 32] = hand[k].get();
+    }
+    double csp[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) csp[i] = lane_read(cs[i], 32 * p + (lane >> 1));
+    wave_lds_order();
+    nister_back_pair<T>(csp, lds, lane, s0, s0 + (lane >> 1) < (size_t)Bt, models, valid, models64);
+  }
+}
+
+// Stewenius: what a sample hands over is its reduced rows 0,1,2,4,5,7 (60 doubles, in accumulation registers) and the polynomial;
+// the null-space basis (36 more doubles: with them the back stage spills) is computed again by the sample's lane pair in its
+// pass -- 700 of the ~7 600 front instructions the lane pairs no longer execute twice.
+template <typename T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_fb_kernel(
+    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  constexpr int kGOff = SturmWs<10>::kDoubles > FinishQueue::kDoubles ? SturmWs<10>::kDoubles : FinishQueue::kDoubles;   // reduced rows of a pass
+  AccDouble hand[60];
+  double cs[11];
+  {
+    const int s = blockIdx.x * 64 + lane;
+    const bool act = s < Bt;
+    const int sc = act ? s : Bt - 1;
+    double e[3][3][4];
+    {
+      double nb[4][9];
+      fivepoint_basis_minimal<T>(samples + (size_t)sc * 20, nullptr, nb);
+      basis_to_entries(nb, e);
+    }
+    double g[6][10];
+    bool ok;
+    {
+      double X[10][10];
+      ok = constraints_reduce_front<GrevlexOrder, 0>(e, LaneWs{lds + lane, 64}, 2.0, X);
+      const int src[6] = {0, 1, 2, 4, 5, 7};
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 10; ++c) g[r][c] = X[src[r]][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 10; ++c) hand[10 * r + c].put(g[r][c]);
+    stewenius_charpoly(g, cs);
+    if (!ok || !act) {
+#pragma unroll
+      for (int i = 0; i <= 10; ++i) cs[i] = (i == 0 || i == 10) ? 1.0 : 0.0;
+    }
+  }
+#pragma unroll 1
+  for (int p = 0; p < 2; ++p) {
+    const size_t s0 = (size_t)blockIdx.x * 64 + 32 * p;
+    if (s0 >= (size_t)Bt) break;
+    const int half = lane & 1, j = lane >> 1;
+    const bool active = s0 + j < (size_t)Bt;
+    double csp[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) csp[i] = lane_read(cs[i], 32 * p + j);
+    wave_lds_order();   // the front stage / the previous pass is done with the LDS
+    if ((lane >> 5) == p) {   // the reduced rows of this pass' samples: behind the root-search workspace and the candidate queue
+      double *img = lds + kGOff + (lane & 31);
+#pragma unroll
+      for (int k = 0; k < 60; ++k) img[k * 32] = hand[k].get();
+    }
+    double roots[10];
+    int nroots;
+#if DR_K3_STURM
+    real_roots_half_sturm<10>(csp, half != 0, roots, nroots, lds, lane);
+#else
+    real_roots_half_wave<10>(csp, half != 0, roots, nroots, lds, lane);
 #endif
+    if (!active) nroots = 0;
+    const FinishQueue fq(lds);
+    {
+      double nb[4][9];
+      fivepoint_basis_minimal<T>(samples + (active ? s0 + j : (size_t)Bt - 1) * 20, nullptr, nb);
+      wave_lds_order();   // the root-search workspace is dead: the basis takes its place
+      park_basis(fq, nb, lane);
+    }
+    double xs[10], ys[10], zs[10];
+    unsigned cand;
+    {
+      double g[6][10];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 10; ++c) g[r][c] = lds[kGOff + (10 * r + c) * 32 + j];
+      stewenius_xyz_of_roots(g, roots, nroots, xs, ys, zs, cand);
+    }
+    wave_lds_order();
+    balanced_finish<T>(fq, lane, nroots, xs, ys, zs, cand, s0, active, models, valid, nullptr);
+  }
 }
 
 static inline bool aligned_out(const void *models, const void *valid) {
   return !DR_K3_STAGE_OUT || ((reinterpret_cast<uintptr_t>(models) & 15u) == 0 && (reinterpret_cast<uintptr_t>(valid) & 3u) == 0);
 }
 
+// SIMDs of the current device (4 per CU), cached per device: one process may drive several GPUs
+static inline int device_simds() {
+  static int simds[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+  if (!simds[dev]) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    simds[dev] = 4 * (cus > 0 ? cus : 256);
+  }
+  return simds[dev];
+}
+
 // samples per 64-lane block of the two-lanes-per-sample kernels: 32, or fewer (down to 4) while the grid stays within one block
-// per SIMD -- a one-pair call (1024 samples) is 256 blocks of 4 samples instead of 32 blocks of 32 on 1024 SIMDs
+// per SIMD -- a one-pair call (1024 samples) is 256 blocks of 4 samples instead of 32 blocks of 32 on 1024 SIMDs.  Always even
+// (>= 4): the staged-output alignment of balanced_finish relies on s0 * 90 floats being a multiple of 16 bytes.
 static inline int samples_per_block(int Bt) {
   int spb = 32;
-#if DR_K3_BALANCED
-  static int simds = 0;
-  if (!simds) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    simds = 4 * (cus > 0 ? cus : 256);
-  }
+  const int simds = device_simds();
   while (spb > 4 && (long)(Bt + spb / 2 - 1) / (spb / 2) <= simds) spb /= 2;
-#endif
   return spb;
 }
 
+// Two-phase kernels or lane pairs?  A pair-kernel block (32 samples) costs kPairCost, a two-phase block (64 samples) kFbCost
+// (relative units from the measured kernels, profiles/r5_k3_variants.md); blocks run one per SIMD, so a launch takes
+// ceil(blocks / SIMDs) rounds.  131 072 samples: 4 x pair against 2 x two-phase; 32 768 samples (one round of pair blocks
+// on 1024 SIMDs) stay with the lane pairs, which also serve the small grids (samples_per_block).
+#ifndef DR_K3_FB_COST_NISTER
+#define DR_K3_FB_COST_NISTER 174   // per cent of a pair-kernel block (measured: 132.9 us in two rounds against 153.4 in four)
+#endif
+#ifndef DR_K3_FB_COST_STEW
+#define DR_K3_FB_COST_STEW 183     // (171.8 us in two rounds against 187.6 in four)
+#endif
+static inline bool fivepoint_two_phase(int Bt, int fb_cost_pct) {
+  const long simds = device_simds();
+  const long rounds_pair = ((Bt + 31) / 32 + simds - 1) / simds;
+  const long rounds_fb = ((Bt + 63) / 64 + simds - 1) / simds;
+  return rounds_fb * fb_cost_pct < rounds_pair * 100;
+}
+
+// path: 0 = automatic (fivepoint_two_phase), 1 = lane pairs, 2 = two-phase
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st,
-                  double *models64 = nullptr) {
+                  double *models64 = nullptr, int path = 0) {
   static bool attr_set[64] = {false};   // per device: one process may drive several GPUs
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -345,6 +358,12 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
     // minimal samples: two lanes per sample; LDS per 32-sample block: 100 doubles per sample for the constraint solve,
     // later basis + B(z) / candidate queue + root-search workspace (36.5 KiB => four blocks per CU, one per SIMD)
     const size_t smem = sizeof(double) * (DR_K3_BALANCED ? kNisterPairDoubles : 100 * 32);
+    if (DR_K3_BALANCED && (path == 2 || (path == 0 && fivepoint_two_phase(Bt, DR_K3_FB_COST_NISTER)))) {
+      static_assert(!DR_K3_BALANCED || 70 * 64 <= kNisterPairDoubles, "front stage: rows 0-6 of 64 right blocks");
+      hipLaunchKernelGGL((nister5_fb_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, models, valid,
+                         models64);
+      return check_launch("nister5_fb_kernel");
+    }
     const int spb = samples_per_block(Bt);
     hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, weights, Bt, models,
                        valid, models64, spb);
@@ -358,10 +377,19 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
 }
 
 template <typename T>
-int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st) {
+int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st, int path = 0) {
   // the right 10x10 block of 32 samples, later the root-search workspace, then the candidate queue
-  constexpr int kDoubles = (DR_K3_BALANCED && FinishQueue::kDoubles > 100 * 32) ? FinishQueue::kDoubles : 100 * 32;
-  static_assert(!DR_K3_WAVE_ROOTS || (RootWs<10>::kDoubles <= kDoubles && SturmWs<10>::kDoubles <= kDoubles), "root-search workspace");
+  constexpr int kDoubles = (FinishQueue::kDoubles > 100 * 32) ? FinishQueue::kDoubles : 100 * 32;
+  static_assert(RootWs<10>::kDoubles <= kDoubles && SturmWs<10>::kDoubles <= kDoubles, "root-search workspace");
+  if (path == 2 || (path == 0 && fivepoint_two_phase(Bt, DR_K3_FB_COST_STEW))) {
+    // front stage: rows 0-6 of 64 right blocks (35 KiB); back: root search / candidate queue + the reduced rows of 32 samples
+    constexpr int kBack = (SturmWs<10>::kDoubles > FinishQueue::kDoubles ? SturmWs<10>::kDoubles : FinishQueue::kDoubles) + 60 * 32;
+    constexpr int kFb = 70 * 64 > kBack ? 70 * 64 : kBack;
+    static_assert(kFb * sizeof(double) <= 40960, "four blocks per CU");
+    hipLaunchKernelGGL((stewenius5_fb_kernel<T>), dim3((Bt + 63) / 64), dim3(64), sizeof(double) * kFb, st, samples, Bt, models,
+                       valid);
+    return check_launch("stewenius5_fb_kernel");
+  }
   const size_t smem = sizeof(double) * kDoubles;
   const int spb = samples_per_block(Bt);
   hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, Bt, models, valid, spb);
@@ -440,6 +468,22 @@ int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   return dr::stewenius_launch<double>(samples, Bt, models, valid, (hipStream_t)stream);
+}
+
+int dr_solve_nister5_path_f32(const float *samples, const float *weights, int Bt, float *models, double *models_f64, uint8_t *valid,
+                              int path, void *stream) {
+  DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
+  return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, models_f64, path);
+}
+int dr_solve_stewenius5_path_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, void *stream) {
+  DR_REQUIRE(samples && models && valid, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
+  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream, path);
 }
 
 }  // extern "C"

@@ -100,6 +100,16 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
 #ifndef DR_K3_STURM
 #define DR_K3_STURM 1   // 1: the two-lanes-per-sample kernels isolate the roots by a Sturm sequence (real_roots_half_sturm)
 #endif
+#ifndef DR_K3_STURM_DRAIN
+#define DR_K3_STURM_DRAIN 0   // 1: emitting an isolated interval does not cost a step of the isolation loop (round 5: 13 -> 11 steps for
+                              // the slowest lane of a wave, but every step pays the extra loop: 165.1 -> 170.9 us at 131 072 samples; off)
+#endif
+#ifndef DR_K3_SYMG
+#define DR_K3_SYMG 1          // 1: the six distinct entries of E E^T once in Nister's lane-pair kernel (constraint_rows; round 5)
+#endif
+#ifndef DR_K3_ISO_FLAT
+#define DR_K3_ISO_FLAT 1      // 1: the isolation step as predicates + selects instead of an if / else-if chain (round 5)
+#endif
 #ifndef DR_ROOT_BIS_LOW
 #define DR_ROOT_BIS_LOW 6
 #define DR_ROOT_NEWT_LOW 4
@@ -671,15 +681,77 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
     v = ws.vv[tc * 64 + lane];
     top += have ? 1 : 0;
   };
+#if DR_K3_ISO_FLAT
+  // Round 5: the step without control flow.  Rounds 3-4 walked an if / else-if chain (isolated -> emit + pop | cannot split -> pop |
+  // left part isolated -> emit, go right | left part holds roots -> push right, go left | go right); with 64 lanes in different
+  // states the wave executed every arm one after the other, ~250 instructions per step where the evaluation of the chain is ~100.
+  // Here a lane derives its action as predicates, writes at most ONE record (the emitted interval or the pushed right part),
+  // updates its interval with selects and pops under one mask.  Same intervals, same order: the roots are bit-identical.
 #pragma unroll 1
   for (int guard = 0; guard < 64 * D; ++guard) {
     if (!__any(have)) break;
 #ifdef DR_PROFILE_STAGES
     ++_iters;
 #endif
+    const int cl = (int)(v & 15u), ch = (int)((v >> 8) & 15u);
+    const bool iso = have && (cl - ch == 1);
+    // split a hair off the centre: a root AT a split point would be counted with the sign of +0 (nice inputs have nice roots:
+    // 0, 1/2, 1/4 ... are exactly where plain halving of (-1, 1] looks)
+    const double mid = __builtin_fma(h - l, 0.49999952316284180, l);
+    const unsigned vmid = variations(mid) & 31u;   // (a lane that emits or idles in this step evaluates for nothing: the wave pays anyway)
+    const int cm = (int)(vmid & 15u);
+    const int nl = cl - cm, nr = cm - ch;
+    // an interval that cannot be split any more (a multiple root to rounding) or whose halves both come out empty
+    // (inconsistent counts of a degenerate chain) is dropped
+    const bool splittable = mid > l && mid < h && (h - l) > 1e-12;
+    const bool room = top - 2 >= nout;
+    const bool split = have && !iso;
+    const bool drop = split && (!splittable || (nl < 1 && nr < 1));
+    const bool go = split && !drop;
+    const bool emit_left = go && nl == 1 && nr >= 1 && room;   // the left part is isolated: straight to the output list, go on with the right
+    const bool to_left = go && !emit_left && nl >= 1;          // the left part holds roots: it is next, the right part waits on the stack
+    const bool push_right = to_left && nr >= 1 && room;        // (dropped if there is no room: degenerate counts)
+    const bool to_right = go && !emit_left && !to_left;
+    const bool emit = iso || emit_left;
+    if (emit || push_right) {
+      const int we = emit ? nout : top - 1;
+      ws.lo[we * 64 + lane] = push_right ? mid : l;
+      ws.hi[we * 64 + lane] = emit_left ? mid : h;
+      ws.vv[we * 64 + lane] = iso ? v : (emit_left ? ((v & 31u) | (vmid << 8)) : (vmid | (v & 0xff00u)));
+    }
+    nout += emit ? 1 : 0;
+    top -= push_right ? 1 : 0;
+    const bool move_l = emit_left || to_right;
+    l = move_l ? mid : l;
+    h = to_left ? mid : h;
+    v = move_l ? (vmid | (v & 0xff00u)) : (to_left ? ((v & 31u) | (vmid << 8)) : v);
+    if (iso || drop) pop();
+  }
+#else
+#pragma unroll 1
+  for (int guard = 0; guard < 64 * D; ++guard) {
+    if (!__any(have)) break;
+#ifdef DR_PROFILE_STAGES
+    ++_iters;
+#endif
+#if DR_K3_STURM_DRAIN
+    // isolated intervals go to the output list and the next pending one comes off the stack (LDS only) WITHOUT costing the wave a
+    // step: rounds 3-4 spent one step of the loop -- i.e. one evaluation of the chain by every other lane -- per emitted interval
+    // (4-5 of the ~13 steps the slowest lane of a wave needs); same intervals in the same order, so the roots are bit-identical
+    while (have && ((int)(v & 15u) - (int)((v >> 8) & 15u) == 1)) {
+      ws.lo[nout * 64 + lane] = l;
+      ws.hi[nout * 64 + lane] = h;
+      ws.vv[nout * 64 + lane] = v;
+      ++nout;
+      pop();
+    }
+    if (!__any(have)) break;
+    const bool iso = false;
+#else
     // one action per lane and step: an isolated interval goes to the output list and the next pending one comes off the stack
     // (LDS only), any other interval is split at its midpoint (one evaluation of the chain)
     const bool iso = have && ((int)(v & 15u) - (int)((v >> 8) & 15u) == 1);
+#endif
     if (iso) {
       ws.lo[nout * 64 + lane] = l;
       ws.hi[nout * 64 + lane] = h;
@@ -720,6 +792,7 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
       }
     }
   }
+#endif
   wave_lds_order();
 #ifdef DR_PROFILE_STAGES
   if (D == 10 && lane == 0) { atomicAdd(&::dr::g_stage_cycles[7], __builtin_readcyclecounter() - _st0); atomicAdd(&::dr::g_stage_cycles[9], (unsigned long long)_iters); atomicMax(&::dr::g_stage_cycles[10], (unsigned long long)_iters); }
@@ -750,19 +823,23 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
 #ifdef DR_PROFILE_STAGES
   if (D == 10 && lane == 0) atomicAdd(&::dr::g_stage_cycles[8], __builtin_readcyclecounter() - _st0);
 #endif
+  // dense list: the roots that count are written back over the lane's own entries (entry `count` <= k: already read) and read again
+  // with static indices -- rounds 3-4 compacted in registers with a 10 x 10 select network (300 instructions)
   count = 0;
-#pragma unroll
-  for (int i = 0; i < D; ++i) roots[i] = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     const double xk = ws.lo[k * 64 + lane];
-    const double vv_ = outer ? 1.0 / xk : xk;
     const bool take = ((has_mask >> k) & 1u) && (!outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0));
-    if (take) {
-#pragma unroll
-      for (int t = 0; t < D; ++t) roots[t] = (t == count) ? vv_ : roots[t];
+    if (__any(take)) {
+      const double vv_ = outer ? 1.0 / xk : xk;
+      if (take) ws.lo[count * 64 + lane] = vv_;
     }
     count += take ? 1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const double r = ws.lo[i * 64 + lane];
+    roots[i] = (i < count) ? r : 0.0;
   }
 }
 
@@ -1197,34 +1274,15 @@ __device__ __forceinline__ void pmul21_acc(const double (&a)[10], const double (
 // ------------------------------------------------------------------------------------------------
 // kSplit: two lanes build and factor the same system (same LDS slot); each then solves five of the ten right-hand-side
 // columns (`half` = 0 / 1) and both read all results back -- block = one wave, so program order is enough.
-template <class Ord, int kFirstRow, bool kSplit = false>
-__device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], const LaneWs &Bw, double s,
-                                   double (&X)[10 - kFirstRow][10], int half = 0) {
-  double A[10][10];
-  // ---- the ten cubic constraints on E(x,y,z) = x B0 + y B1 + z B2 + B3: rows 0-8 = entries (row-major i,j) of
-  //      s*(E E^T E - 1/2 tr(E E^T) E) (s = 2 for Stewenius' 2EE^TE - tr(EE^T)E), row 9 = det E;
-  //      e[i][j][0..3] = entry polynomial (i,j) in (x,y,z,1).  A-part to registers, B-part to LDS
-  double tr[10];
-  {
-    double d0[10], d1[10], d2[10];
-    pmul11<Ord>(e[0][0], e[0][0], d0); pmul11<Ord>(e[0][1], e[0][1], d0, 1.0, true); pmul11<Ord>(e[0][2], e[0][2], d0, 1.0, true);
-    pmul11<Ord>(e[1][0], e[1][0], d1); pmul11<Ord>(e[1][1], e[1][1], d1, 1.0, true); pmul11<Ord>(e[1][2], e[1][2], d1, 1.0, true);
-    pmul11<Ord>(e[2][0], e[2][0], d2); pmul11<Ord>(e[2][1], e[2][1], d2, 1.0, true); pmul11<Ord>(e[2][2], e[2][2], d2, 1.0, true);
-#pragma unroll
-    for (int t = 0; t < 10; ++t) tr[t] = 0.5 * (d0[t] + d1[t] + d2[t]);
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    // (E E^T - 1/2 tr I) row i : three degree-2 polynomials
-    double g[3][10];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      pmul11<Ord>(e[i][0], e[k][0], g[k]);
-      pmul11<Ord>(e[i][1], e[k][1], g[k], 1.0, true);
-      pmul11<Ord>(e[i][2], e[k][2], g[k], 1.0, true);
-    }
-#pragma unroll
-    for (int t = 0; t < 10; ++t) g[i][t] -= tr[t];
+// The ten cubic constraints on E(x,y,z) = x B0 + y B1 + z B2 + B3: rows 0-8 = entries (row-major i,j) of
+// s*(E E^T E - 1/2 tr(E E^T) E) (s = 2 for Stewenius' 2EE^TE - tr(EE^T)E), row 9 = det E;
+// e[i][j][0..3] = entry polynomial (i,j) in (x,y,z,1).  Left block (first ten monomials) -> A, right block -> put_b(row, t, value)
+// kSymmetricG: the six distinct entries of E E^T once (round 5).  Chosen per kernel by measurement: Nister's lane-pair kernel gains
+// (156.8 -> 153.4 us at 131 072 samples); Nister's two-phase kernel and both Stewenius kernels spill more with it and lose
+// (two-phase 132.9 -> 140.1 us; Stewenius lane pairs 1 201 -> 1 520 accumulation-register moves).
+template <class Ord, bool kSymmetricG, class PutB>
+__device__ __forceinline__ void constraint_rows(const double (&e)[3][3][4], double s, double (&A)[10][10], PutB put_b) {
+  auto emit_rows = [&](int i, const double (&g)[3][10]) {   // rows (i, 0..2) from row i of E E^T - 1/2 tr I
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       double row[20];
@@ -1235,8 +1293,52 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
 #pragma unroll
       for (int t = 0; t < 10; ++t) {
         A[3 * i + j][t] = row[t];
-        Bw[(3 * i + j) * 10 + t] = row[10 + t];
+        put_b(3 * i + j, t, row[10 + t]);
       }
+    }
+  };
+  if constexpr (kSymmetricG) {
+    // G = E E^T is symmetric: its six distinct entry polynomials once (rounds 1-4 formed all nine, and the diagonal twice)
+    double G[3][3][10];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = i; k < 3; ++k) {
+        pmul11<Ord>(e[i][0], e[k][0], G[i][k]);
+        pmul11<Ord>(e[i][1], e[k][1], G[i][k], 1.0, true);
+        pmul11<Ord>(e[i][2], e[k][2], G[i][k], 1.0, true);
+      }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      const double tr = 0.5 * (G[0][0][t] + G[1][1][t] + G[2][2][t]);
+      G[0][0][t] -= tr; G[1][1][t] -= tr; G[2][2][t] -= tr;
+      G[1][0][t] = G[0][1][t]; G[2][0][t] = G[0][2][t]; G[2][1][t] = G[1][2][t];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) emit_rows(i, G[i]);
+  } else {
+    double tr[10];
+    {
+      double d0[10], d1[10], d2[10];
+      pmul11<Ord>(e[0][0], e[0][0], d0); pmul11<Ord>(e[0][1], e[0][1], d0, 1.0, true); pmul11<Ord>(e[0][2], e[0][2], d0, 1.0, true);
+      pmul11<Ord>(e[1][0], e[1][0], d1); pmul11<Ord>(e[1][1], e[1][1], d1, 1.0, true); pmul11<Ord>(e[1][2], e[1][2], d1, 1.0, true);
+      pmul11<Ord>(e[2][0], e[2][0], d2); pmul11<Ord>(e[2][1], e[2][1], d2, 1.0, true); pmul11<Ord>(e[2][2], e[2][2], d2, 1.0, true);
+#pragma unroll
+      for (int t = 0; t < 10; ++t) tr[t] = 0.5 * (d0[t] + d1[t] + d2[t]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      // (E E^T - 1/2 tr I) row i : three degree-2 polynomials
+      double g[3][10];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        pmul11<Ord>(e[i][0], e[k][0], g[k]);
+        pmul11<Ord>(e[i][1], e[k][1], g[k], 1.0, true);
+        pmul11<Ord>(e[i][2], e[k][2], g[k], 1.0, true);
+      }
+#pragma unroll
+      for (int t = 0; t < 10; ++t) g[i][t] -= tr[t];
+      emit_rows(i, g);
     }
   }
   {
@@ -1259,10 +1361,81 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
 #pragma unroll
     for (int t = 0; t < 10; ++t) {
       A[9][t] = row[t];
-      Bw[9 * 10 + t] = row[10 + t];
+      put_b(9, t, row[10 + t]);
     }
   }
+}
+
+// Householder QR of A in place: reflector j lives in A[j..9][j] (v, with v_j = A[j][j]), R above the diagonal, 1 / r_jj in rinv.
+// Returns false when |r_jj| underflows against the largest one (nister.py:154-157: rank-deficient left block => sample dropped).
+// (LAPACK storage -- v_j = 1 implicit, 1 / r_jj on the diagonal, 20 registers fewer -- was built in round 5: the compiler spills
+// MORE with it, 349 instead of 261 accumulation-register moves in the Nister pair kernel, 1 813 instead of 1 312 in Stewenius'.)
+__device__ __forceinline__ bool householder_qr10(double (&A)[10][10], double (&beta)[10], double (&rinv)[10]) {
+  double rdiag[10];
+  double amax = 0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    double nrm2 = 0;
+#pragma unroll
+    for (int i = j; i < 10; ++i) nrm2 += A[i][j] * A[i][j];
+    const double nrm = sqrt(nrm2);
+    const double alpha = -dsign(nrm, A[j][j]);
+    const double v0 = A[j][j] - alpha;
+    const double vtv = v0 * v0 + (nrm2 - A[j][j] * A[j][j]);
+    beta[j] = vtv > 0 ? 2.0 / vtv : 0.0;
+    rdiag[j] = alpha;
+    A[j][j] = v0;
+    amax = fmax(amax, fabs(alpha));
+#pragma unroll
+    for (int c = j + 1; c < 10; ++c) {
+      double dot = 0;
+#pragma unroll
+      for (int i = j; i < 10; ++i) dot += A[i][j] * A[i][c];
+      dot *= beta[j];
+#pragma unroll
+      for (int i = j; i < 10; ++i) A[i][c] -= dot * A[i][j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 10; ++j) ok = ok && (fabs(rdiag[j]) > 1e-13 * amax);
+  ok = ok && is_finite(amax) && amax > 0;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) rinv[j] = ok ? 1.0 / rdiag[j] : 0.0;
+  return ok;
+}
+
+// one right-hand-side column through the factorisation: reflectors, then back-substitution R x = b for rows 9 .. kFirstRow
+template <int kFirstRow>
+__device__ __forceinline__ void qr10_solve_column(const double (&A)[10][10], const double (&beta)[10], const double (&rinv)[10],
+                                                  double (&b)[10], double (&x)[10]) {
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    double dot = 0;
+#pragma unroll
+    for (int i = j; i < 10; ++i) dot += A[i][j] * b[i];
+    dot *= beta[j];
+#pragma unroll
+    for (int i = j; i < 10; ++i) b[i] -= dot * A[i][j];
+  }
+#pragma unroll
+  for (int r = 9; r >= kFirstRow; --r) {
+    double acc = b[r];
+#pragma unroll
+    for (int k = r + 1; k < 10; ++k) acc -= A[r][k] * x[k];
+    x[r] = acc * rinv[r];
+  }
+}
+
+template <class Ord, int kFirstRow, bool kSplit = false>
+__device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], const LaneWs &Bw, double s,
+                                   double (&X)[10 - kFirstRow][10], int half = 0) {
+  double A[10][10];
+  // A-part to registers, B-part to LDS
+  constraint_rows<Ord, DR_K3_SYMG != 0 && kFirstRow == 4>(e, s, A, [&](int r, int t, double v) { Bw[r * 10 + t] = v; });   // kFirstRow == 4: Nister
   // ---- Householder QR of A: reflector j lives in A[j..9][j] (v, with v_j = A[j][j]), R above the diagonal + rdiag
+  // (kept inline here, not through householder_qr10 / qr10_solve_column: the shipped pair kernels' register allocation is
+  // sensitive to the form -- 16 579 -> 16 766 instructions for Stewenius' through the helpers)
   double beta[10], rdiag[10];
   double amax = 0;
   bool ok = true;
@@ -1328,6 +1501,59 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
   if (kSplit) wave_lds_order();
 #pragma unroll
   for (int r = kFirstRow; r < 10; ++r)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) X[r - kFirstRow][c] = Bw[r * 10 + c];
+  return ok;
+}
+
+// The same reduction for the FRONT stage of the two-phase kernels (round 5): ONE lane per sample, so the block's 64 lanes park
+// 64 right blocks -- 100 doubles each would be 51 KiB, one block too many for four blocks per CU.  Rows 0 .. kLdsRows-1 wait in
+// LDS (stride 64), the last rows stay in registers; the column loop is unrolled (static register indices) and every lane
+// solves all ten columns.  Results of the LDS rows are parked where the column came from and re-read at the end, like above.
+// a double parked in two ACCUMULATION registers (gfx950: 256 AGPRs next to the 256 VGPRs at one wave per SIMD) by explicit
+// v_accvgpr_write / read: one move per dword and direction, once -- the compiler's own spilling moved the parked rows back and forth
+// (2 300 instead of 260 moves in the kernel)
+struct AccDouble {
+  unsigned lo, hi;   // "a"-class values
+  __device__ __forceinline__ void put(double v) {
+    const unsigned l = (unsigned)__double2loint(v), h = (unsigned)__double2hiint(v);
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(l));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(h));
+  }
+  __device__ __forceinline__ double get() const {
+    unsigned l, h;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+    return __hiloint2double((int)h, (int)l);
+  }
+};
+
+template <class Ord, int kFirstRow, int kLdsRows = 7>
+__device__ __forceinline__ bool constraints_reduce_front(const double (&e)[3][3][4], const LaneWs &Bw, double s,
+                                                         double (&X)[10 - kFirstRow][10]) {
+  static_assert(kLdsRows >= kFirstRow && kLdsRows <= 10, "rows kept in registers must be result rows");
+  double A[10][10];
+  AccDouble Br[kLdsRows < 10 ? 10 - kLdsRows : 1][10];
+  constraint_rows<Ord, false>(e, s, A, [&](int r, int t, double v) {
+    if (r < kLdsRows) Bw[r * 10 + t] = v;
+    else Br[r - kLdsRows][t].put(v);
+  });
+  double beta[10], rinv[10];
+  const bool ok = householder_qr10(A, beta, rinv);
+#pragma unroll
+  for (int c = 0; c < 10; ++c) {
+    double b[10], x[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) b[i] = (i < kLdsRows) ? Bw[i * 10 + c] : Br[i - kLdsRows][c].get();
+    qr10_solve_column<kFirstRow>(A, beta, rinv, b, x);
+#pragma unroll
+    for (int r = kFirstRow; r < 10; ++r) {
+      if (r < kLdsRows) Bw[r * 10 + c] = x[r];
+      else X[r - kFirstRow][c] = x[r];
+    }
+  }
+#pragma unroll
+  for (int r = kFirstRow; r < kLdsRows; ++r)
 #pragma unroll
     for (int c = 0; c < 10; ++c) X[r - kFirstRow][c] = Bw[r * 10 + c];
   return ok;

@@ -331,19 +331,25 @@ def _flat_samples(samples: torch.Tensor, c: int):
     return s, s.shape[0], s.shape[1]
 
 
-def solve_nister5(samples: torch.Tensor, weights: Optional[torch.Tensor] = None):
-    """samples [..., n>=5, 4] -> models [..., 10, 3, 3], valid [..., 10] bool (real solutions, ascending root)."""
+def solve_nister5(samples: torch.Tensor, weights: Optional[torch.Tensor] = None, path: int = 0):
+    """samples [..., n>=5, 4] -> models [..., 10, 3, 3], valid [..., 10] bool (real solutions, ascending root).
+    path (f32 minimal samples only): 0 automatic, 1 lane-pair kernel, 2 two-phase kernel (include/dransac.h)."""
     s, Bt, n = _flat_samples(samples, 4)
     lead = samples.shape[:-2]
     models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=s.dtype)
     valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
     w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
-    L.call(f"dr_solve_nister5_{L.suffix(s.dtype)}", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(valid),
-           stream())
+    if path != 0:
+        if n != 5 or s.dtype != torch.float32:
+            raise L.DransacError("an explicit five-point kernel path exists for f32 minimal samples only")
+        L.call("dr_solve_nister5_path_f32", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(None), ptr(valid), c_int(path), stream())
+    else:
+        L.call(f"dr_solve_nister5_{L.suffix(s.dtype)}", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(valid),
+               stream())
     return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 
-def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = None):
+def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = None, path: int = 0):
     """Minimal f32 samples [..., 5, 4] -> (models f32, models f64, valid): the train-mode entry, one launch."""
     s, Bt, n = _flat_samples(samples, 4)
     if n != 5 or s.dtype != torch.float32:
@@ -353,7 +359,10 @@ def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = No
     m64 = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=torch.float64)
     valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
     w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
-    L.call("dr_solve_nister5_f32_hp", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), stream())
+    if path != 0:
+        L.call("dr_solve_nister5_path_f32", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), c_int(path), stream())
+    else:
+        L.call("dr_solve_nister5_f32_hp", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), stream())
     return models.reshape(*lead, 10, 3, 3), m64.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 
@@ -368,14 +377,20 @@ def debug_real_roots10(coef: torch.Tensor, method: int = 1):
     return roots, counts
 
 
-def solve_stewenius5(samples: torch.Tensor):
+def solve_stewenius5(samples: torch.Tensor, path: int = 0):
+    """samples [..., 5, 4] -> models [..., 10, 3, 3], valid [..., 10].  path: as solve_nister5 (f32 only)."""
     s, Bt, n = _flat_samples(samples, 4)
     if n != 5:
         raise L.DransacError("the Stewenius solver takes exactly 5 correspondences per sample")
     lead = samples.shape[:-2]
     models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=s.dtype)
     valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
-    L.call(f"dr_solve_stewenius5_{L.suffix(s.dtype)}", ptr(s), c_int(Bt), ptr(models), ptr(valid), stream())
+    if path != 0:
+        if s.dtype != torch.float32:
+            raise L.DransacError("an explicit five-point kernel path exists for f32 minimal samples only")
+        L.call("dr_solve_stewenius5_path_f32", ptr(s), c_int(Bt), ptr(models), ptr(valid), c_int(path), stream())
+    else:
+        L.call(f"dr_solve_stewenius5_{L.suffix(s.dtype)}", ptr(s), c_int(Bt), ptr(models), ptr(valid), stream())
     return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 

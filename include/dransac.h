@@ -24,6 +24,7 @@
 #ifndef DRANSAC_H_
 #define DRANSAC_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -175,6 +176,16 @@ int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, 
                             uint8_t *valid, void *stream);
 int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
 int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
+/* Round 5: the minimal (n = 5) f32 solves with an explicit kernel path (tests, A/B runs).  path 1 = two lanes per sample from
+ * the first instruction (the only kernels until round 4), path 2 = the two-phase kernels: ONE lane per sample for the part the two
+ * lanes of a sample otherwise compute twice (null space, the ten constraints, QR, reduced rows, det B(z) of nister.py:117-348 / the
+ * action matrix' characteristic polynomial of stewenius.py:44-74), handed over in registers to the two-lanes-per-sample root search
+ * and final stage (nister.py:355-402, stewenius.py:74-78); path 0 = what dr_solve_nister5_f32 / _f32_hp / dr_solve_stewenius5_f32
+ * choose by themselves (two-phase when the grid is at least two rounds of lane-pair blocks).  Same solutions either way
+ * (Stewenius: bit for bit; Nister: to the rounding of det B(z)).  models_f64: optional second output as in dr_solve_nister5_f32_hp. */
+int dr_solve_nister5_path_f32(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
+                              uint8_t *valid, int path, void *stream);
+int dr_solve_stewenius5_path_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, void *stream);
 int dr_solve_f8_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
                     void *stream);
 int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n, double *models, uint8_t *valid,

@@ -15,16 +15,17 @@ import differentiable_ransac_amd._lib as L
 L.LIB_PATH = os.path.abspath(f'scratch/libdransac_prof{tag}.so')
 from differentiable_ransac_amd import ops, synth
 dev = 'cuda'
-P, N, B = 32, 2000, 1024
+P, N, B = int(os.environ.get('K3_PAIRS', 32)), 2000, 1024
+PATH = int(os.environ.get('K3_PATH', 1))
 data = synth.batch_two_view(P, N)
 r = ops.gumbel_topk(data['logits'].to(dev), B, 5, 1.0, None, seed=1)
 smp = ops.gather(data['matches'].to(dev), r['idx'], r['y_sel'])
 lib = L.lib()
-buf = (ctypes.c_ulonglong * 16)()
-for name, fn in (('nister', ops.solve_nister5),):
+buf = (ctypes.c_ulonglong * 32)()
+for name, fn in (('nister', lambda x: ops.solve_nister5(x, path=PATH)),):
     fn(smp); torch.cuda.synchronize()
     lib.dr_debug_stage_read_fivepoint(buf)
     fn(smp); torch.cuda.synchronize()
     lib.dr_debug_stage_read_fivepoint(buf)
     tot = sum(buf)
-    print(name, 'waves', P * B // 32, 'cycles/wave by stage:', [int(b) // (P * B // 32) for b in buf[:10]] + [round(int(buf[i]) / (P * B // 32), 2) for i in (13, 14, 15)], 'max isolation iterations of a wave', int(buf[10]))
+    print(name, 'path', PATH, 'waves (32-sample units)', P * B // 32, 'cycles/wave by stage:', [int(b) // (P * B // 32) for b in buf[:10]] + ['final', int(buf[11]) // (P * B // 32)] + [round(int(buf[i]) / (P * B // 32), 2) for i in (13, 14, 15)], 'max isolation iterations of a wave', int(buf[10]), '| final stage: start', int(buf[16]) // (P * B // 32), 'precheck', int(buf[17]) // (P * B // 32), 'steps', int(buf[18]) // (P * B // 32), 'verify+store', int(buf[19]) // (P * B // 32), 'identity', int(buf[20]) // (P * B // 32))

@@ -208,15 +208,17 @@ def test_five_point_solver_with_few_samples_per_block_equals_the_full_blocks(dev
     smp = ops.gather(d["matches"].to(dev), r["idx"])[0]                 # [nsmp, 5, 4]
     m_s, v_s = ops.solve_nister5(smp)
     big = torch.cat([smp, smp.flip(0).repeat(1 + 40000 // nsmp, 1, 1)])
-    m_b, v_b = ops.solve_nister5(big)
+    m_b, v_b = ops.solve_nister5(big, path=1)      # round 5: a batch of this size would take the two-phase kernel by itself
     assert torch.equal(v_s, v_b[:nsmp]) and torch.equal(m_s, m_b[:nsmp])
     assert int(v_s.sum()) > 2 * nsmp or nsmp < 10
     mh, m64, vh = ops.solve_nister5_hp(smp)
-    mhb, m64b, vhb = ops.solve_nister5_hp(big)
+    mhb, m64b, vhb = ops.solve_nister5_hp(big, path=1)
     assert torch.equal(mh, mhb[:nsmp]) and torch.equal(m64, m64b[:nsmp]) and torch.equal(vh, vhb[:nsmp])
     ms, vs = ops.solve_stewenius5(smp)
-    msb, vsb = ops.solve_stewenius5(big)
+    msb, vsb = ops.solve_stewenius5(big, path=1)
     assert torch.equal(ms, msb[:nsmp]) and torch.equal(vs, vsb[:nsmp])
+    msf, vsf = ops.solve_stewenius5(big, path=2)   # Stewenius' two-phase kernel runs the same arithmetic per sample
+    assert torch.equal(ms, msf[:nsmp]) and torch.equal(vs, vsf[:nsmp])
 
 
 # ------------------------------------------------------------------------------------- 3-D driver: fused gather + solve, sums without a memset

@@ -1,0 +1,89 @@
+"""Round 5 on the GPU: the two-phase five-point kernels (one lane per sample for the front stage, hand-over in accumulation
+registers: dr_solve_nister5_path_f32 / dr_solve_stewenius5_path_f32 with path = 2) against the f64 CPU oracle and against the
+lane-pair kernels they replace on large grids.  Reference: nister.py:69-408, stewenius.py:20-80."""
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from tests.test_gpu_solvers import TOL, _kat_essential, _set_dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(dev, n_rows, seed=3):
+    from differentiable_ransac_amd import ops, synth
+    pair = synth.two_view_pair(seed, 2000)
+    r = ops.gumbel_topk(pair["logits"][None].to(dev), n_rows, 5, 1.0, None, seed)
+    return ops.gather(pair["matches"][None].to(dev), r["idx"])[0]
+
+
+@pytest.mark.parametrize("solver", ["nister", "stewenius"])
+def test_two_phase_fivepoint_vs_oracle(dev, solver):
+    """forced two-phase path (path = 2) at a size with a partial block (1000 = 15 x 64 + 40: the last block's second half holds
+    8 samples) against the f64 oracle: same tolerances as the lane-pair kernels in test_gpu_solvers.py"""
+    from differentiable_ransac_amd import ops
+    smp = _samples(dev, 1000)
+    fn = ops.solve_nister5 if solver == "nister" else ops.solve_stewenius5
+    E, valid = fn(smp, path=2)
+    E, valid = E.cpu().double(), valid.cpu()
+    _kat_essential(E, valid, smp.cpu().double(), tol=2e-5)
+    Eo, ok, real = O.nister_5pt(smp.cpu().double())
+    fw, bw = _set_dist(E[ok], valid[ok], Eo[ok], real[ok])
+    assert fw.quantile(0.995) < TOL and bw.quantile(0.995) < TOL, (fw.max(), bw.max())
+    assert (fw > TOL).float().mean() < 2e-3 and (bw > TOL).float().mean() < 2e-3
+    assert abs(int(valid.sum()) - int(real[ok].sum())) <= 8
+
+
+@pytest.mark.parametrize("rows", [1, 33, 64, 97, 4096])
+def test_two_phase_fivepoint_equals_lane_pairs(dev, rows):
+    """same solutions in the same slots as the lane-pair kernels (different elimination order in f64: the f32 models agree to
+    rounding; a verification decided by the last bit may flip a slot -- at most a handful in 40 960)"""
+    from differentiable_ransac_amd import ops
+    smp = _samples(dev, rows, seed=11)
+    for fn in (ops.solve_nister5, ops.solve_stewenius5):
+        Ea, va = fn(smp, path=1)
+        Eb, vb = fn(smp, path=2)
+        flips = int((va != vb).sum())
+        assert flips <= max(2, rows // 500), flips
+        same = (va & vb)
+        if same.any():
+            d = (Ea[same] - Eb[same]).abs().amax((-1, -2))
+            assert d.quantile(0.999) < 2e-6, d.max()
+            assert (d > 1e-4).float().mean() < 1e-3
+        eye = torch.eye(3, device=dev)
+        assert (Eb[~vb] == eye).all()
+
+
+def test_two_phase_nister_train_entry_and_weights(dev):
+    """the f64 second output (train mode) and the weighted rows through the two-phase kernel"""
+    from differentiable_ransac_amd import ops
+    smp = _samples(dev, 300, seed=5)
+    w = torch.rand(300, 5, device=dev) + 0.5
+    m32a, m64a, va = ops.solve_nister5_hp(smp, w, path=1)
+    m32b, m64b, vb = ops.solve_nister5_hp(smp, w, path=2)
+    assert int((va != vb).sum()) <= 2
+    same = va & vb
+    assert (m64a[same] - m64b[same]).abs().max() < 1e-9
+    assert torch.equal(m32b, m64b.float())
+    Eo, ok, real = O.nister_5pt(smp.cpu().double(), w.cpu().double())
+    fw, bw = _set_dist(m64b.cpu()[ok], vb.cpu()[ok], Eo[ok], real[ok])
+    assert fw.quantile(0.99) < 1e-6 and bw.quantile(0.99) < 1e-6
+
+
+def test_two_phase_automatic_choice_at_config_size(dev):
+    """131 072 samples (BASELINE configs[1] at 128 pairs per step, configs[2]): the automatic path takes the two-phase kernels
+    and returns what the forced path returns, bit for bit; degenerate inputs never produce NaN"""
+    from differentiable_ransac_amd import ops
+    smp = _samples(dev, 4096, seed=7).repeat(32, 1, 1).contiguous()
+    smp[5] = 0.0
+    smp[6] = float("nan")
+    for fn in (ops.solve_nister5, ops.solve_stewenius5):
+        Ea, va = fn(smp)
+        Eb, vb = fn(smp, path=2)
+        assert torch.equal(va, vb) and torch.equal(Ea, Eb)
+        assert torch.isfinite(Ea).all() and not va[6].any()
+        # the 32 copies of the 4096 samples give identical results wherever they sit in the grid
+        ref = Ea[:4096]
+        for c in (1, 17, 31):
+            blk = Ea[4096 * c:4096 * (c + 1)]
+            assert torch.equal(blk[7:], ref[7:])
