@@ -349,6 +349,66 @@ def _median3_ms(fn, seg):
     return sorted(out)[1], out
 
 
+def dropin_layer_loop_record(dev, pairs=32, reps=6):
+    """The reference's own call pattern (model_cl.py:488-511, test.py:38): the pairs of a batch pushed ONE BY ONE through
+    `layers.RANSACLayer.forward` -- the five-line import swap of INTEGRATION.md section 1, nothing batched by the caller.  Test mode
+    (`-tr 0`: max_iters = 5000 = up to five batches of `-rbs 1024`, adaptive stop, final refit K7) and train mode (`-tr 1`:
+    one batch, best-of-ten vs the ground truth, autograd graph kept).  Wall time per pair over `reps` passes over the batch,
+    device-synchronised once per pass (nothing inside the loop reads a result back)."""
+    import types
+    from differentiable_ransac_amd import layers, synth
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    N, B = 2000, 1024
+    d = synth.batch_two_view(pairs, N)
+    m, lg, K1, K2, gt = (d[k_].to(dev) for k_ in ("matches", "logits", "K1", "K2", "gt_E"))
+    im = torch.tensor([1000.0, 1000.0], device=dev)
+    out = {"workload": f"{pairs} pairs x {N} points pushed one by one through layers.RANSACLayer.forward, -rbs {B}, sampler 2 "
+                       "(Gumbel), Nister; model_cl.py:488-511"}
+
+    def run(layer, train):
+        def one_pass():
+            res = []
+            for p in range(pairs):
+                w = lg[p].clone().requires_grad_(True) if train else lg[p]
+                Es, _ = layer(m[p], w, K1[p], K2[p], im, im, gt[p] if train else None)
+                res.append(Es)
+            return res
+        for _ in range(3):
+            res = one_pass()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = one_pass()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / pairs * 1e3)
+        return sorted(ts)[len(ts) // 2], res
+    opt = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=B, tr=False, weighted=0, threshold=0.75, precision=1,
+                                device=str(dev))
+    layer = layers.RANSACLayer(opt)
+    ms, res = run(layer, False)
+    out["test_mode"] = {"ms_per_pair": ms, "hypotheses_per_s": B / (ms * 1e-3), "issue": "one replayed HIP graph per pair: every "
+                        "round issued, adaptive stop on the device (RANSAC.graph, ransac._GraphedCall), final refit included"}
+    layer.estimator.graph = False
+    ms_e, _ = run(layer, False)
+    out["test_mode_eager"] = {"ms_per_pair": ms_e, "issue": "eager launches, termination read back after every batch (rounds 1-4)"}
+    # the same pairs through ONE batched call (what batched_forward does): the device time the loop competes with
+    drv = BatchedRANSAC("nister", ransac_batch_size=B, threshold=0.75, max_iterations=5000, refit=True)
+    for _ in range(3):
+        drv(m, lg, K1, K2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        drv(m, lg, K1, K2)
+    torch.cuda.synchronize()
+    out["batched_forward_ms_per_pair"] = (time.perf_counter() - t0) / reps / pairs * 1e3
+    opt_t = types.SimpleNamespace(**{**vars(opt), "tr": True})
+    ms_t, res_t = run(layers.RANSACLayer(opt_t), True)
+    out["train_mode"] = {"ms_per_pair": ms_t, "issue": "eager (the autograd tape of a call cannot be replayed); forward only, "
+                         "models per pair: %d" % int(res_t[0].shape[0])}
+    return out
+
+
 def train_record(dev, steps=150, pairs=32):
     """BASELINE configs[4]'s per-GPU share as a sub-record of the default line: the train step (sampler -> solver -> best-of-10
     vs GT -> MatchLoss -> backward to the logits) on 32 pairs x 2000 points x 1024 hypotheses, eager and replayed as one HIP
@@ -922,6 +982,7 @@ def main():
             # SURVEY's literal C2: ONE pair per call (test.py:38, model_cl.py:488-490), eager and replayed as one graph
             result["configs"]["c2_p1"] = config_record("c2", dev, 600, 5, pairs=1, graph=True)
             result["configs"]["c5_train_p32"] = train_record(dev)
+            result["configs"]["dropin_layer_loop"] = dropin_layer_loop_record(dev)
             result["fused_driver"] = fused_driver_record(dev)
             result["k4_all_valid"] = k4_all_valid_record(dev)
         if not args.logits_fixture and os.path.exists(os.path.join(ROOT, "tests", "golden", "clnet_logits.npz")):

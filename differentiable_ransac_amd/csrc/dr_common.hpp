@@ -29,6 +29,15 @@ inline int check_launch(const char *what) {
     }                                    \
   } while (0)
 
+// Per-pair gate of the multi-round test-mode drivers (round 5: device-side termination): a pair whose iteration counter has
+// reached its adaptive bound (ransac.py:135-144, kept on the device by dr_ransac_update) has terminated; the kernels of later rounds
+// return at once for its blocks -- nothing about a round is read back by the host, so a whole multi-round call is one HIP graph.
+struct PairGate {
+  const int32_t *iters = nullptr;
+  const double *max_iters = nullptr;
+  __device__ __forceinline__ bool closed(int p) const { return iters && (double)iters[p] >= max_iters[p]; }
+};
+
 // ---- wave64 reductions (ds_swizzle/DPP chosen by the compiler from the xor pattern) ----
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

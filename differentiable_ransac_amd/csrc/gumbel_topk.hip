@@ -312,8 +312,10 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
                                                                              float *__restrict__ lse_out,
                                                                              const uint64_t *__restrict__ seed_ptr,
                                                                              const float4 *__restrict__ gather_src = nullptr,
-                                                                             float4 *__restrict__ gather_dst = nullptr) {
+                                                                             float4 *__restrict__ gather_dst = nullptr,
+                                                                             PairGate gate = PairGate()) {
   // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
+  if (gate.closed(blockIdx.y)) return;   // this pair has terminated (block-uniform): its rows keep what the last round drew
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
 #if DR_K1_PASSB_ATOMIC
@@ -815,7 +817,7 @@ template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
                       const uint64_t *seed_ptr = nullptr, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr,
-                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr) {
+                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr, PairGate gate = PairGate()) {
   if (gathered) *gathered = false;
   GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
   const int groups = (N + 3) / 4;
@@ -832,7 +834,7 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
       else
       {
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst);
+                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate);
         if (gathered) *gathered = gather_dst != nullptr;
       }
       return check_launch("gumbel_topk_fast_kernel");
@@ -1122,11 +1124,11 @@ __global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_
 
 // ---- seed of the next call, on the device: state = (base, calls) -> out = base * 0x9E3779B97F4A7C15 + calls ; calls += 1
 // (what the drivers compute on the host per call; here a captured graph advances it by itself at every replay)
-__global__ void seed_next_kernel(uint64_t *__restrict__ state, uint64_t *__restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *out = state[0] * 0x9E3779B97F4A7C15ull + state[1];
-    state[1] += 1;
-  }
+__global__ void seed_next_kernel(uint64_t *__restrict__ state, uint64_t *__restrict__ out, int n = 1) {
+  // n > 1: the seeds of the next n calls at once (a multi-round call draws one per round: one launch instead of n)
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)n) out[threadIdx.x] = state[0] * 0x9E3779B97F4A7C15ull + state[1] + threadIdx.x;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) state[1] += (uint64_t)n;
 }
 
 // ---- K2 gather forward / backward
@@ -1278,7 +1280,13 @@ int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, v
 //      graph needs (a by-value seed would be frozen into the graph); dr_seed_next advances such a seed on the device
 int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream) {
   DR_REQUIRE(state && seed_out, "null pointer");
-  hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seed_out);
+  hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seed_out, 1);
+  return dr::check_launch("seed_next_kernel");
+}
+int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream) {
+  DR_REQUIRE(state && seeds_out, "null pointer");
+  DR_REQUIRE(n >= 1 && n <= 64, "1 <= n <= 64 seeds per launch");
+  hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seeds_out, n);
   return dr::check_launch("seed_next_kernel");
 }
 
@@ -1319,8 +1327,8 @@ int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N
 
 // K1 (index sets only) + K2 in one call: idx [P,B,k] and samples [P,B,k,4] = matches[p, idx] (test mode: the points themselves,
 // ransac.py:65).  One launch when the register kernel serves the shape, sampler + gather launches otherwise.
-int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
-                              int B, int N, int k, int32_t *idx, float *samples, void *stream) {
+static int gumbel_topk_gather_impl(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
+                                   int B, int N, int k, int32_t *idx, float *samples, dr::PairGate gate, void *stream) {
   const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
   DR_REQUIRE(logits && matches && samples, "null pointer");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
@@ -1328,12 +1336,30 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
   bool gathered = false;
   if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
                                             (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
-                                            reinterpret_cast<float4 *>(samples), &gathered))
+                                            reinterpret_cast<float4 *>(samples), &gathered, nullptr, gate))
     return rc;
   if (gathered) return 0;
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
                      (const float *)nullptr, N, B * k, 4, samples);
   return dr::check_launch("gather_fwd_kernel");
+}
+
+int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
+                              int B, int N, int k, int32_t *idx, float *samples, void *stream) {
+  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, dr::PairGate(), stream);
+}
+
+// the same for a round > 1 of a multi-round test-mode call: pairs whose iteration counter has reached its bound are skipped
+// (gate_iters [P] int32, gate_max_iters [P] f64: the state dr_ransac_update keeps; the rows of a skipped pair keep their contents).
+// Only the register-resident kernel (N <= 2048, N % 4 == 0, tau = 1) looks at the gate; other shapes simply run.
+int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                                    int P, int B, int N, int k, int32_t *idx, float *samples, const int32_t *gate_iters,
+                                    const double *gate_max_iters, void *stream) {
+  DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
+  dr::PairGate gate;
+  gate.iters = gate_iters;
+  gate.max_iters = gate_max_iters;
+  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream);
 }
 
 // K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 32) * P words, 16-byte aligned): long rows

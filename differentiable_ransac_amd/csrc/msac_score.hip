@@ -415,7 +415,9 @@ __global__ __launch_bounds__(kT16) void msac_score_kernel_f32_fast16(const float
                                                                      const float *__restrict__ thr, int M, int N,
                                                                      float *__restrict__ scores,
                                                                      uint8_t *__restrict__ masks, int write_masks,
-                                                                     int chunks_per_block, int use_atomic, int tile_slots) {
+                                                                     int chunks_per_block, int use_atomic, int tile_slots,
+                                                                     PairGate gate) {
+  if (gate.closed(blockIdx.z)) return;   // a terminated pair of a multi-round call (block-uniform): scores and masks keep their contents
   // tile_slots <= kTile: the slots a half actually owns (64, or 16 for grids that would not fill the chip); the kernel is the
   // same either way -- a 16-slot half simply has an empty second validity word
   constexpr int kTile = kFastTile, kWords = kTile / 32;
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
 
 template <typename T>
 int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, const T *thr, int P, int M, int N,
-                      T *scores, uint8_t *masks, hipStream_t st) {
+                      T *scores, uint8_t *masks, hipStream_t st, PairGate gate = PairGate()) {
   constexpr bool kFast = sizeof(T) == 4;
   if constexpr (kFast) {
     if (N <= kSmallMaxN) {   // short rows: a wave per model (BASELINE configs[0])
@@ -903,7 +905,7 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
     if (fast16) {
       hipLaunchKernelGGL(msac_score_kernel_f32_fast16, grid, dim3(kT16), 0, st, (const float *)matches,
                          (const float *)models, valid, (const float *)thr, M, N, (float *)scores, masks, masks ? 1 : 0,
-                         cpb, use_atomic, small_grid ? kSmallGridTile : kFastTile);
+                         cpb, use_atomic, small_grid ? kSmallGridTile : kFastTile, gate);
       return check_launch("msac_score_kernel");
     }
     hipLaunchKernelGGL(msac_score_kernel_f32_fast, grid, dim3(kThreads), 0, st, (const float *)matches,
@@ -929,6 +931,20 @@ int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   DR_REQUIRE(matches && models && thr && scores, "null pointer");
   return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
+}
+
+// round > 1 of a multi-round test-mode call: the blocks of pairs whose iteration counter has reached its bound return at once
+// (their scores / masks keep their contents; dr_ransac_update ignores such pairs).  Only the 16-points-per-lane kernel looks at
+// the gate; other shapes simply run.
+int dr_msac_score_gated_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P, int M, int N,
+                            float *scores, uint8_t *masks, const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  DR_REQUIRE(matches && models && thr && scores, "null pointer");
+  DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
+  dr::PairGate gate;
+  gate.iters = gate_iters;
+  gate.max_iters = gate_max_iters;
+  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream, gate);
 }
 
 int dr_msac_score_path_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void nister5_pair_kernel(
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models,
-    uint8_t *__restrict__ valid, double *__restrict__ models64, int spb) {
+    uint8_t *__restrict__ valid, double *__restrict__ models64, int spb, PairGate gate, int per_pair) {
+  // gate (rounds > 1 of a multi-round call): a block all of whose samples belong to terminated pairs returns at once
+  if (gate.iters && gate.closed((blockIdx.x * spb) / per_pair) && gate.closed((min(blockIdx.x * spb + spb, Bt) - 1) / per_pair)) return;
   // spb = samples per block: 32 when the grid fills the chip.  Calls with few samples (one pair = 1024 samples = 32 blocks on
   // 1024 SIMDs) run 16 / 8 / 4 samples per block instead: the lane pairs beyond spb hold no sample, queue no bracket and no
   // candidate, so the wave's task rounds (refine, polish, verification) shrink with spb while the per-lane stages cost what they
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
 // (The per-lane final stage of round 1, -DDR_K3_BALANCED=0, is gone from this kernel in round 5: the balanced one is the product.)
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void stewenius5_pair_kernel(
-    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, int spb) {
+    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, int spb, PairGate gate, int per_pair) {
+  if (gate.iters && gate.closed((blockIdx.x * spb) / per_pair) && gate.closed((min(blockIdx.x * spb + spb, Bt) - 1) / per_pair)) return;
   // spb = samples per block (32, or 16 / 8 / 4 on small grids): see nister5_pair_kernel
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
@@ -161,7 +164,8 @@ __device__ __forceinline__ double lane_read(double v, int src) { return __shfl(v
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_fb_kernel(
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid,
-    double *__restrict__ models64) {
+    double *__restrict__ models64, PairGate gate, int per_pair) {
+  if (gate.iters && gate.closed((blockIdx.x * 64) / per_pair) && gate.closed((min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   AccDouble hand[36 + 39];   // this lane's sample: basis | B(z)
@@ -216,7 +220,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // pass -- 700 of the ~7 600 front instructions the lane pairs no longer execute twice.
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_fb_kernel(
-    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid) {
+    const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, PairGate gate, int per_pair) {
+  if (gate.iters && gate.closed((blockIdx.x * 64) / per_pair) && gate.closed((min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   constexpr int kGOff = SturmWs<10>::kDoubles > FinishQueue::kDoubles ? SturmWs<10>::kDoubles : FinishQueue::kDoubles;   // reduced rows of a pass
@@ -345,7 +350,7 @@ static inline bool fivepoint_two_phase(int Bt, int fb_cost_pct) {
 // path: 0 = automatic (fivepoint_two_phase), 1 = lane pairs, 2 = two-phase
 template <typename T>
 int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, uint8_t *valid, hipStream_t st,
-                  double *models64 = nullptr, int path = 0) {
+                  double *models64 = nullptr, int path = 0, PairGate gate = PairGate(), int per_pair = 1) {
   static bool attr_set[64] = {false};   // per device: one process may drive several GPUs
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -361,12 +366,12 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
     if (DR_K3_BALANCED && (path == 2 || (path == 0 && fivepoint_two_phase(Bt, DR_K3_FB_COST_NISTER)))) {
       static_assert(!DR_K3_BALANCED || 70 * 64 <= kNisterPairDoubles, "front stage: rows 0-6 of 64 right blocks");
       hipLaunchKernelGGL((nister5_fb_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, st, samples, weights, Bt, models, valid,
-                         models64);
+                         models64, gate, per_pair);
       return check_launch("nister5_fb_kernel");
     }
     const int spb = samples_per_block(Bt);
     hipLaunchKernelGGL((nister5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, weights, Bt, models,
-                       valid, models64, spb);
+                       valid, models64, spb, gate, per_pair);
     return check_launch("nister5_pair_kernel");
   }
   // n > 5 fallback (refit): one lane per sample, A^T A + eigenvectors in LDS (162 doubles)
@@ -377,7 +382,8 @@ int nister_launch(const T *samples, const T *weights, int Bt, int n, T *models, 
 }
 
 template <typename T>
-int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st, int path = 0) {
+int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStream_t st, int path = 0, PairGate gate = PairGate(),
+                     int per_pair = 1) {
   // the right 10x10 block of 32 samples, later the root-search workspace, then the candidate queue
   constexpr int kDoubles = (FinishQueue::kDoubles > 100 * 32) ? FinishQueue::kDoubles : 100 * 32;
   static_assert(RootWs<10>::kDoubles <= kDoubles && SturmWs<10>::kDoubles <= kDoubles, "root-search workspace");
@@ -387,12 +393,13 @@ int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStr
     constexpr int kFb = 70 * 64 > kBack ? 70 * 64 : kBack;
     static_assert(kFb * sizeof(double) <= 40960, "four blocks per CU");
     hipLaunchKernelGGL((stewenius5_fb_kernel<T>), dim3((Bt + 63) / 64), dim3(64), sizeof(double) * kFb, st, samples, Bt, models,
-                       valid);
+                       valid, gate, per_pair);
     return check_launch("stewenius5_fb_kernel");
   }
   const size_t smem = sizeof(double) * kDoubles;
   const int spb = samples_per_block(Bt);
-  hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, Bt, models, valid, spb);
+  hipLaunchKernelGGL((stewenius5_pair_kernel<T>), dim3((Bt + spb - 1) / spb), dim3(64), smem, st, samples, Bt, models, valid, spb,
+                     gate, per_pair);
   return check_launch("stewenius5_pair_kernel");
 }
 
@@ -484,6 +491,29 @@ int dr_solve_stewenius5_path_f32(const float *samples, int Bt, float *models, ui
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
   return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream, path);
+}
+
+// rounds > 1 of a multi-round test-mode call (P pairs x per_pair minimal samples each, Bt = P * per_pair): blocks whose samples all
+// belong to pairs with iters >= max_iters (the state dr_ransac_update keeps) return at once; their models / valid keep their contents
+int dr_solve_nister5_gated_f32(const float *samples, const float *weights, int Bt, float *models, uint8_t *valid, int per_pair,
+                               const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
+  DR_REQUIRE(samples && models && valid && gate_iters && gate_max_iters, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
+  DR_REQUIRE(Bt > 0 && per_pair > 0 && Bt % per_pair == 0, "need Bt = pairs x per_pair");
+  dr::PairGate gate;
+  gate.iters = gate_iters;
+  gate.max_iters = gate_max_iters;
+  return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, nullptr, 0, gate, per_pair);
+}
+int dr_solve_stewenius5_gated_f32(const float *samples, int Bt, float *models, uint8_t *valid, int per_pair, const int32_t *gate_iters,
+                                  const double *gate_max_iters, void *stream) {
+  DR_REQUIRE(samples && models && valid && gate_iters && gate_max_iters, "null pointer");
+  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
+  DR_REQUIRE(Bt > 0 && per_pair > 0 && Bt % per_pair == 0, "need Bt = pairs x per_pair");
+  dr::PairGate gate;
+  gate.iters = gate_iters;
+  gate.max_iters = gate_max_iters;
+  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream, 0, gate, per_pair);
 }
 
 }  // extern "C"

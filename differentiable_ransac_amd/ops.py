@@ -23,7 +23,7 @@ def _thr_tensor(threshold, P: int, like: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------ K4 / K6
 def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_masks: bool = True,
-               valid: Optional[torch.Tensor] = None, path: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               valid: Optional[torch.Tensor] = None, path: int = 0, gate=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None.
     valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row).
     path (f32 only): 0 = 1 = the general kernels; 2 (the matrix-core candidate filter of round 2, measured slower: DESIGN 2b)
@@ -41,6 +41,12 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
             raise L.DransacError("msac_score: an explicit kernel path exists for f32 only")
         L.call("dr_msac_score_path_f32", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N),
                ptr(scores), ptr(masks), c_int(path), stream())
+        return scores, masks
+    if gate is not None and matches.dtype == torch.float32:
+        # a later round of a multi-round call: the blocks of terminated pairs (gate = RansacState) return at once, their scores
+        # are never looked at (dr_ransac_update skips such pairs)
+        L.call("dr_msac_score_gated_f32", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N), ptr(scores),
+               ptr(masks), ptr(gate.iters), ptr(gate.max_iters), stream())
         return scores, masks
     L.call(f"dr_msac_score_{L.suffix(matches.dtype)}", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M),
            c_int(N), ptr(scores), ptr(masks), stream())
@@ -134,6 +140,12 @@ class DeviceSeed:
         L.call("dr_seed_next", ptr(self.state), ptr(out), stream())
         return out
 
+    def next_n(self, n: int):
+        """the seeds of the next n calls from ONE launch (a multi-round call draws one per round): list of n one-word tensors"""
+        out = torch.empty(n, dtype=torch.int64, device=self.state.device)
+        L.call("dr_seed_next_n", ptr(self.state), ptr(out), c_int(n), stream())
+        return [out[i:i + 1] for i in range(n)]
+
 
 def _dev_seed(seed):
     if torch.is_tensor(seed):
@@ -198,7 +210,7 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
     return out
 
 
-def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0):
+def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None):
     """K1 (index sets only, in-kernel noise) + K2 in one call: matches [P,N,4] f32, logits [P,N] f32 ->
     (idx [P,B,k] int32 ascending, samples [P,B,k,4] = matches[p, idx]).  What test mode asks of sampler + gather
     (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor."""
@@ -209,6 +221,11 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
     idx = torch.empty((P, B, k), device=logits.device, dtype=torch.int32)
     samples = torch.empty((P, B, k, 4), device=logits.device, dtype=torch.float32)
     dev_seed = _dev_seed(seed)
+    if gate is not None:     # a later round of a multi-round call: terminated pairs (gate = RansacState) are skipped
+        L.call("dr_gumbel_topk_gather_gated_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
+               ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
+               ptr(gate.iters), ptr(gate.max_iters), stream())
+        return idx, samples
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
            ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples), stream())
     return idx, samples
@@ -364,6 +381,23 @@ def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = No
     else:
         L.call("dr_solve_nister5_f32_hp", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), stream())
     return models.reshape(*lead, 10, 3, 3), m64.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
+
+
+def solve_essential_gated(samples: torch.Tensor, which: str, gate):
+    """A later round of a multi-round test-mode call: samples [P,B,5,4] f32 -> (models [P,B,10,3,3], valid [P,B,10]); the
+    blocks of pairs that have terminated (gate = RansacState: iters >= max_iters) return at once and leave their part of the
+    outputs unwritten -- dr_ransac_update never looks at it (dr_solve_nister5_gated_f32 / dr_solve_stewenius5_gated_f32)."""
+    P, B = samples.shape[0], samples.shape[1]
+    s = samples.reshape(P * B, 5, 4).contiguous()
+    models = torch.empty((P * B, 10, 3, 3), device=s.device, dtype=torch.float32)
+    valid = torch.empty((P * B, 10), device=s.device, dtype=torch.bool)
+    if which == "nister":
+        L.call("dr_solve_nister5_gated_f32", ptr(s), ptr(None), c_int(P * B), ptr(models), ptr(valid), c_int(B), ptr(gate.iters),
+               ptr(gate.max_iters), stream())
+    else:
+        L.call("dr_solve_stewenius5_gated_f32", ptr(s), c_int(P * B), ptr(models), ptr(valid), c_int(B), ptr(gate.iters),
+               ptr(gate.max_iters), stream())
+    return models.reshape(P, B, 10, 3, 3), valid.reshape(P, B, 10)
 
 
 def debug_real_roots10(coef: torch.Tensor, method: int = 1):

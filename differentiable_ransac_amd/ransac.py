@@ -71,8 +71,10 @@ class RANSAC(object):
         self.eps = eps
         self._soft0 = None       # y_soft of hypothesis 0 of the last batch (weighted F refit, ransac.py:151-153)
         self.fused = True        # test mode with this package's own plugins: run on the device-resident batched driver
+        self.graph = True        # ... and, when a call is at most 8 batches, as ONE replayed HIP graph per call (_GraphedCall)
         self._fast = None
         self._fast_cfg = None
+        self._graphs = {}
         if lo:
             raise NotImplementedError("local optimisation is out of scope (it never ran in the reference either: "
                                       "lo defaults to 0 and lo=3 raises TypeError, SURVEY Q2)")
@@ -127,6 +129,11 @@ class RANSAC(object):
         models = models.reshape(nb, S, 3, 3)
         return models, torch.isfinite(models).flatten(2).all(-1)
 
+    def _make_fast(self, solver, seed=0):
+        return BatchedRANSAC(solver, ransac_batch_size=self.ransac_batch_size, train=False, threshold=self.threshold,
+                             confidence=self.confidence, max_iterations=self.max_iterations, tau=self.sampler.tau,
+                             weighted=self.weighted, refit=True, eps=self.eps, seed=seed)
+
     def _fused_solver(self):
         """Name of the BatchedRANSAC solver equivalent to this object's plugins, or None (custom plugins, uniform
         sampler, train mode): test mode then runs on the device-resident driver with P = 1 -- same result, no host
@@ -154,12 +161,22 @@ class RANSAC(object):
         if solver is not None and matches.is_cuda:
             cfg = (solver, self.ransac_batch_size, self.threshold, self.confidence, self.max_iterations, self.sampler.tau,
                    self.weighted, self.eps)
-            if self._fast is None or self._fast_cfg != cfg:     # public attributes may change between calls (sweeps)
-                self._fast = BatchedRANSAC(solver, ransac_batch_size=self.ransac_batch_size, train=False,
-                                           threshold=self.threshold, confidence=self.confidence,
-                                           max_iterations=self.max_iterations, tau=self.sampler.tau, weighted=self.weighted,
-                                           refit=True, eps=self.eps)
-                self._fast_cfg = cfg
+            if self._fast_cfg != cfg:     # public attributes may change between calls (sweeps)
+                self._fast, self._graphs, self._fast_cfg = None, {}, cfg
+            rounds = max(1, math.ceil(self.max_iterations / self.ransac_batch_size))
+            if (self.graph and gumbels is None and rounds <= 8 and matches.dtype == torch.float32 and not self.weighted
+                    and not torch.cuda.is_current_stream_capturing()):
+                # The reference calls this object one pair at a time (model_cl.py:488-490, test.py:38): ~25 launches of 5-30 us
+                # per pair.  Round 5: the whole call -- threshold, every round, the adaptive stop taken on the device, refit --
+                # is captured once per (point count, device) and replayed: one graph launch + one staging copy per pair.
+                key = (matches.shape[0], matches.device.index)
+                g = self._graphs.get(key)
+                if g is None:
+                    g = self._graphs[key] = _GraphedCall(self._make_fast(solver, seed=self.sampler._next_seed()),
+                                                         matches.shape[0], matches.device)
+                return g(matches, logits, K1, K2)
+            if self._fast is None:
+                self._fast = self._make_fast(solver)
             self._fast.seed = self.sampler._next_seed()
             out = self._fast(matches.unsqueeze(0), logits.unsqueeze(0).to(matches.dtype), K1, K2,
                              gumbels=None if gumbels is None else [g.unsqueeze(0) for g in gumbels])
@@ -245,6 +262,48 @@ class RANSAC(object):
                     b = torch.argmax(scores)
                     best_model, best_score = cand[b], scores[b]
         return best_model, best_mask, best_score, iterations
+
+
+class _GraphedCall(object):
+    """One test-mode RANSAC call on one image pair as a replayed HIP graph (drop-in path of RANSAC.__call__).
+
+    The captured call is BatchedRANSAC with P = 1, seeds advanced on the device (`device_seeds`) and the adaptive stop taken
+    on the device (`device_termination`): every round is in the graph, the kernels of a round skip a pair that has terminated.
+    Inputs are staged into the buffers the graph was captured on (one multi-tensor copy), results are handed out as fresh
+    tensors (one more): the caller keeps them across calls, as `ret.append(Es)` of model_cl.py:492 does.  `iterations` is
+    returned as a 0-dim int32 tensor -- reading it as an int would be the only host synchronisation of the call."""
+
+    def __init__(self, driver, N, device):
+        from .graphs import GraphedStep
+        self.driver = driver.device_seeds(device)
+        driver.device_termination = True
+        self.matches = torch.zeros(1, N, 4, device=device)
+        self.logits = torch.zeros(1, N, device=device)
+        self.K1 = torch.eye(3, device=device).unsqueeze(0).clone()
+        self.K2 = torch.eye(3, device=device).unsqueeze(0).clone()
+        self.matches[0, :, :2] = torch.rand(N, 2, device=device)      # something solvable for the warm-up calls
+        self.matches[0, :, 2:] = self.matches[0, :, :2] + 0.01 * torch.rand(N, 2, device=device)
+        self.step = GraphedStep(self._run, warmup=2)
+
+    def _run(self):
+        out = self.driver(self.matches, self.logits, self.K1, self.K2)
+        u8 = lambda t: t.contiguous().view(torch.uint8).reshape(-1)
+        # one buffer for everything a call returns: model 36 B | score 4 | iterations 4 | mask N (handed out by ONE copy per call)
+        return torch.cat([u8(out["model"][0]), u8(out["score"][:1]), u8(out["iterations"][:1]), u8(out["mask"][0])])
+
+    def __call__(self, matches, logits, K1, K2):
+        src = [matches, logits.to(torch.float32)]
+        dst = [self.matches[0], self.logits[0]]
+        if K1 is not None and K2 is not None:
+            src += [K1.to(device=matches.device, dtype=torch.float32).reshape(3, 3), K2.to(device=matches.device, dtype=torch.float32).reshape(3, 3)]
+            dst += [self.K1[0], self.K2[0]]
+        torch._foreach_copy_(dst, src)
+        packed = self.step().clone()
+        model = packed[:36].view(torch.float32).view(3, 3)
+        score = packed[36:40].view(torch.float32)[0]
+        iterations = packed[40:44].view(torch.int32)[0]
+        mask = packed[44:].view(torch.bool)
+        return model, mask, score, iterations
 
 
 class RANSAC3D(object):
@@ -335,6 +394,11 @@ class BatchedRANSAC(object):
             raise ValueError(f"{sampling} sampling yields index sets only: train mode and weighted=1 need the Gumbel sampler")
         self.sampling = sampling
         self.pipeline = True     # test mode: issue round r+1's sampler/solver on a second stream while round r is scored
+        # test mode, round 5: True = every round of a call is ISSUED and the adaptive stop of ransac.py:135-144 is taken on the
+        # device (the kernels of a round skip the pairs whose counter has reached its bound, ops `gate=`): no read-back, so a
+        # whole call -- however many rounds the data ask for -- is capturable in one HIP graph.  Costs a handful of empty
+        # launches per unneeded round; meant for few rounds (max_iterations / ransac_batch_size <= 8), refused above 16.
+        self.device_termination = False
         self.sync_every = max(1, 256 // max(1, ransac_batch_size))   # rounds between termination read-backs
         self._pipe = None
         self.solver = solver
@@ -358,10 +422,13 @@ class BatchedRANSAC(object):
         self.fmat = solver in ("f8", "f7")
         self._side = None
         self._dev_seed = None
+        self._seed_queue = []
 
     def _next_seed(self):
         if self._dev_seed is not None:       # seeds advanced on the device (device_seeds(): graph-capturable steps)
             self.calls += 1
+            if self._seed_queue:             # drawn ahead for every round of this call by ONE launch (device_termination)
+                return self._seed_queue.pop(0)
             return self._dev_seed.next()
         s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
         self.calls += 1
@@ -379,7 +446,7 @@ class BatchedRANSAC(object):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S], idx [P,B,k] (differentiable w.r.t. logits)."""
         return self._hypotheses(matches, logits, gumbels)[:3]
 
-    def _hypotheses(self, matches, logits, gumbels=None):
+    def _hypotheses(self, matches, logits, gumbels=None, gate=None):
         """hypotheses() + the (seed, noise) pair of the draw when the weighted refit will need row 0's soft weights again
         (returned, not stashed on self: two rounds are in flight on two streams when `pipeline` is on), else None."""
         if self.weighted and self.solver == "f8" and not self.train and self.refit:
@@ -405,8 +472,11 @@ class BatchedRANSAC(object):
             # test mode consumes the index sets only (`points[samples != 0]`, ransac.py:65): no soft-max statistics, and
             # the samples are the points themselves (not points x a straight-through value of 1 +- 1 ulp)
             if gumbels is None and matches.dtype == torch.float32 and logits.dtype == torch.float32 and matches.shape[-1] == 4:
-                idx, samples = ops.gumbel_topk_gather(matches, logits, self.B, self.k, self.tau, self._next_seed())   # one launch
+                idx, samples = ops.gumbel_topk_gather(matches, logits, self.B, self.k, self.tau, self._next_seed(), gate=gate)   # one launch
                 w = None
+                if gate is not None and self.solver in ("nister", "stewenius") and self.k == 5:
+                    models, valid = ops.solve_essential_gated(samples, self.solver, gate)
+                    return models, valid, idx, None
             else:
                 idx = ops.gumbel_topk(logits, self.B, self.k, self.tau, gumbels, self._next_seed(), soft=False)["idx"]
                 samples, w = ops.gather(matches, idx), None
@@ -471,7 +541,8 @@ class BatchedRANSAC(object):
                 self._side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._side):
                     out_ = ops.refit_essential(matches)
-                    matches.record_stream(self._side)
+                    if not torch.cuda.is_current_stream_capturing():
+                        matches.record_stream(self._side)
                 return out_
             # Rounds are pipelined: the hypotheses of round r+1 (sampler + solver, latency-bound, independent of round r's
             # outcome) are issued on a second stream before round r is scored, so they run under K4/K6 and under the
@@ -486,6 +557,29 @@ class BatchedRANSAC(object):
 
             if self.refit and not self.fmat:
                 pre = issue_refit()
+            if self.device_termination:
+                if rounds > 16:
+                    raise ValueError("device_termination issues every round: max_iterations / ransac_batch_size must be <= 16")
+                want_w = bool(self.weighted and self.solver == "f8" and self.refit)
+                last_w = torch.zeros((P, N), device=dev, dtype=dt) if want_w else None
+                if self._dev_seed is not None and rounds > 1 and gumbels is None:
+                    self._seed_queue = self._dev_seed.next_n(rounds)
+                for r in range(rounds):
+                    if not have_round(r):
+                        break
+                    gate = st if r > 0 else None
+                    models, valid, _, row0 = self._hypotheses(matches, logits, noise_of(r), gate=gate)
+                    if want_w:
+                        w0 = ops.soft_weights_row0(logits, self.k, self.tau, row0[1], row0[0])
+                        last_w = torch.where((st.iters.double() < st.max_iters)[:, None], w0, last_w)
+                    flat = models.reshape(P, self.B * self.S, 3, 3)
+                    scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks, valid=valid.reshape(P, -1),
+                                                   gate=gate)
+                    if self.keep_masks:
+                        all_masks = masks
+                    ops.ransac_update(st, matches, flat, valid.reshape(P, -1), scores, thr, self.B, self.k, self.confidence,
+                                      self.eps)
+                return self._finish(st, matches, thr, pre, last_w, all_masks)
             ahead = None
             if have_round(0):
                 h = self._hypotheses(matches, logits, noise_of(0))
@@ -532,21 +626,26 @@ class BatchedRANSAC(object):
                         t_.record_stream(main)
             if ahead is not None and self._pipe is not None:
                 main.wait_stream(self._pipe)              # dropped speculative work: keep the allocator's stream order simple
-            best_score, best_model, best_mask, best_inl, iters = (st.best_score, st.best_model, st.best_mask,
-                                                                  st.best_inliers, st.iters)
-            if self.refit:
-                if self.fmat:
-                    F, fvalid = ops.refit_fundamental(matches, best_mask, last_w)   # (weighted) LSQ on the inliers of the best mask
-                    cand, cvalid = F.unsqueeze(1), fvalid.unsqueeze(1)
-                else:
-                    torch.cuda.current_stream().wait_stream(self._side)
-                    cand, cvalid = pre
+            return self._finish(st, matches, thr, pre, last_w, all_masks)
+
+    def _finish(self, st, matches, thr, pre, last_w, all_masks):
+        """final refit on the inliers of the best model (ransac.py:148-195) and the result dictionary"""
+        best_score, best_model, best_mask, best_inl, iters = (st.best_score, st.best_model, st.best_mask,
+                                                              st.best_inliers, st.iters)
+        if self.refit:
+            if self.fmat:
+                F, fvalid = ops.refit_fundamental(matches, best_mask, last_w)   # (weighted) LSQ on the inliers of the best mask
+                cand, cvalid = F.unsqueeze(1), fvalid.unsqueeze(1)
+            else:
+                torch.cuda.current_stream().wait_stream(self._side)
+                cand, cvalid = pre
+                if not torch.cuda.is_current_stream_capturing():
                     cand.record_stream(torch.cuda.current_stream())
                     cvalid.record_stream(torch.cuda.current_stream())
-                # score the candidates and keep the best one where it beats the RANSAC result: one launch, in place
-                ops.refit_accept(matches, cand, cvalid, thr, best_score, best_model)
-            return dict(model=best_model, mask=best_mask, score=best_score, iterations=iters, inliers=best_inl,
-                        masks=all_masks)
+            # score the candidates and keep the best one where it beats the RANSAC result: one launch, in place
+            ops.refit_accept(matches, cand, cvalid, thr, best_score, best_model)
+        return dict(model=best_model, mask=best_mask, score=best_score, iterations=iters, inliers=best_inl,
+                    masks=all_masks)
 
 
 class BatchedRANSAC3D(object):

@@ -99,6 +99,8 @@ int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, v
  * (mod 2^64), calls += 1: the per-call seed of the batched drivers (ransac.py of this package: `_next_seed`), advanced on
  * the device so that every replay of a captured step draws fresh hypotheses. */
 int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream);
+/* the seeds of the next n (<= 64) calls in one launch: seeds_out[i] = base * 0x9E3779B97F4A7C15 + calls + i, calls += n */
+int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream);
 int dr_gumbel_topk_fwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
                                  int32_t *idx, float *y_sel, float *lse, void *stream);
 int dr_gumbel_topk_fwd_f64_dseed(const double *logits, const uint64_t *seed_dev, double tau, int P, int B, int N, int k,
@@ -115,6 +117,11 @@ int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N
  * sampler kernel serves the shape (N % 4 == 0, N <= 2048, tau == 1), sampler + gather launches otherwise. */
 int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
                               int B, int N, int k, int32_t *idx, float *samples, void *stream);
+/* the same for a round > 1 of a multi-round test-mode call: pairs with gate_iters[p] >= gate_max_iters[p] are skipped (see the
+ * `_gated` solver entries below) */
+int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                                    int P, int B, int N, int k, int32_t *idx, float *samples, const int32_t *gate_iters,
+                                    const double *gate_max_iters, void *stream);
 
 /* K1, index sets only, in-kernel noise, with an optional screening workspace (round 4; GumbelSoftmaxSampler.sample,
  * samplers/gumbel_sampler.py:25-42, as test mode consumes it: `points[samples != 0]`, ransac.py:65).
@@ -186,6 +193,15 @@ int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8
 int dr_solve_nister5_path_f32(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
                               uint8_t *valid, int path, void *stream);
 int dr_solve_stewenius5_path_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, void *stream);
+/* Round 5, device-side termination (ransac.py:135-144: `max_iters = min(max_iterations, adaptive_iteration_number(...))` decides per
+ * pair when the loop of ransac.py:55 ends).  The per-pair counters live on the device (dr_ransac_init / dr_ransac_update: iters [P]
+ * int32, max_iters [P] f64); the `_gated` forms of the kernels of one round take them as a gate: the blocks of a pair with
+ * iters >= max_iters return at once, its outputs keep their contents, and dr_ransac_update leaves its state alone.  The driver can
+ * therefore ISSUE every round of a call without reading anything back -- one HIP graph per call, whatever the data decide. */
+int dr_solve_nister5_gated_f32(const float *samples, const float *weights, int Bt, float *models, uint8_t *valid, int per_pair,
+                               const int32_t *gate_iters, const double *gate_max_iters, void *stream);
+int dr_solve_stewenius5_gated_f32(const float *samples, int Bt, float *models, uint8_t *valid, int per_pair,
+                                  const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 int dr_solve_f8_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
                     void *stream);
 int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n, double *models, uint8_t *valid,
@@ -253,6 +269,8 @@ int dr_msac_score_f64(const double *matches, const double *models, const uint8_t
  *           rows of <= 256 points: a wave per model with 1 / 2 / 4 points per lane, longer rows: a lane owns 8 / 16 points);
  *   path 2  (round 2: matrix-core candidate filter + exact evaluation of the candidates; bit-identical masks, measured slower,
  *           DESIGN.md section 2b) left the library in round 4 (scratch/k4_filter_kernel.patch): DR_EINVAL. */
+int dr_msac_score_gated_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P, int M, int N,
+                            float *scores, uint8_t *masks, const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 int dr_msac_score_path_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
                            int M, int N, float *scores, uint8_t *masks, int path, void *stream);
 /* dL/dmodels [P,M,9] from dL/dscores [P,M] (flows only through points with d2 < thr2). */

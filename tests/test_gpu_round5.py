@@ -87,3 +87,65 @@ def test_two_phase_automatic_choice_at_config_size(dev):
         for c in (1, 17, 31):
             blk = Ea[4096 * c:4096 * (c + 1)]
             assert torch.equal(blk[7:], ref[7:])
+
+
+# ------------------------------------------------------------------------------------- device-side termination, the drop-in as a graph
+def _hard_pairs(dev, P, N=2000, pixel=False):
+    """pairs with inlier ratios from 0.5 down to 0.2: the adaptive bound of ransac.py:135-144 asks for 1 to 5 batches of 1024"""
+    from differentiable_ransac_amd import synth
+    items = [synth.two_view_pair(100 + p, N, inlier_ratio=(0.5, 0.3, 0.2, 0.35)[p % 4], pixel=pixel) for p in range(P)]
+    st = lambda k: torch.stack([it[k] for it in items]).to(dev)
+    return st("matches"), st("logits"), st("K1"), st("K2")
+
+
+@pytest.mark.parametrize("solver", ["nister", "stewenius", "f8"])
+def test_device_termination_equals_the_host_loop(dev, solver):
+    """every round issued, the kernels of a round skipping the pairs that have terminated (gated entry points), against the
+    driver that reads the per-pair counters back after every round: same best model, mask, score and iteration count"""
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    m, lg, K1, K2 = _hard_pairs(dev, 4, pixel=solver == "f8")
+    kw = dict(ransac_batch_size=1024, threshold=0.75, max_iterations=5000, seed=11, refit=True)
+    host = BatchedRANSAC(solver, **kw)
+    devt = BatchedRANSAC(solver, **kw)
+    devt.device_termination = True
+    for call in range(2):
+        a = host(m, lg, K1, K2)
+        b = devt(m, lg, K1, K2)
+        for key in ("model", "mask", "score", "inliers", "iterations"):
+            assert torch.equal(a[key], b[key]), (key, call)
+    its = a["iterations"].tolist()
+    assert max(its) >= 3072, its
+    if solver != "f8":                                      # (eight-point samples at these inlier ratios: every pair runs all five batches)
+        assert min(its) < max(its), its                     # the pairs really stop after different numbers of batches
+
+
+def test_dropin_ransac_replays_a_graph_per_call(dev):
+    """RANSAC.__call__ (test mode, this package's plugins, max_iterations <= 8 batches) = one replayed HIP graph per pair:
+    pair after pair the results of a BatchedRANSAC with the same base seed, seeds and termination on the device, run eagerly;
+    the tensors handed out stay what they were when the next pair overwrites the graph's buffers"""
+    from differentiable_ransac_amd import estimators, samplers, scorings
+    from differentiable_ransac_amd.ransac import RANSAC, BatchedRANSAC
+    m, lg, K1, K2 = _hard_pairs(dev, 6)
+    smp = samplers.GumbelSoftmaxSampler(1024, 5, device=dev, seed=3)
+    rn = RANSAC(estimators.EssentialMatrixEstimatorNister(dev), smp, scorings.MSACScore(dev), train=False,
+                ransac_batch_size=1024, sampler_id=2, threshold=0.75, max_iterations=5000)
+    base = (3 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)          # the sampler's first seed: the graph's base seed
+    ref = BatchedRANSAC("nister", ransac_batch_size=1024, threshold=0.75, max_iterations=5000, seed=base, refit=True).device_seeds(dev)
+    ref.device_termination = True
+    for _ in range(2):                                         # the two warm-up calls of the capture advanced the device seed
+        ref(m[:1], lg[:1], K1[:1], K2[:1])
+    ref.calls = 0
+    kept = []
+    for p in range(6):
+        model, mask, score, iters = rn(m[p], lg[p], K1[p], K2[p], None)
+        want = ref(m[p:p + 1], lg[p:p + 1], K1[p:p + 1], K2[p:p + 1])
+        assert torch.equal(model, want["model"][0]) and torch.equal(mask, want["mask"][0])
+        assert torch.equal(score, want["score"][0]) and int(iters) == int(want["iterations"][0])
+        kept.append((model, mask, score.clone(), want["model"][0].clone(), want["mask"][0].clone()))
+    for model, mask, _, wm, wk in kept:
+        assert torch.equal(model, wm) and torch.equal(mask, wk)
+    assert len(rn._graphs) == 1
+    # the eager fused path is still there (explicit noise, or graph = False) and agrees on the interface
+    rn.graph = False
+    model, mask, score, iters = rn(m[0], lg[0], K1[0], K2[0], None)
+    assert model.shape == (3, 3) and mask.shape == (2000,) and isinstance(iters, int)
