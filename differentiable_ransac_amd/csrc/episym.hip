@@ -15,6 +15,62 @@ constexpr int kEPw = 16, kEPass = 64 * kEPw;     // a wave holds 16 points per l
 typedef float ev2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ev2 esplat(float a) { return (ev2){a, a}; }
 
+constexpr int kMeanT = 1024;
+// number of non-zero bytes among the 16 of a uint4 (the masks are torch.bool tensors, but the contract is "!= 0")
+__device__ __forceinline__ int nonzero_bytes(uint4 v) {
+  auto nz = [](uint32_t w) { return __popc((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); };
+  return nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+}
+// count of non-zero bytes of row[0..n) by one wave: 16-byte loads when the row allows it (every lane's loads are independent:
+// the byte-at-a-time loop of the per-pair kernel is a chain of ~30 dependent memory round trips per pair)
+__device__ __forceinline__ int wave_count_nonzero(const uint8_t *row, int n, int lane) {
+  int c = 0;
+  if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+    for (int i = lane; i < (n >> 4); i += 64) c += nonzero_bytes(r4[i]);
+  } else {
+    for (int i = lane; i < n; i += 64) c += row[i] != 0;
+  }
+  return wave_sum(c);
+}
+// per-pair means and their mean by the `nwaves` waves of ONE block (fixed reduction order); s_tot: nwaves floats of LDS
+__device__ __forceinline__ void match_loss_reduce(const float *__restrict__ sums, const uint8_t *__restrict__ mask,
+                                                  const uint8_t *__restrict__ keep, int P, int M, int N, float *__restrict__ per_pair,
+                                                  float *__restrict__ coef, float *__restrict__ mean, float *s_tot, int nwaves) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float wave_total = 0.f;
+  for (int p = wv; p < P; p += nwaves) {
+    float acc = 0.f;
+    const float *sp = sums + (size_t)p * M;
+    if ((M & 3) == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+      const float4 *s4 = reinterpret_cast<const float4 *>(sp);
+      for (int i = lane; i < (M >> 2); i += 64) {
+        const float4 v = s4[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int m = lane; m < M; m += 64) acc += sp[m];
+    }
+    acc = wave_sum(acc);
+    const int n_in = mask ? wave_count_nonzero(mask + (size_t)p * N, N, lane) : N;
+    const int n_kept = keep ? wave_count_nonzero(keep + (size_t)p * M, M, lane) : M;
+    const float den = fmaxf((float)n_in * (float)n_kept, 1.0f);
+    if (lane == 0) {
+      per_pair[p] = acc / den;
+      coef[p] = 1.0f / den;
+    }
+    wave_total += acc / den;
+  }
+  if (lane == 0) s_tot[wv] = wave_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < nwaves; ++w) t += s_tot[w];
+    mean[0] = t / (float)P;
+  }
+}
+
+
 // v4 (v2 = mask compaction + packed f32 + v_rcp_f32; v3 = a wave takes its models over ALL compacted points, one DPP
 // reduction per accumulator and wave).  The points selected by the mask (the GT inliers: half of the points at C2) are
 // compacted per block, so no lane evaluates a point whose weight is 0.  v3 ran the compaction (mask bytes, wave scans, three
@@ -23,14 +79,22 @@ __device__ __forceinline__ ev2 esplat(float a) { return (ev2){a, a}; }
 // 8 x `groups` models: every wave takes `groups` groups of two, and when the selected points fit one pass (<= 1024 of <= 2048:
 // the training shape) they are loaded ONCE and stay in VGPRs for all groups.  `groups` is chosen per launch so that the grid
 // is one round of resident waves where the shape allows it (episym_groups below).
-template <bool kBackward>
+// kMode 0 = forward (sums), 1 = backward (scaled gradient), 2 = round 5: BOTH in one pass -- the loss is a scalar mean, so its
+// gradient w.r.t. a model is (one number per pair) x a quantity the forward can write while it holds the residuals in registers:
+// out = the UNSCALED gradient d sums[p,m] / d M [P,M,9], out2 = sums [P,M].  The training step then walks the (model x point) grid
+// once instead of twice (dr_match_loss_fused_f32 / dr_match_loss_scale_f32 below).  (Built first with the per-pair reduction in the
+// SAME launch -- the block that takes the last ticket reduces: 166 us instead of 82 for forward + backward, because the agent-scope
+// release every block needs before its ticket is an L2 write-back on a part with eight L2s; the reduction stays a launch of its own.)
+template <int kMode>
 __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ matches, const uint8_t *__restrict__ mask,
                                                      const float *__restrict__ models, const uint8_t *__restrict__ valid,
                                                      const float *__restrict__ grad_sums, int grad_per_pair, int M,
                                                      int N, float *__restrict__ out, int groups,
-                                                     const float *__restrict__ grad_scalar, float scalar_scale) {
+                                                     const float *__restrict__ grad_scalar, float scalar_scale,
+                                                     float *__restrict__ out2 = nullptr) {
   // forward: out = sums [P,M]; backward: out = grad_models [P,M,9]
-  constexpr int kV = kBackward ? 9 : 1;
+  constexpr bool kBackward = kMode != 0;
+  constexpr int kV = kMode == 0 ? 1 : (kMode == 1 ? 9 : 10);
   __shared__ int s_list[kEChunk];
   __shared__ int s_wave[kET / 64];
   const int p = blockIdx.z, m0 = blockIdx.x * kEMperGroup * groups;
@@ -132,11 +196,12 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
             ia[0] = __builtin_amdgcn_rcpf(da[0]); ia[1] = __builtin_amdgcn_rcpf(da[1]);
             const ev2 rr = r * r, s = ib + ia;
             const ev2 ys = rr * s;
-            if (!kBackward) {
+            if (kMode != 1) {
               ev2 cl;
               cl[0] = fminf(ys[0], 1.0f); cl[1] = fminf(ys[1], 1.0f);
-              acc[mi][0] = cl * w[j] + acc[mi][0];
-            } else {
+              acc[mi][kMode == 0 ? 0 : 9] = cl * w[j] + acc[mi][kMode == 0 ? 0 : 9];
+            }
+            if (kBackward) {
               ev2 live;   // the clamp passes no gradient at or above 1
               live[0] = ys[0] < 1.0f ? w[j][0] : 0.f;
               live[1] = ys[1] < 1.0f ? w[j][1] : 0.f;
@@ -163,13 +228,17 @@ __global__ __launch_bounds__(kET) void episym_kernel(const float *__restrict__ m
       const int m = mg + mi;
       if (m >= M) continue;
       // backward: d loss / d sums[p,m] = grad_sums (per model or per pair) x, for the fused mean, the upstream scalar / P
-      const float gs = kBackward ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] *
-                                       (grad_scalar ? grad_scalar[0] * scalar_scale : 1.f)
-                                 : 1.f;
+      const float gs = kMode == 1 ? grad_sums[grad_per_pair ? (size_t)p : (size_t)p * M + m] *
+                                        (grad_scalar ? grad_scalar[0] * scalar_scale : 1.f)
+                                  : 1.f;
 #pragma unroll
       for (int q = 0; q < kV; ++q) {
         const float v = wave_sum_lane63(acc[mi][q][0] + acc[mi][q][1]);
-        if (lane == 63) out[((size_t)p * M + m) * kV + q] = v * gs;
+        if (kMode == 2 && q == 9) {
+          if (lane == 63) out2[(size_t)p * M + m] = v;
+        } else if (lane == 63) {
+          out[((size_t)p * M + m) * (kMode == 0 ? 1 : 9) + q] = v * gs;
+        }
       }
     }
   }
@@ -213,60 +282,20 @@ __global__ __launch_bounds__(kET) void match_loss_pair_kernel(const float *__res
 // P results in ONE launch -- a 1024-thread block whose sixteen waves take the pairs in turn (a pair is M sums + N mask bytes:
 // nothing), fixed reduction order.  Replaces, per training step, a torch mean kernel and the two small kernels of its
 // backward; for P <= 64 (a rank's pairs), beyond that the per-pair kernel + torch.mean stay.
-constexpr int kMeanT = 1024;
-// number of non-zero bytes among the 16 of a uint4 (the masks are torch.bool tensors, but the contract is "!= 0")
-__device__ __forceinline__ int nonzero_bytes(uint4 v) {
-  auto nz = [](uint32_t w) { return __popc((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); };
-  return nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
-}
-// count of non-zero bytes of row[0..n) by one wave: 16-byte loads when the row allows it (every lane's loads are independent:
-// the byte-at-a-time loop of the per-pair kernel is a chain of ~30 dependent memory round trips per pair)
-__device__ __forceinline__ int wave_count_nonzero(const uint8_t *row, int n, int lane) {
-  int c = 0;
-  if ((n & 15) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
-    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
-    for (int i = lane; i < (n >> 4); i += 64) c += nonzero_bytes(r4[i]);
-  } else {
-    for (int i = lane; i < n; i += 64) c += row[i] != 0;
-  }
-  return wave_sum(c);
-}
 __global__ __launch_bounds__(kMeanT) void match_loss_mean_kernel(const float *__restrict__ sums, const uint8_t *__restrict__ mask,
                                                                 const uint8_t *__restrict__ keep, int P, int M, int N,
                                                                 float *__restrict__ per_pair, float *__restrict__ coef,
                                                                 float *__restrict__ mean) {
   __shared__ float s_tot[kMeanT / 64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float wave_total = 0.f;
-  for (int p = wv; p < P; p += kMeanT / 64) {
-    float acc = 0.f;
-    const float *sp = sums + (size_t)p * M;
-    if ((M & 3) == 0 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
-      const float4 *s4 = reinterpret_cast<const float4 *>(sp);
-      for (int i = lane; i < (M >> 2); i += 64) {
-        const float4 v = s4[i];
-        acc += (v.x + v.y) + (v.z + v.w);
-      }
-    } else {
-      for (int m = lane; m < M; m += 64) acc += sp[m];
-    }
-    acc = wave_sum(acc);
-    const int n_in = mask ? wave_count_nonzero(mask + (size_t)p * N, N, lane) : N;
-    const int n_kept = keep ? wave_count_nonzero(keep + (size_t)p * M, M, lane) : M;
-    const float den = fmaxf((float)n_in * (float)n_kept, 1.0f);
-    if (lane == 0) {
-      per_pair[p] = acc / den;
-      coef[p] = 1.0f / den;
-    }
-    wave_total += acc / den;
-  }
-  if (lane == 0) s_tot[wv] = wave_total;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < kMeanT / 64; ++w) t += s_tot[w];
-    mean[0] = t / (float)P;
-  }
+  match_loss_reduce(sums, mask, keep, P, M, N, per_pair, coef, mean, s_tot, kMeanT / 64);
+}
+
+__global__ __launch_bounds__(kET) void match_loss_scale_kernel(const float *__restrict__ grad_unscaled, const float *__restrict__ coef,
+                                                              const float *__restrict__ grad_mean, float inv_pairs, int per_pair,
+                                                              size_t total, float *__restrict__ grad_models) {
+  // grad_models[p, m, q] = grad_unscaled[p, m, q] * coef[p] * (upstream scalar) / P
+  const size_t i = (size_t)blockIdx.x * kET + threadIdx.x;
+  if (i < total) grad_models[i] = grad_unscaled[i] * (coef[i / per_pair] * grad_mean[0] * inv_pairs);
 }
 
 }  // namespace dr
@@ -295,7 +324,7 @@ int dr_episym_fwd_f32(const float *matches, const uint8_t *mask, const float *mo
   DR_REQUIRE(matches && models && sums, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
-  hipLaunchKernelGGL((dr::episym_kernel<false>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+  hipLaunchKernelGGL((dr::episym_kernel<0>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
                      (hipStream_t)stream, matches, mask, models, valid, (const float *)nullptr, 0, M, N, sums, groups,
                      (const float *)nullptr, 1.0f);
   return dr::check_launch("episym_kernel");
@@ -306,7 +335,7 @@ int dr_episym_bwd_f32(const float *matches, const uint8_t *mask, const float *mo
   DR_REQUIRE(matches && models && grad_sums && grad_models, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
-  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+  hipLaunchKernelGGL((dr::episym_kernel<1>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
                      (hipStream_t)stream, matches, mask, models, valid, grad_sums, 0, M, N, grad_models, groups,
                      (const float *)nullptr, 1.0f);
   return dr::check_launch("episym_kernel");
@@ -317,7 +346,7 @@ int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const floa
   DR_REQUIRE(matches && models && grad_pair && grad_models, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
-  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+  hipLaunchKernelGGL((dr::episym_kernel<1>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
                      (hipStream_t)stream, matches, mask, models, valid, grad_pair, 1, M, N, grad_models, groups,
                      (const float *)nullptr, 1.0f);
   return dr::check_launch("episym_kernel");
@@ -328,10 +357,38 @@ int dr_episym_bwd_mean_f32(const float *matches, const uint8_t *mask, const floa
   DR_REQUIRE(matches && models && coef && grad_mean && grad_models, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
-  hipLaunchKernelGGL((dr::episym_kernel<true>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
+  hipLaunchKernelGGL((dr::episym_kernel<1>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0,
                      (hipStream_t)stream, matches, mask, models, valid, coef, 1, M, N, grad_models, groups, grad_mean,
                      1.0f / (float)P);
   return dr::check_launch("episym_kernel");
+}
+
+/* Round 5: MatchLoss (loss.py:107-153) value + gradient in one pass over the (model x point) grid.  dr_match_loss_fused_f32: sums
+ * [P,M], per_pair [P], coef [P], mean [1] as dr_episym_fwd + dr_match_loss_mean produce them (the second launch is issued here), plus
+ * grad_unscaled [P,M,9] = d sums[p,m] / d model (invalid slots 0).  dr_match_loss_scale_f32: grad_models = grad_unscaled x coef[p] x
+ * grad_mean / P -- the whole backward of the loss. */
+int dr_match_loss_fused_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid, int P, int M, int N,
+                            float *sums, float *grad_unscaled, float *per_pair, float *coef, float *mean, void *stream) {
+  DR_REQUIRE(matches && models && sums && grad_unscaled && per_pair && coef && mean, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
+  const int groups = dr::episym_groups(P, M, 4), per_block = dr::kEMperGroup * groups;
+  hipLaunchKernelGGL((dr::episym_kernel<2>), dim3((M + per_block - 1) / per_block, 1, P), dim3(dr::kET), 0, (hipStream_t)stream,
+                     matches, mask, models, valid, (const float *)nullptr, 0, M, N, grad_unscaled, groups, (const float *)nullptr,
+                     1.0f, sums);
+  if (int rc = dr::check_launch("episym_kernel<fused>")) return rc;
+  hipLaunchKernelGGL(dr::match_loss_mean_kernel, dim3(1), dim3(dr::kMeanT), 0, (hipStream_t)stream, sums, mask, valid, P, M, N,
+                     per_pair, coef, mean);
+  return dr::check_launch("match_loss_mean_kernel");
+}
+
+int dr_match_loss_scale_f32(const float *grad_unscaled, const float *coef, const float *grad_mean, int P, int M, float *grad_models,
+                            void *stream) {
+  DR_REQUIRE(grad_unscaled && coef && grad_mean && grad_models, "null pointer");
+  DR_REQUIRE(P > 0 && M > 0, "bad sizes");
+  const size_t total = (size_t)P * M * 9;
+  hipLaunchKernelGGL(dr::match_loss_scale_kernel, dim3((unsigned)((total + dr::kET - 1) / dr::kET)), dim3(dr::kET), 0,
+                     (hipStream_t)stream, grad_unscaled, coef, grad_mean, 1.0f / (float)P, M * 9, total, grad_models);
+  return dr::check_launch("match_loss_scale_kernel");
 }
 
 int dr_match_loss_mean_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,

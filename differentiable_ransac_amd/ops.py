@@ -974,14 +974,56 @@ class _MatchLossMean(torch.autograd.Function):
         return None, None, gm, None
 
 
+class _MatchLossFused(torch.autograd.Function):
+    """MatchLoss value AND gradient in one pass (round 5: dr_match_loss_fused_f32): the forward writes, next to the loss, the
+    unscaled gradient of every model; the backward is one elementwise launch (x coef[p] x upstream / P) -- no second walk over
+    the (model x point) grid.  Taken in training (the models require grad)."""
+
+    @staticmethod
+    def forward(ctx, matches, mask, models, keep):
+        P, N, _ = matches.shape
+        M = models.shape[1]
+        matches, models = matches.contiguous(), models.contiguous()
+        mk = None if mask is None else mask.contiguous().view(torch.uint8)
+        v = None if keep is None else keep.contiguous().view(torch.uint8)
+        dev, dt = matches.device, matches.dtype
+        sums = torch.empty((P, M), device=dev, dtype=dt)
+        gun = torch.empty((P, M, 3, 3), device=dev, dtype=dt)
+        per_pair = torch.empty((P,), device=dev, dtype=dt)
+        coef = torch.empty((P,), device=dev, dtype=dt)
+        mean = torch.empty((), device=dev, dtype=dt)
+        L.call("dr_match_loss_fused_f32", ptr(matches), ptr(mk), ptr(models), ptr(v), c_int(P), c_int(M), c_int(N), ptr(sums),
+               ptr(gun), ptr(per_pair), ptr(coef), ptr(mean), stream())
+        ctx.save_for_backward(gun, coef)
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        gun, coef = ctx.saved_tensors
+        P, M = gun.shape[0], gun.shape[1]
+        gm = torch.empty_like(gun)
+        L.call("dr_match_loss_scale_f32", ptr(gun), ptr(coef), ptr(g.to(gun.dtype).contiguous()), c_int(P), c_int(M), ptr(gm),
+               stream())
+        return None, None, gm, None
+
+
 def match_loss_mean(matches, mask, models, keep=None):
     """MatchLoss of a batch: mean over pairs of the per-pair means (match_loss_per_pair(...).mean()) -> scalar, with the mean
-    and its backward folded into the kernels (P <= 64; larger batches take the per-pair kernel + torch.mean)."""
+    and its backward folded into the kernels (P <= 64; larger batches take the per-pair kernel + torch.mean).  When the models
+    require grad (training), value and gradient come from ONE pass over the (model x point) grid (_MatchLossFused)."""
     if matches.dtype != torch.float32:
         raise L.DransacError("match_loss_mean is implemented for f32")
+    models = models.reshape(models.shape[0], -1, 3, 3)
+    if FUSED_MATCH_LOSS and torch.is_grad_enabled() and models.requires_grad:
+        return _MatchLossFused.apply(matches, mask, models, keep)
     if matches.shape[0] > 64:
         return match_loss_per_pair(matches, mask, models, keep).mean()
-    return _MatchLossMean.apply(matches, mask, models.reshape(models.shape[0], -1, 3, 3), keep)
+    return _MatchLossMean.apply(matches, mask, models, keep)
+
+
+FUSED_MATCH_LOSS = True   # tests / A-B runs: False = the two-pass form of rounds 3-4
 
 
 def match_loss_per_pair(matches, mask, models, keep=None):

@@ -434,6 +434,14 @@ int dr_episym_bwd_pair_f32(const float *matches, const uint8_t *mask, const floa
  *   per_pair / coef as above and mean[0] = sum_p per_pair[p] / P.  dr_episym_bwd_mean is the matching backward:
  *   d loss / d sums[p,m] = grad_mean[0] * coef[p] / P (grad_mean = the upstream gradient of the scalar, one float in device
  *   memory), so no per-pair gradient tensor is formed on the host side. */
+/* Round 5: MatchLoss value + gradient in ONE pass over the (model x point) grid (the loss is a scalar mean: its gradient w.r.t. a
+ * model is one number per pair times a quantity the forward can write while it holds the residuals in registers).
+ * dr_match_loss_fused_f32 = dr_episym_fwd + dr_match_loss_mean + the unscaled gradient grad_unscaled [P,M,9] = d sums[p,m] / d model.
+ * dr_match_loss_scale_f32: grad_models = grad_unscaled x coef[p] x grad_mean[0] / P, the whole backward of the loss. */
+int dr_match_loss_fused_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid, int P, int M, int N,
+                            float *sums, float *grad_unscaled, float *per_pair, float *coef, float *mean, void *stream);
+int dr_match_loss_scale_f32(const float *grad_unscaled, const float *coef, const float *grad_mean, int P, int M, float *grad_models,
+                            void *stream);
 int dr_match_loss_mean_f32(const float *sums, const uint8_t *mask, const uint8_t *keep, int P, int M, int N,
                            float *per_pair, float *coef, float *mean, void *stream);
 int dr_episym_bwd_mean_f32(const float *matches, const uint8_t *mask, const float *models, const uint8_t *valid,

@@ -149,3 +149,48 @@ def test_dropin_ransac_replays_a_graph_per_call(dev):
     rn.graph = False
     model, mask, score, iters = rn(m[0], lg[0], K1[0], K2[0], None)
     assert model.shape == (3, 3) and mask.shape == (2000,) and isinstance(iters, int)
+
+
+# ------------------------------------------------------------------------------------- MatchLoss: value + gradient in one pass
+@pytest.mark.parametrize("N", [2000, 1000, 513])
+def test_match_loss_value_and_gradient_in_one_pass(dev, N):
+    """loss.py:107-153: the fused kernel (sums, per-pair means, their mean and the unscaled gradient of every model from ONE walk over
+    the (model x point) grid, backward = one elementwise launch) against the two-pass form of rounds 3-4 and against torch autograd
+    through the f64 restatement of batch_episym (cv_utils.py:680-695) -- incl. slots that are not kept and an empty mask row"""
+    from differentiable_ransac_amd import ops, synth
+    P, M = 3, 300
+    d = synth.batch_two_view(P, N, seed0=5)
+    gen = torch.Generator().manual_seed(N)
+    models = torch.randn(P, M, 3, 3, generator=gen).to(dev) * 0.5 + d["gt_E"][:, None].to(dev)
+    keep = (torch.rand(P, M, generator=gen) < 0.7).to(dev)
+    mask = d["inliers"].to(dev).clone()
+    mask[2] = False                                   # a pair without ground-truth inliers: loss 0, gradient 0
+    m = d["matches"].to(dev)
+    out = {}
+    for fused in (True, False):
+        ops.FUSED_MATCH_LOSS = fused
+        try:
+            md = models.clone().requires_grad_(True)
+            loss = ops.match_loss_mean(m, mask, md, keep)
+            (loss * 3.0).backward()
+            out[fused] = (loss.detach(), md.grad.clone())
+        finally:
+            ops.FUSED_MATCH_LOSS = True
+    (la, ga), (lb, gb) = out[True], out[False]
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+    assert float((ga - gb).abs().max()) <= 2e-5 * max(1e-6, float(gb.abs().max()))
+    assert float(ga[~keep].abs().max()) == 0.0 and float(ga[2].abs().max()) == 0.0
+    # f64 autograd of the formula
+    md = models.double().cpu().requires_grad_(True)
+    x1 = torch.cat((m[..., :2], torch.ones_like(m[..., :1])), -1).double().cpu()
+    x2 = torch.cat((m[..., 2:], torch.ones_like(m[..., :1])), -1).double().cpu()
+    Fx1 = torch.einsum("pmij,pnj->pmni", md, x1)
+    Ftx2 = torch.einsum("pmji,pnj->pmni", md, x2)
+    r = (x2[:, None] * Fx1).sum(-1)
+    ys = r ** 2 * (1 / (Fx1[..., 0] ** 2 + Fx1[..., 1] ** 2 + 1e-15) + 1 / (Ftx2[..., 0] ** 2 + Ftx2[..., 1] ** 2 + 1e-15))
+    w = mask.cpu().double()[:, None, :] * keep.cpu().double()[:, :, None]
+    den = (mask.cpu().double().sum(1) * keep.cpu().double().sum(1)).clamp(min=1.0)
+    ref = ((ys.clamp(max=1.0) * w).sum((1, 2)) / den).mean()
+    (ref * 3.0).backward()
+    assert abs(float(la) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert float((ga.double().cpu() - md.grad).abs().max()) <= 2e-4 * float(md.grad.abs().max())
