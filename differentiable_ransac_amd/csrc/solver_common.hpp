@@ -104,6 +104,9 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
 #define DR_K3_STURM_DRAIN 0   // 1: emitting an isolated interval does not cost a step of the isolation loop (round 5: 13 -> 11 steps for
                               // the slowest lane of a wave, but every step pays the extra loop: 165.1 -> 170.9 us at 131 072 samples; off)
 #endif
+#ifndef DR_K3_STURM_FALLBACK
+#define DR_K3_STURM_FALLBACK 1   // 1: lanes whose Sturm chain loses a degree walk the derivative chain instead (round 5)
+#endif
 #ifndef DR_K3_SYMG
 #define DR_K3_SYMG 1          // 1: the six distinct entries of E E^T once in Nister's lane-pair kernel (constraint_rows; round 5)
 #endif
@@ -593,6 +596,103 @@ __device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The derivative chain once more, COMPACT: every loop rolled, every array in LDS (dynamic indices), plain bisection -- ~200
+// instructions and a dozen registers instead of the ~7 500 instructions of real_roots_half_wave.  It is the fallback of the Sturm
+// isolation (round 5) for the lanes whose chain lost a degree: rare, so its speed (tens of thousands of dependent FMAs) does not
+// matter, but its footprint does -- inlined next to the hot path, the unrolled version cost the Stewenius kernels 2-3 % through
+// the register allocation alone.  No division, no assumption about the degree: a vanishing leading coefficient only makes the
+// top derivatives vanish.  At the last level a critical point of p (a breakpoint between two brackets WITHOUT a sign change) at
+// which |p| is at rounding level is reported as a root: a root of even multiplicity, which no sign test can see (the reference's
+// eigvals returns it as a close real pair, or as a complex pair whose real parts it keeps, Q10).
+// LDS: 3 x (D + 1) x 64 doubles at `ws` (<= SturmWs<D>::kDoubles).  Every lane of the wave must call it (lanes without a polynomial: pass 1 + z^D).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void real_roots_half_compact(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count, double *ws,
+                                                        int lane) {
+  double *CH = ws + lane, *Q = ws + (D + 1) * 64 + lane, *PT = ws + 2 * (D + 1) * 64 + lane;
+  double cmax = 0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
+  const bool ok = is_finite(cmax) && cmax > 0;
+  const double sc = ok ? 1.0 / cmax : 0.0;
+#pragma unroll
+  for (int i = 0; i <= D; ++i) {
+    const double a = ok ? c[i] * sc : (i == 0 ? 1.0 : 0.0);
+    const double b = ok ? c[D - i] * sc : (i == 0 ? 1.0 : 0.0);
+    CH[i * 64] = outer ? b : a;
+    PT[i * 64] = i == 0 ? -1.0 : 1.0;
+  }
+  unsigned has = 0, flat = 0;
+#pragma unroll 1
+  for (int d = 1; d <= D; ++d) {
+    // q = p^(D-d): q_i = ch[i + D - d] * (i + D - d)! / i!
+#pragma unroll 1
+    for (int i = 0; i <= d; ++i) {
+      double f = 1.0;
+#pragma unroll 1
+      for (int t = 0; t < D - d; ++t) f *= (double)(i + D - d - t);
+      Q[i * 64] = CH[(i + D - d) * 64] * f;
+    }
+    auto evalq = [&](double x) {
+      double fx = Q[d * 64];
+#pragma unroll 1
+      for (int i = d - 1; i >= 0; --i) fx = fx * x + Q[i * 64];
+      return fx;
+    };
+    has = 0;
+    flat = 0;
+    double lo = PT[0];
+    double fprev = evalq(lo);
+#pragma unroll 1
+    for (int i = 0; i < d; ++i) {
+      // the brackets of a level are cut at the OLD breakpoints: the right end is read before the slot takes the level's result
+      const double hi = (i == d - 1) ? 1.0 : PT[(i + 1) * 64];
+      const double fhi = evalq(hi);
+      // a level polynomial that vanishes AT the left end (a root of p at 0 is a breakpoint of every level): its sign just inside
+      if (fprev == 0.0 && hi > lo) fprev = evalq(__builtin_fma(hi - lo, 1e-7, lo));
+      const bool h = ((fprev < 0) != (fhi < 0)) && (hi > lo);
+      double a = lo, b = hi;
+      const bool neg_a = fprev < 0;
+      if (__any(h)) {
+#pragma unroll 1
+        for (int it = 0; it < 48; ++it) {
+          const double m = 0.5 * (a + b);
+          const double fm = evalq(m);
+          const bool left = (fm < 0) == neg_a, hit = fm == 0.0;
+          a = (left || hit) ? m : a;
+          b = (left && !hit) ? b : m;
+        }
+      }
+      PT[(i + 1) * 64] = h ? 0.5 * (a + b) : hi;
+      has |= h ? (1u << i) : 0u;
+      // |p| at the right end of bracket i (coefficients: max 1); not near 0: an even-fold root of the REVERSED polynomial there is a
+      // root of p at infinity (vanishing leading coefficients), and a constant p would otherwise "vanish" (w^D) all around it
+      if (d == D && i < d - 1 && fabs(fhi) <= 1e-11 && fabs(hi) > 1e-3) flat |= 1u << i;
+      fprev = fhi;
+      lo = hi;
+    }
+  }
+  // bracket i empty, bracket i + 1 empty, p(their common end) = 0: slot i holds that end
+  unsigned mk = has | (flat & ~has & ~(has >> 1));
+  if (!ok) mk = 0;
+  count = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) roots[i] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < D; ++k) {
+    const double xk = PT[(k + 1) * 64];
+    const bool take = ((mk >> k) & 1u) && (!outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0));
+    if (take) Q[count * 64] = outer ? 1.0 / xk : xk;   // (the level polynomials are dead)
+    count += take ? 1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const double r = Q[i * 64];
+    roots[i] = (i < count) ? r : 0.0;
+  }
+}
+
 // wave-cooperative (block = one wave): every lane must call it.  Same outputs as real_roots_half_wave.
 template <int D, int kBisLast = DR_ROOT_BIS_LAST, int kNewtLast = DR_ROOT_NEWT_LAST>
 __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count, double *lds_ws,
@@ -629,11 +729,20 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
 #pragma unroll
   for (int i = 0; i < D; ++i) F[1][i] = F[0][i + 1] * (double)(i + 1);
   renorm(F[1], D - 1);
+  // Round 5 (review of rounds 3-4): the static-degree pseudo-remainder below divides -- in effect -- by the leading coefficient b of
+  // every chain member.  Where b is at rounding level against the member's largest coefficient (1 after renorm) the member has
+  // lost a degree (p itself of lower degree: a vanishing leading coefficient; or a common factor of p and p': a multiple root) and
+  // the signs that follow are noise: the counts come out inconsistent and the interval logic below DROPS roots.  Such a lane
+  // (`degenerate`) takes its polynomial through the derivative chain afterwards (real_roots_half_wave: no division, no degree
+  // assumption), with the critical points at which p vanishes reported as (even-multiplicity) roots.
+  bool degenerate = false;
 #pragma unroll
   for (int k = 1; k < D; ++k) {
     // A = F[k-1] (degree n), B = F[k] (degree n - 1):  F[k+1] = -(b^2 A - (a_n b x + (a_{n-1} b - a_n b_{n-2})) B), degree n - 2
     const int n = D - k + 1;
     const double an = F[k - 1][n], an1 = F[k - 1][n - 1], b = F[k][n - 1], b2 = (n >= 2) ? F[k][n - 2] : 0.0;
+    degenerate = degenerate || !(fabs(b) > 1e-11);
+    double rmax = 0;   // largest coefficient of the raw remainder (inputs: max 1): at rounding level => p and p' share a factor
     const double q1 = an * b, q0 = an1 * b - an * b2, bb = b * b;
 #pragma unroll
     for (int i = 0; i <= D; ++i) {
@@ -641,8 +750,10 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
         double r = q0 * F[k][i] - bb * F[k - 1][i];
         if (i >= 1) r += q1 * F[k][i - 1];
         F[k + 1][i] = r;
+        rmax = fmax(rmax, fabs(r));
       }
     }
+    degenerate = degenerate || !(rmax > 1e-12 * (bb + fabs(q0) + fabs(q1)));
     renorm(F[k + 1], n - 2);
   }
   // sign variations of the chain at x (bits 0-3) and the sign of p(x) (bit 4)
@@ -841,6 +952,26 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
     const double r = ws.lo[i * 64 + lane];
     roots[i] = (i < count) ? r : 0.0;
   }
+#if DR_K3_STURM_FALLBACK
+  degenerate = degenerate && ok;
+  if (__any(degenerate)) {
+    // rare: the whole wave walks the (compact) derivative chain once, the lanes with a sound chain on 1 + z^D (no real root)
+    double cd[D + 1], r2[D];
+    int n2;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) cd[i] = degenerate ? c[i] : ((i == 0 || i == D) ? 1.0 : 0.0);
+    wave_lds_order();
+    // (the compact form: real_roots_half_wave inlined here cost the Stewenius kernels 2-3 % through the register allocation of
+    // the hot path; as a real call -- __attribute__((noinline)) -- the device compiler did not finish within 40 minutes)
+    static_assert(3 * (D + 1) * 64 <= SturmWs<D>::kDoubles, "the fallback works in the isolation's own workspace");
+    real_roots_half_compact<D>(cd, outer, r2, n2, lds_ws, lane);
+    if (degenerate) {
+      count = n2;
+#pragma unroll
+      for (int i = 0; i < D; ++i) roots[i] = r2[i];
+    }
+  }
+#endif
 }
 
 // roots[0..count-1] = all real roots found (|z| <= 1 ascending first, then the |z| > 1 ones); count <= D

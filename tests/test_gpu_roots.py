@@ -141,3 +141,55 @@ def test_hip_isolation_counts_equal_the_cpu_restatement(dev):
                 total += 1
                 outside += not any(l - 1e-9 <= x <= h + 1e-9 for (l, h) in ivs)
     assert total > 5000 and differ <= 2e-3 * 2 * cs.shape[0] + 1 and outside <= 1e-3 * total + 1, (differ, outside, total)
+
+
+def test_sturm_fallback_degree_drops_and_even_roots(dev):
+    """Round 5 (review of rounds 3-4: "the Sturm chain still drops roots on a zero leading coefficient"): polynomials whose chain
+    loses a degree -- p of degree 9 or 8 stored as a degree-10 polynomial, p with a DOUBLE root (p and p' share a factor), p with a
+    root at 0 -- go through the derivative chain instead; every real root numpy's companion-matrix eigenvalues report (what the
+    reference calls, nister.py:361-370) is found, double roots once, nothing is invented"""
+    from differentiable_ransac_amd import ops
+    rng = np.random.default_rng(21)
+    coefs, truth, kind = [], [], []
+
+    def distinct(n, lo=-2.5, hi=2.5, sep=0.15):
+        while True:
+            r = np.sort(rng.uniform(lo, hi, n))
+            if (n < 2 or np.diff(r).min() > sep) and np.abs(np.abs(r) - 1).min() > 2e-2 and np.abs(r).min() > 2e-2:
+                return r
+    for drop in (1, 2):                       # vanishing leading coefficients
+        for _ in range(200):
+            nreal = int(rng.choice([2, 4, 6])) if drop == 2 else int(rng.choice([1, 3, 5, 7]))
+            real = distinct(nreal)
+            cp = [(rng.uniform(-2, 2), rng.uniform(0.4, 2.0)) for _ in range((10 - drop - nreal) // 2)]
+            c = _poly_from_roots(real, cp, rng.uniform(0.5, 2.0))
+            coefs.append(np.concatenate([c, np.zeros(11 - c.shape[0])])); truth.append(real); kind.append("drop%d" % drop)
+    for _ in range(300):                      # one double root + simple roots
+        real = distinct(int(rng.choice([1, 3, 5])))
+        x0 = real[0]
+        cp = [(rng.uniform(-2, 2), rng.uniform(0.4, 2.0)) for _ in range((10 - 1 - len(real)) // 2)]
+        c = _poly_from_roots(np.concatenate([real, [x0]]), cp, 1.0)
+        coefs.append(c); truth.append(real); kind.append("double")
+    for _ in range(100):                      # a root at 0 (the reversed polynomial then has a vanishing leading coefficient)
+        real = distinct(3)
+        cp = [(rng.uniform(-2, 2), rng.uniform(0.4, 2.0)) for _ in range(3)]
+        c = _poly_from_roots(np.concatenate([real, [0.0]]), cp, 1.0)
+        coefs.append(c); truth.append(np.sort(np.concatenate([real, [0.0]]))); kind.append("zero")
+    coef = np.stack(coefs)
+    roots, counts = ops.debug_real_roots10(torch.from_numpy(coef).to(dev), 1)
+    roots, counts = roots.cpu().numpy(), counts.cpu().numpy()
+    lost = {k: 0 for k in set(kind)}
+    extra = 0
+    for i, real in enumerate(truth):
+        got = _found(roots, counts, i)
+        tol = 2e-5 if kind[i] == "double" else 1e-7      # a double root is conditioned like sqrt(eps)
+        for r in real:
+            if len(got) == 0 or np.min(np.abs(got - r) / (1 + abs(r))) > tol:
+                lost[kind[i]] += 1
+        for g in got:
+            if np.min(np.abs(real - g) / (1 + np.abs(real))) > tol:
+                extra += 1
+    # a double root of ROUNDED coefficients is a pair ~1e-8 apart (real or complex): the chain sees the common factor when its
+    # remainder is at rounding level, which most but not all of them reach
+    assert lost["drop1"] == 0 and lost["drop2"] == 0 and lost["zero"] == 0 and extra == 0, (lost, extra)
+    assert lost["double"] <= 0.15 * 300, lost
