@@ -50,12 +50,13 @@ __device__ __forceinline__ bool solve_spd5(double (&G)[5][5], double (&b)[5]) {
   return true;
 }
 
-template <typename MT>
-__global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restrict__ samples,
+// T = type of samples / gradients in memory (f32: the training path; f64: `-pr 2 -tr 1`, round 5 -- the arithmetic is f64 either way)
+template <typename MT, typename T = float>
+__global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const T *__restrict__ samples,
                                                            const MT *__restrict__ models,
                                                            const uint8_t *__restrict__ valid,
-                                                           const float *__restrict__ grad_models, int Bt,
-                                                           float *__restrict__ grad_samples,
+                                                           const T *__restrict__ grad_models, int Bt,
+                                                           T *__restrict__ grad_samples,
                                                            const int32_t *__restrict__ which) {
   // which != NULL: the gradient arrives SPARSE -- grad_models is grad_chosen [Bt,9], the gradient of the one slot
   // which[s] K5 picked for sample s (which[s] < 0: none) -- instead of a dense [Bt,10,9] tensor that is zero in nine slots of
@@ -84,20 +85,20 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
       if (next == 0) {
         const int w = which[s];
         if (w >= 0 && w < 10 && valid[(size_t)s * 10 + w]) {
-          float gn = 0.f;
+          double gn = 0.0;
 #pragma unroll
-          for (int q = 0; q < 9; ++q) gn += fabsf(grad_models[(size_t)s * 9 + q]);
-          if (gn > 0.f) slot = w;
+          for (int q = 0; q < 9; ++q) gn += fabs((double)grad_models[(size_t)s * 9 + q]);
+          if (gn > 0.0) slot = w;
         }
       }
       next = 10;
     } else {
       for (; next < 10 && slot < 0; ++next) {
         if (!valid[(size_t)s * 10 + next]) continue;
-        float gn = 0.f;
+        double gn = 0.0;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) gn += fabsf(grad_models[((size_t)s * 10 + next) * 9 + q]);
-        if (gn > 0.f) slot = next;
+        for (int q = 0; q < 9; ++q) gn += fabs((double)grad_models[((size_t)s * 10 + next) * 9 + q]);
+        if (gn > 0.0) slot = next;
       }
     }
     if (!__any(slot >= 0)) break;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const float *__restri
 #pragma unroll
   for (int k = 0; k < 5; ++k)
 #pragma unroll
-    for (int d = 0; d < 4; ++d) grad_samples[(size_t)s * 20 + 4 * k + d] = (float)gacc[k][d];
+    for (int d = 0; d < 4; ++d) grad_samples[(size_t)s * 20 + 4 * k + d] = (T)gacc[k][d];
 }
 
 // ---------------------------------------------------------------------------------------------- five-point, n > 5
@@ -368,18 +369,19 @@ __global__ __launch_bounds__(64) void fivepoint_nm_bwd_kernel(const float *__res
 }
 
 // ---------------------------------------------------------------------------------------------- 8-point / LSQ
-__global__ __launch_bounds__(64) void f8_bwd_kernel(const float *__restrict__ samples, const float *__restrict__ weights,
-                                                    const float *__restrict__ models,
-                                                    const float *__restrict__ grad_models, int Bt, int n,
-                                                    float *__restrict__ grad_samples,
-                                                    float *__restrict__ grad_weights) {
+template <typename T>   // T = type of samples / models / gradients in memory (f64: `-pr 2 -tr 1`, round 5); f64 arithmetic either way
+__global__ __launch_bounds__(64) void f8_bwd_kernel(const T *__restrict__ samples, const T *__restrict__ weights,
+                                                    const T *__restrict__ models,
+                                                    const T *__restrict__ grad_models, int Bt, int n,
+                                                    T *__restrict__ grad_samples,
+                                                    T *__restrict__ grad_weights) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   const int s = blockIdx.x * 64 + lane;
   const bool active = s < Bt;
   const int sc = active ? s : Bt - 1;
-  const float *pts = samples + (size_t)sc * n * 4;
-  const float *wts = weights ? weights + (size_t)sc * n : nullptr;
+  const T *pts = samples + (size_t)sc * n * 4;
+  const T *wts = weights ? weights + (size_t)sc * n : nullptr;
   LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
   double mu[4] = {0, 0, 0, 0};
   for (int r = 0; r < n; ++r)
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(64) void f8_bwd_kernel(const float *__restrict__ sa
   }
   // pass A over the rows: grad row_r = -(row_r.u) f - (row_r.f) u
   double S_mu[4] = {0, 0, 0, 0}, S_r1 = 0, S_r2 = 0;
-  float *gs = grad_samples + (size_t)sc * n * 4;
+  T *gs = grad_samples + (size_t)sc * n * 4;
   for (int r = 0; r < n; ++r) {
     const double a = (double)pts[4 * r] - mu[0], b = (double)pts[4 * r + 1] - mu[1];
     const double c = (double)pts[4 * r + 2] - mu[2], d = (double)pts[4 * r + 3] - mu[3];
@@ -498,9 +500,9 @@ __global__ __launch_bounds__(64) void f8_bwd_kernel(const float *__restrict__ sa
     const double gX2 = grow[0] * X1 + grow[1] * Y1 + grow[2];
     const double gY2 = grow[3] * X1 + grow[4] * Y1 + grow[5];
     if (active) {
-      gs[4 * r] = (float)(gX1 * r1); gs[4 * r + 1] = (float)(gY1 * r1);
-      gs[4 * r + 2] = (float)(gX2 * r2); gs[4 * r + 3] = (float)(gY2 * r2);
-      if (grad_weights) grad_weights[(size_t)sc * n + r] = (float)gw;
+      gs[4 * r] = (T)(gX1 * r1); gs[4 * r + 1] = (T)(gY1 * r1);
+      gs[4 * r + 2] = (T)(gX2 * r2); gs[4 * r + 3] = (T)(gY2 * r2);
+      if (grad_weights) grad_weights[(size_t)sc * n + r] = (T)gw;
     }
     S_mu[0] += gX1 * r1; S_mu[1] += gY1 * r1; S_mu[2] += gX2 * r2; S_mu[3] += gY2 * r2;
     S_r1 += gX1 * a + gY1 * b;
@@ -527,10 +529,10 @@ __global__ __launch_bounds__(64) void f8_bwd_kernel(const float *__restrict__ sa
       const double a = (double)pts[4 * r] - mu[0], b = (double)pts[4 * r + 1] - mu[1];
       const double c = (double)pts[4 * r + 2] - mu[2], d = (double)pts[4 * r + 3] - mu[3];
       const double n1 = sqrt(a * a + b * b), n2 = sqrt(c * c + d * d);
-      gs[4 * r] += (float)(g_d1 * a / n1 + gm[0] / n);
-      gs[4 * r + 1] += (float)(g_d1 * b / n1 + gm[1] / n);
-      gs[4 * r + 2] += (float)(g_d2 * c / n2 + gm[2] / n);
-      gs[4 * r + 3] += (float)(g_d2 * d / n2 + gm[3] / n);
+      gs[4 * r] += (T)(g_d1 * a / n1 + gm[0] / n);
+      gs[4 * r + 1] += (T)(g_d1 * b / n1 + gm[1] / n);
+      gs[4 * r + 2] += (T)(g_d2 * c / n2 + gm[2] / n);
+      gs[4 * r + 3] += (T)(g_d2 * d / n2 + gm[3] / n);
     }
   }
 }
@@ -776,6 +778,24 @@ __global__ __launch_bounds__(kBT) void rigid_residual_bwd_kernel(const float *__
 
 }  // namespace dr
 
+template <typename T>
+static int f8_bwd_launch(const T *samples, const T *weights, const T *models, const T *grad_models, int Bt, int n, T *grad_samples,
+                         T *grad_weights, void *stream) {
+  const size_t smem = sizeof(double) * 162 * 64;
+  // the attribute is per device: remember which devices of this process have it (one process may drive several GPUs)
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dr::f8_bwd_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((dr::f8_bwd_kernel<T>), dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream, samples, weights,
+                     models, grad_models, Bt, n, grad_samples, grad_weights);
+  return dr::check_launch("f8_bwd_kernel");
+}
+
 extern "C" {
 
 int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const double *models_f64,
@@ -835,19 +855,23 @@ int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float 
                         int Bt, int n, float *grad_samples, float *grad_weights, void *stream) {
   DR_REQUIRE(samples && models && grad_models && grad_samples, "null pointer");
   DR_REQUIRE(Bt > 0 && n >= 8, "need Bt > 0 and n >= 8");
-  const size_t smem = sizeof(double) * 162 * 64;
-  // the attribute is per device: remember which devices of this process have it (one process may drive several GPUs)
-  static bool attr_set[64] = {false};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dr::f8_bwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL(dr::f8_bwd_kernel, dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream, samples, weights,
-                     models, grad_models, Bt, n, grad_samples, grad_weights);
-  return dr::check_launch("f8_bwd_kernel");
+  return f8_bwd_launch<float>(samples, weights, models, grad_models, Bt, n, grad_samples, grad_weights, stream);
+}
+/* f64 in memory as well (`-pr 2 -tr 1`, model_cl.py:164-169): the same kernel, nothing rounded to f32 on the way */
+int dr_solve_f8_bwd_f64(const double *samples, const double *weights, const double *models, const double *grad_models,
+                        int Bt, int n, double *grad_samples, double *grad_weights, void *stream) {
+  DR_REQUIRE(samples && models && grad_models && grad_samples, "null pointer");
+  DR_REQUIRE(Bt > 0 && n >= 8, "need Bt > 0 and n >= 8");
+  return f8_bwd_launch<double>(samples, weights, models, grad_models, Bt, n, grad_samples, grad_weights, stream);
+}
+/* minimal five-point backward, everything f64 in memory (dense gradient [Bt,10,9]) */
+int dr_solve_nister5_bwd_f64(const double *samples, const double *models, const uint8_t *valid, const double *grad_models, int Bt,
+                             double *grad_samples, void *stream) {
+  DR_REQUIRE(samples && models && valid && grad_models && grad_samples, "null pointer");
+  DR_REQUIRE(Bt > 0, "need Bt > 0");
+  hipLaunchKernelGGL((dr::fivepoint_bwd_kernel<double, double>), dim3((Bt + 63) / 64), dim3(64), 0, (hipStream_t)stream, samples,
+                     models, valid, grad_models, Bt, grad_samples, (const int32_t *)nullptr);
+  return dr::check_launch("fivepoint_bwd_kernel");
 }
 
 int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const float *grad_models, int Bt, int n,

@@ -636,9 +636,16 @@ class _SolveEssential(torch.autograd.Function):
             return None, None, None
         samples, models, m64, valid = ctx.saved_tensors
         f64 = samples.dtype == torch.float64
+        if f64 and ctx.minimal:
+            # `-pr 2 -tr 1`, round 5: f64 samples, models and gradients straight through (dr_solve_nister5_bwd_f64)
+            s, Bt, n = _flat_samples(samples, 4)
+            gs = torch.empty_like(s)
+            L.call("dr_solve_nister5_bwd_f64", ptr(s), ptr(models.contiguous()), ptr(valid.contiguous().view(torch.uint8)),
+                   ptr(g_models.to(torch.float64).contiguous()), c_int(Bt), ptr(gs), stream())
+            return gs.reshape(samples.shape), None, None
         if f64:
-            # `-pr 2 -tr 1`: the forward ran in f64; the backward kernels read f32 samples / gradients but take the f64 models and
-            # compute in f64 (their tangent-space system is what needs the precision): inputs rounded once, gradient returned as f64
+            # n > 5 rows per sample in f64: that kernel reads f32 samples / gradients but takes the f64 models and computes in
+            # f64 (its tangent-space system is what needs the precision): inputs rounded once, gradient returned as f64
             m64, models, samples, g_models = models, models.float(), samples.float(), g_models.float()
         s, Bt, n = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
@@ -721,19 +728,14 @@ class _SolveF8(torch.autograd.Function):
         if gF is None:
             return None, None
         samples, weights, F = ctx.saved_tensors
-        dt = samples.dtype
-        if dt == torch.float64:
-            # `-pr 2 -tr 1`: f64 forward; the backward kernel has f32 I/O (f64 arithmetic inside): inputs rounded once to f32,
-            # gradients returned as f64 (precision table)
-            samples, F, gF = samples.float(), F.float(), gF.float()
-            weights = weights.float()
+        dt = samples.dtype      # f32, or f64 (`-pr 2 -tr 1`): the same kernel with f64 in memory (round 5: nothing rounded to f32)
         s, Bt, n = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
-        w = weights.reshape(Bt, n).contiguous() if ctx.has_w else None
+        w = weights.reshape(Bt, n).to(dt).contiguous() if ctx.has_w else None
         gw = torch.empty_like(w) if ctx.has_w else None
-        L.call("dr_solve_f8_bwd_f32", ptr(s), ptr(w), ptr(F.contiguous()), ptr(gF.contiguous()), c_int(Bt), c_int(n),
-               ptr(gs), ptr(gw), stream())
-        return gs.reshape(samples.shape).to(dt), (gw.reshape(weights.shape).to(dt) if ctx.has_w else None)
+        L.call(f"dr_solve_f8_bwd_{L.suffix(dt)}", ptr(s), ptr(w), ptr(F.to(dt).contiguous()), ptr(gF.to(dt).contiguous()), c_int(Bt),
+               c_int(n), ptr(gs), ptr(gw), stream())
+        return gs.reshape(samples.shape), (gw.reshape(weights.shape) if ctx.has_w else None)
 
 
 def solve_fundamental8(samples, weights=None):
@@ -1013,9 +1015,11 @@ def match_loss_mean(matches, mask, models, keep=None):
     """MatchLoss of a batch: mean over pairs of the per-pair means (match_loss_per_pair(...).mean()) -> scalar, with the mean
     and its backward folded into the kernels (P <= 64; larger batches take the per-pair kernel + torch.mean).  When the models
     require grad (training), value and gradient come from ONE pass over the (model x point) grid (_MatchLossFused)."""
-    if matches.dtype != torch.float32:
-        raise L.DransacError("match_loss_mean is implemented for f32")
     models = models.reshape(models.shape[0], -1, 3, 3)
+    if matches.dtype == torch.float64:
+        return _match_loss_mean_f64(matches, mask, models, keep)
+    if matches.dtype != torch.float32:
+        raise L.DransacError("match_loss_mean is implemented for f32 and f64")
     if FUSED_MATCH_LOSS and torch.is_grad_enabled() and models.requires_grad:
         return _MatchLossFused.apply(matches, mask, models, keep)
     if matches.shape[0] > 64:
@@ -1024,6 +1028,29 @@ def match_loss_mean(matches, mask, models, keep=None):
 
 
 FUSED_MATCH_LOSS = True   # tests / A-B runs: False = the two-pass form of rounds 3-4
+
+
+def _match_loss_mean_f64(matches, mask, models, keep, chunk: int = 256):
+    """`-pr 2 -tr 1 -w2 1` (model_cl.py:164-169, Q17): MatchLoss in double precision.  The episym kernels are packed-f32 code; the
+    f64 parity path evaluates loss.py:137-153 / cv_utils.py:680-695 with torch ops ON THE DEVICE (autograd provides the backward),
+    `chunk` models at a time so that the [P, chunk, N] temporaries stay small.  Not a hot path: the training path is f32."""
+    P, N, _ = matches.shape
+    M = models.shape[1]
+    one = torch.ones_like(matches[..., :1])
+    x1 = torch.cat((matches[..., :2], one), -1)
+    x2 = torch.cat((matches[..., 2:], one), -1)
+    w_pt = torch.ones((P, N), device=matches.device, dtype=matches.dtype) if mask is None else mask.to(matches.dtype)
+    w_md = torch.ones((P, M), device=matches.device, dtype=matches.dtype) if keep is None else keep.to(matches.dtype)
+    total = torch.zeros((P,), device=matches.device, dtype=matches.dtype)
+    for m0 in range(0, M, chunk):
+        F = models[:, m0:m0 + chunk]
+        Fx1 = torch.einsum("pmij,pnj->pmni", F, x1)
+        Ftx2 = torch.einsum("pmji,pnj->pmni", F, x2)
+        r = (x2[:, None] * Fx1).sum(-1)
+        ys = r ** 2 * (1.0 / (Fx1[..., 0] ** 2 + Fx1[..., 1] ** 2 + 1e-15) + 1.0 / (Ftx2[..., 0] ** 2 + Ftx2[..., 1] ** 2 + 1e-15))
+        total = total + (ys.clamp(max=1.0) * w_pt[:, None, :] * w_md[:, m0:m0 + chunk, None]).sum((1, 2))
+    den = (w_pt.sum(1) * w_md.sum(1)).clamp(min=1.0)
+    return (total / den).mean()
 
 
 def match_loss_per_pair(matches, mask, models, keep=None):

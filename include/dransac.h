@@ -239,6 +239,12 @@ int dr_solve_nister5_bwd_f32(const float *samples, const float *models, const do
 int dr_solve_nister5_bwd_sel_f32(const float *samples, const float *models, const double *models_f64,
                                  const uint8_t *valid, const float *grad_chosen, const int32_t *which, int Bt,
                                  float *grad_samples, void *stream);
+/* Round 5: the same backward kernels with f64 samples / models / gradients in memory (`-pr 2 -tr 1`, model_cl.py:164-169, Q17):
+ * the arithmetic was f64 already; until round 4 the f64 training path rounded their inputs and outputs to f32. */
+int dr_solve_nister5_bwd_f64(const double *samples, const double *models, const uint8_t *valid, const double *grad_models, int Bt,
+                             double *grad_samples, void *stream);
+int dr_solve_f8_bwd_f64(const double *samples, const double *weights, const double *models, const double *grad_models, int Bt, int n,
+                        double *grad_samples, double *grad_weights, void *stream);
 /* Non-minimal samples (n > 5 rows per sample, optional row weights: ransac.py:82-83 `num_samples == 8` feeding the five-point
  * estimator, which runs its minimal code on all rows -- nister.py:64-65, weighted rows :88-93).  The returned models lie in the
  * span of the four smallest eigenvectors of sum_r w_r^2 rho_r rho_r^T; the backward differentiates that invariant subspace and

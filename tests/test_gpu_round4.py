@@ -121,8 +121,8 @@ def test_sampler_backward_tail_group_with_very_negative_logits(dev, N):
 # ------------------------------------------------------------------------------------- f64 train mode (`-pr 2 -tr 1`, model_cl.py:164-169, Q17)
 def test_f64_train_mode_f8_gradient_against_the_f64_oracle(dev):
     """the drop-in RANSAC in double precision, train mode, on the reference's own training fixture: chosen models and the gradient
-    to the logits against torch autograd through the f64 oracle on the same noise (sampler + gather backward in f64 kernels, the
-    8-point backward through its f32-I/O kernel: tolerance = one f32 rounding of the solver's inputs)"""
+    to the logits against torch autograd through the f64 oracle on the same noise (round 5: sampler, gather AND the 8-point
+    backward with f64 in memory -- dr_solve_f8_bwd_f64 -- so the tolerance is a rounding-level one, not one f32 rounding)"""
     import numpy as np
     from differentiable_ransac_amd import estimators, samplers, scorings
     from differentiable_ransac_amd.ransac import RANSAC
@@ -148,7 +148,7 @@ def test_f64_train_mode_f8_gradient_against_the_f64_oracle(dev):
     (chosen * (w * s[:, None, None]).to(dev)).sum().backward()
     gl = logits.grad.cpu()
     assert gl.dtype == torch.float64 and bool(torch.isfinite(gl).all())
-    assert (gl - l64.grad).abs().max() <= 2e-3 * l64.grad.abs().max(), (float((gl - l64.grad).abs().max()), float(l64.grad.abs().max()))
+    assert (gl - l64.grad).abs().max() <= 1e-8 * l64.grad.abs().max(), (float((gl - l64.grad).abs().max()), float(l64.grad.abs().max()))
 
 
 def test_f64_sampler_and_gather_backward_against_autograd(dev):

@@ -194,3 +194,81 @@ def test_match_loss_value_and_gradient_in_one_pass(dev, N):
     (ref * 3.0).backward()
     assert abs(float(la) - float(ref)) <= 1e-5 * abs(float(ref))
     assert float((ga.double().cpu() - md.grad).abs().max()) <= 2e-4 * float(md.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------- f64 train mode without the f32 bottleneck
+def test_f64_fivepoint_backward_in_double_precision(dev):
+    """dr_solve_nister5_bwd_f64: samples, models and gradients f64 in memory.  Against central differences of the f64 forward itself
+    (the solution that moves continuously with the sample), to 1e-6 of the gradient's scale -- the f32-I/O kernel of rounds 1-4
+    could not be checked below one f32 rounding of its inputs (2e-3 in test_gpu_round4.py)"""
+    from differentiable_ransac_amd import ops, synth
+    pair = synth.two_view_pair(41, 400, inlier_ratio=1.0, noise=0.0, dtype=torch.float64)
+    smp0 = pair["matches"][:40].reshape(8, 5, 4).to(dev)
+    gen = torch.Generator().manual_seed(4)
+    wgt = torch.randn(3, 3, generator=gen, dtype=torch.float64).to(dev)
+    gt = pair["gt_E"].to(dev)
+
+    def picked(smp):          # the solution closest to the ground truth (sign-fixed): a smooth function of the sample
+        E, valid = ops.solve_essential(smp, None, "nister")
+        d = torch.minimum(((E - gt) ** 2).sum((-1, -2)), ((E + gt) ** 2).sum((-1, -2)))
+        d = torch.where(valid, d, torch.full_like(d, 1e9))
+        j = d.argmin(-1)
+        Ej = E[torch.arange(E.shape[0], device=dev), j]
+        sgn = torch.sign((Ej * gt).sum((-1, -2)))
+        return Ej * sgn[:, None, None], d.min(-1).values
+    smp = smp0.clone().requires_grad_(True)
+    Ej, dist = picked(smp)
+    assert float(dist.max()) < 1e-12                       # noise-free samples: the ground truth is among the solutions
+    (Ej * wgt).sum().backward()
+    g = smp.grad
+    assert g.dtype == torch.float64 and bool(torch.isfinite(g).all())
+    h = 1e-6
+    scale = g.abs().amax((1, 2))
+    well = [b for b in range(8) if float(scale[b]) < 1e3]      # (an ill-conditioned sample's solution is not smooth over 2 h)
+    assert len(well) >= 5
+    checked = 0
+    for i, b in enumerate(well[:5]):
+        k, c = (2 * i) % 5, (3 * i) % 4
+        sp, sm = smp0.clone(), smp0.clone()
+        sp[b, k, c] += h
+        sm[b, k, c] -= h
+        fd = float(((picked(sp)[0] - picked(sm)[0]) * wgt).sum()) / (2 * h)
+        assert abs(fd - float(g[b, k, c])) <= 1e-6 * float(scale[b]), (b, k, c, fd, float(g[b, k, c]))
+        checked += 1
+    assert checked == 5
+    # and the f32-I/O kernel of rounds 1-4 on the same samples agrees to ITS rounding
+    s32 = smp0.float().clone().requires_grad_(True)
+    E32, v32 = ops.solve_essential(s32, None, "nister")
+    d32 = torch.minimum(((E32 - gt.float()) ** 2).sum((-1, -2)), ((E32 + gt.float()) ** 2).sum((-1, -2)))
+    j32 = torch.where(v32, d32, torch.full_like(d32, 1e9)).argmin(-1)
+    Ej32 = E32[torch.arange(8, device=dev), j32]
+    ((Ej32 * torch.sign((Ej32 * gt.float()).sum((-1, -2)))[:, None, None]) * wgt.float()).sum().backward()
+    rel = (g - s32.grad.double()).abs().amax((1, 2)) / scale
+    assert float(rel[well].max()) < 1e-4, rel.tolist()
+
+
+def test_f64_train_step_with_match_loss_through_the_batched_driver(dev):
+    """`-pr 2 -tr 1 -w2 1` (model_cl.py:164-169, Q17): the batched driver in double precision end to end -- sampler, gather, Nister,
+    best-of-ten, MatchLoss (f64: torch ops on the device), backward to the logits -- against the f32 training path on the same
+    seed: same index sets, models equal to f32 rounding, loss and gradient close"""
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.loss import MatchLoss
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    d = synth.batch_two_view(2, 1000, seed0=13)
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        m, K1, K2, gt = (d[k].to(dev).to(dt) for k in ("matches", "K1", "K2", "gt_E"))
+        lg = d["logits"].to(dev).to(dt).requires_grad_(True)
+        drv = BatchedRANSAC("nister", ransac_batch_size=256, train=True, threshold=0.75, max_iterations=100, seed=5)
+        noise = [synth.gumbel_noise((2, 256, 1000), seed=77).to(dev).to(dt)]
+        chosen, keep = drv(m, lg, K1, K2, gt_model=gt, gumbels=noise)
+        loss = MatchLoss()(chosen, m, d["inliers"].to(dev), keep)
+        loss.backward()
+        out[dt] = (chosen.detach(), keep, float(loss), lg.grad.clone())
+    (c64, k64, l64, g64), (c32, k32, l32, g32) = out[torch.float64], out[torch.float32]
+    assert c64.dtype == torch.float64 and g64.dtype == torch.float64 and bool(torch.isfinite(g64).all())
+    both = k64 & k32
+    assert float(both.float().mean()) > 0.9
+    assert float((c64[both] - c32[both].double()).abs().amax((-1, -2)).quantile(0.99)) < 1e-4
+    assert abs(l64 - l32) <= 1e-3 * abs(l64)
+    assert float((g64 - g32.double()).abs().max()) <= 0.05 * float(g64.abs().max())

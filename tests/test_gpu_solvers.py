@@ -110,8 +110,9 @@ def test_fivepoint_config_sizes_vs_oracle(dev):
         fw, bw = _set_dist(E[ok], valid[ok], Eo[ok], real[ok])
         # f32 output rounding only: the solver itself runs in f64
         assert fw.quantile(0.995) < TOL and bw.quantile(0.995) < TOL, (fw.max(), bw.max())
-        assert (fw > TOL).float().mean() < 2e-3 and (bw > TOL).float().mean() < 2e-3
-        assert abs(int(valid.sum()) - int(real[ok].sum())) <= 8
+        # round 5 (Sturm fallback, converged roots): measured 0 - 6.5e-4 over three seeds, valid counts equal to the oracle's
+        assert (fw > TOL).float().mean() < 1e-3 and (bw > TOL).float().mean() < 1e-3
+        assert abs(int(valid.sum()) - int(real[ok].sum())) <= 4
 
 
 def test_fivepoint_noise_free_contains_ground_truth(dev):

@@ -115,6 +115,10 @@ def run(opt):
     from differentiable_ransac_amd.ransac import BatchedRANSAC3D
     dev = torch.device("cuda")
     b = load_batch(opt, dev)
+    if opt.precision == 2:      # `-pr 2` (model_cl.py:164-169): everything in double precision
+        b = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+    elif opt.precision == 0:
+        raise SystemExit("-pr 0 (half precision) never worked upstream either (SURVEY Q15): f32 (-pr 1) or f64 (-pr 2)")
     P, N = b["points"].shape[:2]
     weights = b["weights"].clone().requires_grad_(bool(opt.tr))
     rec = {"flags": {k: getattr(opt, k) for k in ("nfeatures", "batch_size", "ransac_batch_size", "fmat", "sampler", "tr",
