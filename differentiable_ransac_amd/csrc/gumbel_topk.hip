@@ -586,6 +586,9 @@ __global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restr
   }
   float Tf = bm + __logf(bs) - __logf(lambda);
   if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY) Tf = INFINITY;   // non-finite logits: no point passes, every row takes the full pass
+  // the margin covers the f32 rounding of fl(logit + G) -- half an ulp of a score near T -- only while |T| stays below ~1.6e4
+  // (round-4 advice: unnormalised scores, a large additive bias): beyond 4096 the pair is not screened at all
+  if (fabsf(Tf) > 4096.f) Tf = INFINITY;
   if (blockIdx.x == 0 && threadIdx.x == 0) T_out[p] = Tf;
   if (n >= N) return;
   constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);

@@ -327,7 +327,7 @@ static inline int samples_per_block(int Bt) {
   int spb = 32;
   const int simds = device_simds();
   while (spb > 4 && (long)(Bt + spb / 2 - 1) / (spb / 2) <= simds) spb /= 2;
-  return spb;
+  return spb;   // 32, 16, 8 or 4: even, so a block's first output row (s0 * 90 floats, s0 * 10 bytes) keeps the staged-output alignment
 }
 
 // Two-phase kernels or lane pairs?  A pair-kernel block (32 samples) costs kPairCost, a two-phase block (64 samples) kFbCost

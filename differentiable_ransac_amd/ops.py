@@ -321,6 +321,9 @@ class SampleGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, matches, logits, B, k, tau, gumbel, seed):
         ctx.set_materialize_grads(False)   # unused / non-differentiable outputs arrive as None, not as zero-filled tensors
+        if logits.dtype == torch.float64 and logits.requires_grad and gumbel is None and _dev_seed(seed):
+            # refused HERE, not at backward time (round-4 advice): the f64 sampler backward takes a by-value seed or explicit noise
+            raise L.DransacError("SampleGather: f64 logits with a device seed have no backward (device seeds serve f32 only)")
         r = gumbel_topk(logits, B, k, tau, gumbel, seed)
         samples = gather(matches, r["idx"], r["y_sel"])
         ctx.save_for_backward(matches, logits, r["idx"], r["y_sel"], r["lse"], gumbel if gumbel is not None else

@@ -708,7 +708,11 @@ class BatchedRANSAC3D(object):
                 idx = ops.gumbel_topk(logits, self.B, 3, self.tau, g, self._next_seed(), soft=False)["idx"]
                 if matches.dtype == torch.float32:
                     # K2 + K3r in one launch (samples read through the index sets), the round's residual sums cleared on the way
-                    res = torch.empty((P, self.B), device=matches.device, dtype=torch.float32)
+                    # the residual sums are ACCUMULATED (atomics: order-nondeterministic in the last bits) into a buffer that
+                    # dr_solve_rigid_gather_f32 clears; outside a graph capture it also starts from zeros, so that an error
+                    # between the two launches can never leave garbage sums (round-4 advice; under capture: no extra node)
+                    alloc = torch.empty if torch.cuda.is_current_stream_capturing() else torch.zeros
+                    res = alloc((P, self.B), device=matches.device, dtype=torch.float32)
                     model, valid = ops.solve_rigid_gather(matches, idx, self.flag, zero_sums=res)
                     res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks, res=res)
                 else:

@@ -97,6 +97,10 @@ class AsyncGradientBucket:
 
     def launch(self) -> None:
         i = self.issued
+        if self.issued - self.waited >= 2:
+            # both buffers are in flight: a third launch would overwrite a live work handle and reduce a buffer the process
+            # group may still be reading (round-4 advice) -- the oldest one is waited for first
+            self.wait()
         if self.dist is not None:
             self.work[i % 2] = self.dist.all_reduce(self.buf[i % 2], op=self.dist.ReduceOp.SUM, async_op=True)
         self.trace.append(("launch", i))
@@ -132,13 +136,19 @@ class OverlappedStep:
     The first launch of step i + 1 is therefore enqueued BEFORE the wait on bucket i (tests/test_sharding_gloo.py asserts the
     order on `bucket.trace`)."""
 
-    def __init__(self, step_fn, bucket: AsyncGradientBucket):
-        self.step_fn, self.bucket, self.n = step_fn, bucket, 0
+    def __init__(self, step_fn, bucket: AsyncGradientBucket, on_reduced=None):
+        # on_reduced(averaged_bucket, step_index): the optimizer's hook -- called with the averaged gradient of step i - 1 the
+        # moment it has been waited for (round-4 advice: the waited bucket used to be dropped); also kept as `last_reduced`
+        self.step_fn, self.bucket, self.n, self.on_reduced, self.last_reduced = step_fn, bucket, 0, on_reduced, None
 
     def __call__(self):
         out = self.step_fn()
         self.bucket.trace.append(("enqueued", self.n))
-        self.bucket.wait()
+        reduced = self.bucket.wait()
+        if reduced is not None:
+            self.last_reduced = reduced
+            if self.on_reduced is not None:
+                self.on_reduced(reduced, self.n - 1)
         self.bucket.launch()
         self.n += 1
         return out

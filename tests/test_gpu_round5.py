@@ -272,3 +272,18 @@ def test_f64_train_step_with_match_loss_through_the_batched_driver(dev):
     assert float((c64[both] - c32[both].double()).abs().amax((-1, -2)).quantile(0.99)) < 1e-4
     assert abs(l64 - l32) <= 1e-3 * abs(l64)
     assert float((g64 - g32.double()).abs().max()) <= 0.05 * float(g64.abs().max())
+
+
+# ------------------------------------------------------------------------------------- round-4 advice: screened sampler, large logits
+@pytest.mark.parametrize("bias", [0.0, 3.0e3, 1.0e5, -2.0e4])
+def test_screened_sampler_with_large_logit_offsets_equals_the_unscreened_kernel(dev, bias):
+    """the screening margin of dr_gumbel_topk_index_f32 covers the f32 rounding of logit + G only while the scores stay below ~1.6e4:
+    pairs whose threshold lies beyond 4096 are not screened -- either way the index sets are those of the unscreened kernel"""
+    from differentiable_ransac_amd import ops
+    P, B, N, k = 2, 512, 16384, 3
+    logits = torch.randn(P, N, generator=torch.Generator().manual_seed(3)) * 2.0 + bias
+    logits[1] += 0.37 * bias
+    logits = logits.to(dev)
+    a = ops.gumbel_topk(logits, B, k, 1.0, None, 9, soft=False, screen=True)["idx"]
+    b = ops.gumbel_topk(logits, B, k, 1.0, None, 9, soft=False, screen=False)["idx"]
+    assert torch.equal(a, b)
