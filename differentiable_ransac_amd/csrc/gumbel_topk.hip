@@ -305,7 +305,15 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
 // 7.7, everything else 42-48), this kernel 60.0 us (everything else: 29); train mode 88.1 -> 74.4 us.
 constexpr int kFastGroups = 8;   // groups per lane: 64 lanes x 8 groups x 4 elements = 2048
 
-template <bool kSoft>
+// kScreen (round 5, index-only mode): the screening words of the long-row kernel for SHORT rows.  A point can only be among the k
+// winners if its score reaches T = logsumexp(logits) - ln(lambda), i.e. if its Philox word reaches a per-point threshold that
+// depends on the pair's logits only (gumbel_screen_short_kernel: screen_tb [P,N] words, screen_T [P]).  A lane compares the 32
+// words of its elements against their thresholds -- no logarithm, no logit -- parks the words in LDS, and the wave then evaluates
+// only the ~lambda elements that passed, one per lane and round (lambda = 11 + k: two or three rounds), exactly as the unscreened
+// kernel would have (same word, same logit, same rounding): the winners are ranked among them by (value, index).  A row with
+// fewer than k evaluated scores >= T (4e-4 of the rows at lambda = 16), or more candidates than the list holds, takes the
+// unscreened path below.  Per row ~520 vector instructions instead of ~890: Philox stays, 32 x (two logarithms + adds) go.
+template <bool kSoft, bool kScreen = false>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(const float *__restrict__ logits, uint64_t seed,
                                                                              int B, int N, int k, int32_t *__restrict__ idx,
                                                                              float *__restrict__ y_sel,
@@ -313,11 +321,15 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
                                                                              const uint64_t *__restrict__ seed_ptr,
                                                                              const float4 *__restrict__ gather_src = nullptr,
                                                                              float4 *__restrict__ gather_dst = nullptr,
-                                                                             PairGate gate = PairGate()) {
+                                                                             PairGate gate = PairGate(),
+                                                                             const uint32_t *__restrict__ screen_tb = nullptr,
+                                                                             const float *__restrict__ screen_T = nullptr) {
   // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
   if (gate.closed(blockIdx.y)) return;   // this pair has terminated (block-uniform): its rows keep what the last round drew
+  static_assert(!(kSoft && kScreen), "the soft-max statistics need every element's score");
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
+  __shared__ __align__(16) uint32_t s_words[kScreen ? kRowsPerBlock : 1][kScreen ? kFastGroups * 64 * 4 : 4];
 #if DR_K1_PASSB_ATOMIC
   __shared__ int s_cnt[kRowsPerBlock];
 #endif
@@ -335,6 +347,69 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
   float *cand_val = s_val[wv];
   int *cand_idx = s_idx[wv];
+
+  if constexpr (kScreen) {
+    const float Tf = screen_T[p];
+    if (Tf != INFINITY) {   // (non-finite logits, or a threshold beyond the margin's reach: the pair is not screened)
+      const uint4 *tb4 = reinterpret_cast<const uint4 *>(screen_tb + (size_t)p * N);
+      uint32_t *wst = s_words[wv];
+      uint32_t hit = 0;
+#pragma unroll
+      for (int i = 0; i < kFastGroups; ++i) {
+        const int q = lane + 64 * i;
+        if (q < groups) {
+          uint32_t r[4];
+          Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+          const uint4 t = tb4[q];
+          hit |= (r[0] >= t.x ? 1u : 0u) << (4 * i);
+          hit |= (r[1] >= t.y ? 1u : 0u) << (4 * i + 1);
+          hit |= (r[2] >= t.z ? 1u : 0u) << (4 * i + 2);
+          hit |= (r[3] >= t.w ? 1u : 0u) << (4 * i + 3);
+          *reinterpret_cast<uint4 *>(wst + (i * 64 + lane) * 4) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+      }
+      int ncand = 0, reach = 0;
+      while (__any(hit != 0)) {
+        const bool has = hit != 0;
+        const int e = has ? __builtin_ctz(hit) : 0;
+        hit &= hit - 1;
+        const int n = 4 * (lane + 64 * (e >> 2)) + (e & 3);
+        const uint32_t word = wst[((e >> 2) * 64 + lane) * 4 + (e & 3)];      // the lane's own slot: program order
+        const float gv = logits[(size_t)p * N + (has ? n : 0)] + gumbel_from_bits(word);
+        const unsigned long long bal = __ballot(has);
+        const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+        if (has && pos < kMaxCand) { cand_val[pos] = gv; cand_idx[pos] = n; }
+        ncand += __popcll(bal);
+        reach += __popcll(__ballot(has && gv >= Tf));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (reach >= k && ncand <= kMaxCand) {
+        // the k winners are all >= T, hence all in the list: rank by (value descending, index ascending)
+        const bool have = lane < ncand;
+        const float cv = have ? cand_val[lane] : -INFINITY;
+        const int ci = have ? cand_idx[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < ncand; ++j) {
+          const float ov = cand_val[j];
+          const int oi = cand_idx[j];
+          rank += (ov > cv) || (ov == cv && oi < ci);
+        }
+        const bool win = have && rank < k;
+        const unsigned long long wb = __ballot(win);
+        int pos = 0;
+        for (int j = 0; j < ncand; ++j) {
+          if ((wb >> j) & 1ull) pos += cand_idx[j] < ci;
+        }
+        if (win) {
+          idx[row * k + pos] = ci;
+          if (gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + ci];
+        }
+        return;
+      }
+      __builtin_amdgcn_wave_barrier();   // too few scores reach T (or too many candidates): the unscreened path
+    }
+  }
 
   // ---------------- pass A: g into registers, online soft-max, lane maximum
   float g[kFastGroups][4];
@@ -602,6 +677,59 @@ __global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restr
   tb[(size_t)p * N + n] = (Tf == INFINITY) ? 0xffffffffu : (uint32_t)w;
 }
 
+// (c) short rows (N <= 2048, N % 4 == 0: the register-resident sampler): T and the words of a pair by ONE block of 256 threads --
+//     one launch per call instead of two
+__global__ __launch_bounds__(256) void gumbel_screen_short_kernel(const float *__restrict__ logits, int N, float lambda,
+                                                                 float *__restrict__ T_out, uint32_t *__restrict__ tb) {
+  __shared__ float s_mx[4], s_sm[4];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float4 *l4 = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
+  const int groups = N >> 2;
+  float4 v[2];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = tid + 256 * u;
+    v[u] = q < groups ? l4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    mx = fmaxf(mx, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+  }
+  const float wmx = row_max(mx);
+  if (lane == 0) s_mx[wv] = wmx;
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+  float sm = 0.f;
+  if (bm > -INFINITY) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sm += (__expf(v[u].x - bm) + __expf(v[u].y - bm)) + (__expf(v[u].z - bm) + __expf(v[u].w - bm));
+  }
+  sm = row_sum(sm);
+  if (lane == 0) s_sm[wv] = sm;
+  __syncthreads();
+  const float bs = (s_sm[0] + s_sm[1]) + (s_sm[2] + s_sm[3]);
+  float Tf = bm + __logf(bs) - __logf(lambda);
+  if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY || fabsf(Tf) > 4096.f) Tf = INFINITY;   // as gumbel_screen_kernel
+  if (tid == 0) T_out[p] = Tf;
+  constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = tid + 256 * u;
+    if (q >= groups) continue;
+    const float lv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+    uint32_t wv4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double a = ((double)Tf - (double)kScreenMargin) - (double)lv[j];
+      const double e = exp(-a);
+      const double us = (e < 745.0) ? exp(-e) : 0.0;
+      double w = floor((us - kTiny) / kScale) - 1024.0;
+      if (!(w == w)) w = 0.0;
+      w = fmin(fmax(w, 0.0), 4294967295.0);
+      wv4[j] = (Tf == INFINITY) ? 0xffffffffu : (uint32_t)w;
+    }
+    reinterpret_cast<uint4 *>(tb + (size_t)p * N)[q] = make_uint4(wv4[0], wv4[1], wv4[2], wv4[3]);
+  }
+}
+
 // ---- rows longer than the register kernel holds (N > 2048): ONE pass ----------------------------------------------------
 // The general kernel above makes two passes over a row that does not fit its LDS cache -- lane maxima first, then the
 // candidates above the k-th largest lane maximum -- and generates the Philox noise of every element twice.  Here a lane keeps
@@ -834,6 +962,15 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
       if (soft)
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
                            (float *)y_sel, (float *)lse, seed_ptr);
+      else if (screen_ws && k <= 5 && B >= 64) {
+        // screened (round 5): workspace = P x N words + P scores
+        float *Tw = reinterpret_cast<float *>(screen_ws + (size_t)P * N);
+        hipLaunchKernelGGL(gumbel_screen_short_kernel, dim3(P), dim3(256), 0, st, (const float *)logits, N, (float)(11 + k), Tw, screen_ws);
+        hipLaunchKernelGGL((gumbel_topk_fast_kernel<false, true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
+                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate, (const uint32_t *)screen_ws,
+                           (const float *)Tw);
+        if (gathered) *gathered = gather_dst != nullptr;
+      }
       else
       {
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
@@ -1331,7 +1468,8 @@ int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N
 // K1 (index sets only) + K2 in one call: idx [P,B,k] and samples [P,B,k,4] = matches[p, idx] (test mode: the points themselves,
 // ransac.py:65).  One launch when the register kernel serves the shape, sampler + gather launches otherwise.
 static int gumbel_topk_gather_impl(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
-                                   int B, int N, int k, int32_t *idx, float *samples, dr::PairGate gate, void *stream) {
+                                   int B, int N, int k, int32_t *idx, float *samples, dr::PairGate gate, void *stream,
+                                   uint32_t *screen_ws = nullptr) {
   const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
   DR_REQUIRE(logits && matches && samples, "null pointer");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
@@ -1339,7 +1477,7 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
   bool gathered = false;
   if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
                                             (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
-                                            reinterpret_cast<float4 *>(samples), &gathered, nullptr, gate))
+                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate))
     return rc;
   if (gathered) return 0;
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
@@ -1355,14 +1493,18 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
 // the same for a round > 1 of a multi-round test-mode call: pairs whose iteration counter has reached its bound are skipped
 // (gate_iters [P] int32, gate_max_iters [P] f64: the state dr_ransac_update keeps; the rows of a skipped pair keep their contents).
 // Only the register-resident kernel (N <= 2048, N % 4 == 0, tau = 1) looks at the gate; other shapes simply run.
+// screen_ws (optional, (N + 32) * P words, 16-byte aligned; round 5): short rows (N <= 2048, N % 4 == 0, tau = 1, k <= 5, B >= 64)
+// then take the SCREENED register kernel -- per point the smallest Philox word that can lift it to the score logsumexp - ln(11 + k),
+// only the ~16 points of a row that pass are evaluated; the index sets are those of the unscreened kernel, bit for bit.
 int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
-                                    int P, int B, int N, int k, int32_t *idx, float *samples, const int32_t *gate_iters,
-                                    const double *gate_max_iters, void *stream) {
+                                    int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
+                                    const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
   DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
+  DR_REQUIRE((reinterpret_cast<uintptr_t>(screen_ws) & 15) == 0, "workspace alignment");
   dr::PairGate gate;
   gate.iters = gate_iters;
   gate.max_iters = gate_max_iters;
-  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream);
+  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws);
 }
 
 // K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 32) * P words, 16-byte aligned): long rows

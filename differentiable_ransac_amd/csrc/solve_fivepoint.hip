@@ -11,6 +11,10 @@
 // -> Gauss-Newton polish on the defining constraints -> verification.
 #include "fivepoint_device.hpp"
 
+// 1: the two-phase Nister kernel hands over B(z) only and computes the null-space basis again in the back pass (A/B, round 5)
+#ifndef DR_K3_FB_REBASIS
+#define DR_K3_FB_REBASIS 0
+#endif
 // waves per SIMD the minimal-sample kernels are compiled for (register budget = 512 / DR_K3_WAVES)
 #ifndef DR_K3_WAVES
 #define DR_K3_WAVES 1
@@ -168,7 +172,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   if (gate.iters && gate.closed((blockIdx.x * 64) / per_pair) && gate.closed((min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
+#if DR_K3_FB_REBASIS
+  AccDouble hand[39];        // this lane's sample: B(z) (the basis is computed again by the sample's lane pair in its pass)
+#else
   AccDouble hand[36 + 39];   // this lane's sample: basis | B(z)
+#endif
   double cs[11];
   DR_STAGE_BEGIN();
   {
@@ -179,10 +187,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     {
       double nb[4][9];
       fivepoint_basis_minimal<T>(samples + (size_t)sc * 20, weights ? weights + (size_t)sc * 5 : nullptr, nb);
+#if !DR_K3_FB_REBASIS
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int q = 0; q < 9; ++q) hand[9 * t + q].put(nb[t][q]);
+#endif
       basis_to_entries(nb, e);
     }
     double X[6][10];
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     double bz[39];
     nister_bz_det(X, bz, cs);
 #pragma unroll
-    for (int k = 0; k < 39; ++k) hand[36 + k].put(bz[k]);
+    for (int k = 0; k < 39; ++k) hand[(DR_K3_FB_REBASIS ? 0 : 36) + k].put(bz[k]);
     if (!ok || !act) {   // 1 + z^10: no real root in either half of the search, no bracket in the wave's queues
 #pragma unroll
       for (int i = 0; i <= 10; ++i) cs[i] = (i == 0 || i == 10) ? 1.0 : 0.0;
@@ -202,11 +212,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const size_t s0 = (size_t)blockIdx.x * 64 + 32 * p;
     if (s0 >= (size_t)Bt) break;
     wave_lds_order();   // the front stage / the previous pass is done with the LDS
+#if DR_K3_FB_REBASIS
+    if ((lane >> 5) == p) {
+      double *img = lds + 36 * 32 + (lane & 31);   // FinishQueue layout: B(z) behind the basis
+#pragma unroll
+      for (int k = 0; k < 39; ++k) img[k * 32] = hand[k].get();
+    }
+    {
+      const size_t sj = s0 + (lane >> 1) < (size_t)Bt ? s0 + (lane >> 1) : (size_t)Bt - 1;
+      double nb[4][9];
+      fivepoint_basis_minimal<T>(samples + sj * 20, weights ? weights + sj * 5 : nullptr, nb);
+      park_basis(FinishQueue(lds), nb, lane);
+    }
+#else
     if ((lane >> 5) == p) {
       double *img = lds + (lane & 31);   // FinishQueue layout: basis element e of sample j at [e * 32 + j], then B(z)
 #pragma unroll
       for (int k = 0; k < 36 + 39; ++k) img[k * 32] = hand[k].get();
     }
+#endif
     double csp[11];
 #pragma unroll
     for (int i = 0; i <= 10; ++i) csp[i] = lane_read(cs[i], 32 * p + (lane >> 1));

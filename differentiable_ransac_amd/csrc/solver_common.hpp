@@ -105,7 +105,7 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
                               // the slowest lane of a wave, but every step pays the extra loop: 165.1 -> 170.9 us at 131 072 samples; off)
 #endif
 #ifndef DR_K3_STURM_FALLBACK
-#define DR_K3_STURM_FALLBACK 1   // 1: lanes whose Sturm chain loses a degree walk the derivative chain instead (round 5)
+#define DR_K3_STURM_FALLBACK 1   // 1: a lane whose Sturm chain loses a degree has its roots found by the whole wave on a grid (round 5)
 #endif
 #ifndef DR_K3_SYMG
 #define DR_K3_SYMG 1          // 1: the six distinct entries of E E^T once in Nister's lane-pair kernel (constraint_rows; round 5)
@@ -597,100 +597,151 @@ __device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// The derivative chain once more, COMPACT: every loop rolled, every array in LDS (dynamic indices), plain bisection -- ~200
-// instructions and a dozen registers instead of the ~7 500 instructions of real_roots_half_wave.  It is the fallback of the Sturm
-// isolation (round 5) for the lanes whose chain lost a degree: rare, so its speed (tens of thousands of dependent FMAs) does not
-// matter, but its footprint does -- inlined next to the hot path, the unrolled version cost the Stewenius kernels 2-3 % through
-// the register allocation alone.  No division, no assumption about the degree: a vanishing leading coefficient only makes the
-// top derivatives vanish.  At the last level a critical point of p (a breakpoint between two brackets WITHOUT a sign change) at
-// which |p| is at rounding level is reported as a root: a root of even multiplicity, which no sign test can see (the reference's
-// eigvals returns it as a close real pair, or as a complex pair whose real parts it keeps, Q10).
-// LDS: 3 x (D + 1) x 64 doubles at `ws` (<= SturmWs<D>::kDoubles).  Every lane of the wave must call it (lanes without a polynomial: pass 1 + z^D).
+// Fallback of the Sturm isolation (round 5) for a lane whose chain lost a degree: the real roots of ONE polynomial in (-1, 1],
+// found by the WHOLE WAVE.  (First version: the lane itself walked a rolled derivative chain -- correct, and a catastrophe: tens
+// of thousands of dependent LDS reads, ~1 ms for the wave, and with one block per SIMD the launch ends when its slowest block
+// does: 0.15 -> 0.62 ms on 131 072 RANSAC samples, of which 1e-4 take this path.)  Here the 64 lanes evaluate q and q' on a grid of
+// 1024 cells (16 per lane, ~340 instructions); a cell over which q changes sign brackets a root; a cell over which only q'
+// changes sign holds an extremum of q -- the wave bisects q' there, and the extremum either separates two roots (q has the other
+// sign there), or is an even-multiplicity root (|q| at rounding level), or nothing.  Brackets are refined by the fixed schedule of
+// the refine tasks.  No division by a leading coefficient, no assumption about the degree; ~2-5 us per polynomial.
+// q: wave-uniform coefficients (max |q_i| = 1), ascending.  out (LDS, >= D doubles): the roots ascending; returns their number.
+// lo_ws / hi_ws: LDS scratch of 64 doubles each, cnt_ws: 64 ints.
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__device__ __forceinline__ void real_roots_half_compact(const double (&c)[D + 1], bool outer, double (&roots)[D], int &count, double *ws,
-                                                        int lane) {
-  double *CH = ws + lane, *Q = ws + (D + 1) * 64 + lane, *PT = ws + 2 * (D + 1) * 64 + lane;
-  double cmax = 0;
+__device__ __forceinline__ int wave_grid_roots(const double (&q)[D + 1], double *out, double *lo_ws, double *hi_ws, int *kind_ws, int lane) {
+  auto ev = [&](double x, double &fx, double &dfx) {
+    fx = q[D];
+    dfx = 0;
 #pragma unroll
-  for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
-  const bool ok = is_finite(cmax) && cmax > 0;
-  const double sc = ok ? 1.0 / cmax : 0.0;
-#pragma unroll
-  for (int i = 0; i <= D; ++i) {
-    const double a = ok ? c[i] * sc : (i == 0 ? 1.0 : 0.0);
-    const double b = ok ? c[D - i] * sc : (i == 0 ? 1.0 : 0.0);
-    CH[i * 64] = outer ? b : a;
-    PT[i * 64] = i == 0 ? -1.0 : 1.0;
-  }
-  unsigned has = 0, flat = 0;
-#pragma unroll 1
-  for (int d = 1; d <= D; ++d) {
-    // q = p^(D-d): q_i = ch[i + D - d] * (i + D - d)! / i!
-#pragma unroll 1
-    for (int i = 0; i <= d; ++i) {
-      double f = 1.0;
-#pragma unroll 1
-      for (int t = 0; t < D - d; ++t) f *= (double)(i + D - d - t);
-      Q[i * 64] = CH[(i + D - d) * 64] * f;
+    for (int i = D - 1; i >= 0; --i) {
+      dfx = dfx * x + fx;
+      fx = fx * x + q[i];
     }
-    auto evalq = [&](double x) {
-      double fx = Q[d * 64];
+  };
+  constexpr int kCells = 16;
+  const double h = 2.0 / (64 * kCells);
+  const double x0 = -1.0 + (double)(kCells * lane) * h;
+  // cells of this lane: sign change of q (kind 1), or of q' only with |q| small enough to matter (kind 2)
+  unsigned ma = 0, mb = 0;
+  double f0, d0;
+  ev(x0, f0, d0);
 #pragma unroll 1
-      for (int i = d - 1; i >= 0; --i) fx = fx * x + Q[i * 64];
-      return fx;
-    };
-    has = 0;
-    flat = 0;
-    double lo = PT[0];
-    double fprev = evalq(lo);
+  for (int i = 0; i < kCells; ++i) {
+    const double x1 = (lane == 63 && i == kCells - 1) ? 1.0 : x0 + (double)(i + 1) * h;
+    double f1, d1;
+    ev(x1, f1, d1);
+    const bool a = (f0 < 0) != (f1 < 0);
+    // an extremum inside the cell moves q by at most |q'| h ~ (|d0| + |d1|) h from its end values (q'' changes it further only in
+    // second order of h = 2e-3): cells whose end values are far above that cannot hide a root
+    const bool bb = !a && ((d0 < 0) != (d1 < 0)) && fmin(fabs(f0), fabs(f1)) <= 4.0 * h * (fabs(d0) + fabs(d1)) + 1e-10;
+    ma |= a ? (1u << i) : 0u;
+    mb |= bb ? (1u << i) : 0u;
+    f0 = f1;
+    d0 = d1;
+  }
+  // task list in grid order (ascending x): exclusive prefix of the per-lane counts
+  const int mine = __popc(ma | mb);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    incl += (lane >= d) ? o : 0;
+  }
+  const int total = min(__shfl(incl, 63, 64), 64);
+  int pos = incl - mine;
+  unsigned m = ma | mb;
+  while (m) {
+    const int i = __builtin_ctz(m);
+    m &= m - 1;
+    if (pos < 64) {
+      lo_ws[pos] = x0 + (double)i * h;
+      hi_ws[pos] = (lane == 63 && i == kCells - 1) ? 1.0 : x0 + (double)(i + 1) * h;
+      kind_ws[pos] = ((ma >> i) & 1u) ? 1 : 2;
+    }
+    ++pos;
+  }
+  wave_lds_order();
+  // one task per lane
+  const bool has = lane < total;
+  double lo = has ? lo_ws[lane] : 0.0, hi = has ? hi_ws[lane] : 0.0;
+  const int kind = has ? kind_ws[lane] : 0;
+  double r0 = 0, r1 = 0;
+  int nr = 0;
+  double flo, dlo;
+  ev(lo, flo, dlo);
+  double mid_ext = lo;
+  bool two = false;
+  if (__any(kind == 2)) {
+    // extremum of q in the cell: bisection on q'
+    double a = lo, b = hi;
+    const bool dneg = dlo < 0;
 #pragma unroll 1
-    for (int i = 0; i < d; ++i) {
-      // the brackets of a level are cut at the OLD breakpoints: the right end is read before the slot takes the level's result
-      const double hi = (i == d - 1) ? 1.0 : PT[(i + 1) * 64];
-      const double fhi = evalq(hi);
-      // a level polynomial that vanishes AT the left end (a root of p at 0 is a breakpoint of every level): its sign just inside
-      if (fprev == 0.0 && hi > lo) fprev = evalq(__builtin_fma(hi - lo, 1e-7, lo));
-      const bool h = ((fprev < 0) != (fhi < 0)) && (hi > lo);
-      double a = lo, b = hi;
-      const bool neg_a = fprev < 0;
-      if (__any(h)) {
-#pragma unroll 1
-        for (int it = 0; it < 48; ++it) {
-          const double m = 0.5 * (a + b);
-          const double fm = evalq(m);
-          const bool left = (fm < 0) == neg_a, hit = fm == 0.0;
-          a = (left || hit) ? m : a;
-          b = (left && !hit) ? b : m;
-        }
-      }
-      PT[(i + 1) * 64] = h ? 0.5 * (a + b) : hi;
-      has |= h ? (1u << i) : 0u;
-      // |p| at the right end of bracket i (coefficients: max 1); not near 0: an even-fold root of the REVERSED polynomial there is a
-      // root of p at infinity (vanishing leading coefficients), and a constant p would otherwise "vanish" (w^D) all around it
-      if (d == D && i < d - 1 && fabs(fhi) <= 1e-11 && fabs(hi) > 1e-3) flat |= 1u << i;
-      fprev = fhi;
-      lo = hi;
+    for (int it = 0; it < 28; ++it) {   // a cell is 2e-3 wide: 2^-28 of it is below the rounding of the extremum's position
+      const double mm = 0.5 * (a + b);
+      double fm, dm;
+      ev(mm, fm, dm);
+      const bool left = (dm < 0) == dneg;
+      a = left ? mm : a;
+      b = left ? b : mm;
+    }
+    mid_ext = 0.5 * (a + b);
+    double fe, de;
+    ev(mid_ext, fe, de);
+    if (kind == 2) {
+      two = (fe < 0) != (flo < 0) && fe != 0.0;           // the extremum lies on the other side: two simple roots around it
+      if (!two && fabs(fe) <= 1e-11) { r0 = mid_ext; nr = 1; }   // q touches zero: a root of even multiplicity
     }
   }
-  // bracket i empty, bracket i + 1 empty, p(their common end) = 0: slot i holds that end
-  unsigned mk = has | (flat & ~has & ~(has >> 1));
-  if (!ok) mk = 0;
-  count = 0;
-#pragma unroll
-  for (int i = 0; i < D; ++i) roots[i] = 0.0;
+  // brackets with a sign change: [lo, hi] (kind 1), or [lo, ext] and [ext, hi] (kind 2, two)
+  auto refine = [&](double a, double b, bool want) -> double {
+    double fa, da;
+    ev(a, fa, da);
+    const bool neg = fa < 0;
 #pragma unroll 1
-  for (int k = 0; k < D; ++k) {
-    const double xk = PT[(k + 1) * 64];
-    const bool take = ((mk >> k) & 1u) && (!outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0));
-    if (take) Q[count * 64] = outer ? 1.0 / xk : xk;   // (the level polynomials are dead)
-    count += take ? 1 : 0;
+    for (int it = 0; it < 12; ++it) {
+      const double mm = 0.5 * (a + b);
+      double fm, dm;
+      ev(mm, fm, dm);
+      const bool left = (fm < 0) == neg, hit = fm == 0.0;
+      a = (left || hit) ? mm : a;
+      b = (left && !hit) ? b : mm;
+    }
+    double y = 0.5 * (a + b);
+#pragma unroll 1
+    for (int it = 0; it < 6; ++it) {
+      double fx, dfx;
+      ev(y, fx, dfx);
+      const bool left = (fx < 0) == neg;
+      a = left ? y : a;
+      b = left ? b : y;
+      const double yn = safeguarded_newton<double>(y, fx * __builtin_amdgcn_rcp(dfx), a, b);
+      y = (fx == 0.0) ? y : yn;
+    }
+    (void)want;
+    return y;
+  };
+  if (__any(kind == 1 || two)) {
+    const double y = refine(lo, two ? mid_ext : hi, kind == 1 || two);
+    if (kind == 1 || two) { r0 = y; nr = 1; }
   }
+  if (__any(two)) {
+    const double y = refine(mid_ext, hi, two);
+    if (two) { r1 = y; nr = 2; }
+  }
+  // roots in ascending order: prefix of the per-task counts
+  int inc2 = nr;
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const double r = Q[i * 64];
-    roots[i] = (i < count) ? r : 0.0;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc2, d, 64);
+    inc2 += (lane >= d) ? o : 0;
   }
+  const int nall = __shfl(inc2, 63, 64);
+  const int p0 = inc2 - nr;
+  if (nr >= 1 && p0 < D) out[p0] = r0;
+  if (nr >= 2 && p0 + 1 < D) out[p0 + 1] = r1;
+  wave_lds_order();
+  return min(nall, D);
 }
 
 // wave-cooperative (block = one wave): every lane must call it.  Same outputs as real_roots_half_wave.
@@ -742,6 +793,9 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
     const int n = D - k + 1;
     const double an = F[k - 1][n], an1 = F[k - 1][n - 1], b = F[k][n - 1], b2 = (n >= 2) ? F[k][n - 2] : 0.0;
     degenerate = degenerate || !(fabs(b) > 1e-11);
+#ifdef DR_PROFILE_STAGES
+    if (D == 10 && !(fabs(b) > 1e-11)) atomicAdd(&::dr::g_stage_cycles[23], 1ull);
+#endif
     double rmax = 0;   // largest coefficient of the raw remainder (inputs: max 1): at rounding level => p and p' share a factor
     const double q1 = an * b, q0 = an1 * b - an * b2, bb = b * b;
 #pragma unroll
@@ -753,6 +807,9 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
         rmax = fmax(rmax, fabs(r));
       }
     }
+#ifdef DR_PROFILE_STAGES
+    if (D == 10 && fabs(b) > 1e-11 && !(rmax > 1e-12 * (bb + fabs(q0) + fabs(q1)))) atomicAdd(&::dr::g_stage_cycles[24], 1ull);
+#endif
     degenerate = degenerate || !(rmax > 1e-12 * (bb + fabs(q0) + fabs(q1)));
     renorm(F[k + 1], n - 2);
   }
@@ -954,21 +1011,41 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
   }
 #if DR_K3_STURM_FALLBACK
   degenerate = degenerate && ok;
-  if (__any(degenerate)) {
-    // rare: the whole wave walks the (compact) derivative chain once, the lanes with a sound chain on 1 + z^D (no real root)
-    double cd[D + 1], r2[D];
-    int n2;
-#pragma unroll
-    for (int i = 0; i <= D; ++i) cd[i] = degenerate ? c[i] : ((i == 0 || i == D) ? 1.0 : 0.0);
+#ifdef DR_PROFILE_STAGES
+  if (D == 10) { if (degenerate) atomicAdd(&::dr::g_stage_cycles[21], 1ull); if (lane == 0 && __any(degenerate)) atomicAdd(&::dr::g_stage_cycles[22], 1ull); }
+#endif
+  unsigned long long todo = __ballot(degenerate);
+  if (todo) {
+    // rare (1e-4 of the lanes on RANSAC samples): one polynomial at a time, by the whole wave (wave_grid_roots)
     wave_lds_order();
-    // (the compact form: real_roots_half_wave inlined here cost the Stewenius kernels 2-3 % through the register allocation of
-    // the hot path; as a real call -- __attribute__((noinline)) -- the device compiler did not finish within 40 minutes)
-    static_assert(3 * (D + 1) * 64 <= SturmWs<D>::kDoubles, "the fallback works in the isolation's own workspace");
-    real_roots_half_compact<D>(cd, outer, r2, n2, lds_ws, lane);
-    if (degenerate) {
-      count = n2;
+    double *gout = lds_ws, *glo = lds_ws + 64, *ghi = lds_ws + 128;
+    int *gkind = reinterpret_cast<int *>(lds_ws + 192);
+    static_assert(192 + 32 <= SturmWs<D>::kDoubles, "the fallback works in the isolation's own workspace");
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      double qq[D + 1];
 #pragma unroll
-      for (int i = 0; i < D; ++i) roots[i] = r2[i];
+      for (int i = 0; i <= D; ++i) qq[i] = __shfl(F[0][i], src, 64);   // the lane's normalised (and, for its outer half, reversed) polynomial
+      const int nfound = wave_grid_roots<D>(qq, gout, glo, ghi, gkind, lane);
+      const bool src_outer = __shfl((int)outer, src, 64) != 0;
+      if (lane == src) {
+        count = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) roots[i] = 0.0;
+      }
+#pragma unroll 1
+      for (int kk = 0; kk < nfound; ++kk) {
+        const double xk = gout[kk];
+        const bool take = !src_outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0);
+        const double vv_ = src_outer ? 1.0 / xk : xk;
+        if (lane == src && take) {
+#pragma unroll
+          for (int t = 0; t < D; ++t) roots[t] = (t == count) ? vv_ : roots[t];
+          ++count;
+        }
+      }
+      wave_lds_order();
     }
   }
 #endif

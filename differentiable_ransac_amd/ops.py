@@ -210,7 +210,17 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
     return out
 
 
-def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None):
+import os as _os
+# Round 5: the screened register kernel for rows of <= 2048 points (dr_gumbel_topk_gather_gated_f32 with a workspace) is built,
+# bit-identical (tests/test_gpu_round5.py) and SLOWER than the unscreened one at the shapes measured -- 200.8 vs 164.1 us at 128
+# pairs x 1024 rows x 2000 points, 55.2 vs 44.4 at 32 pairs, 17.8 vs 12.5 at one pair (scratch/ab_k1_screen.py): ~16 of 2000 points
+# pass, but a wave owns ONE row, so what it saves in logarithms it pays in the dependent loads of its 3-4 evaluation rounds and in
+# the 32 KiB of LDS per block its parked words cost in occupancy.  Off unless asked for (screen=True, DRANSAC_SCREEN_SHORT=1).
+SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
+
+
+def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None,
+                       screen: Optional[bool] = None):
     """K1 (index sets only, in-kernel noise) + K2 in one call: matches [P,N,4] f32, logits [P,N] f32 ->
     (idx [P,B,k] int32 ascending, samples [P,B,k,4] = matches[p, idx]).  What test mode asks of sampler + gather
     (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor."""
@@ -221,10 +231,14 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
     idx = torch.empty((P, B, k), device=logits.device, dtype=torch.int32)
     samples = torch.empty((P, B, k, 4), device=logits.device, dtype=torch.float32)
     dev_seed = _dev_seed(seed)
-    if gate is not None:     # a later round of a multi-round call: terminated pairs (gate = RansacState) are skipped
+    # round 5: rows of <= 2048 points through the SCREENED register kernel (a workspace of thresholds per point: same index sets)
+    want_screen = SCREEN_SHORT_ROWS if screen is None else screen
+    ws = (torch.empty((P, N + 32), device=logits.device, dtype=torch.int32)
+          if want_screen and N <= 2048 and N % 4 == 0 and tau == 1.0 and k <= 5 and B >= 64 else None)
+    if gate is not None or ws is not None:     # (gate: a later round of a multi-round call, terminated pairs are skipped)
         L.call("dr_gumbel_topk_gather_gated_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
                ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
-               ptr(gate.iters), ptr(gate.max_iters), stream())
+               ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters), stream())
         return idx, samples
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
            ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples), stream())

@@ -119,9 +119,11 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
                               int B, int N, int k, int32_t *idx, float *samples, void *stream);
 /* the same for a round > 1 of a multi-round test-mode call: pairs with gate_iters[p] >= gate_max_iters[p] are skipped (see the
  * `_gated` solver entries below) */
+/* screen_ws (optional; (N + 32) * P words, 16-byte aligned): rows of <= 2048 points then take the screened register kernel -- only
+ * the points whose Philox word can lift them to logsumexp(logits) - ln(11 + k) are evaluated (same index sets, bit for bit). */
 int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
-                                    int P, int B, int N, int k, int32_t *idx, float *samples, const int32_t *gate_iters,
-                                    const double *gate_max_iters, void *stream);
+                                    int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
+                                    const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 
 /* K1, index sets only, in-kernel noise, with an optional screening workspace (round 4; GumbelSoftmaxSampler.sample,
  * samplers/gumbel_sampler.py:25-42, as test mode consumes it: `points[samples != 0]`, ransac.py:65).

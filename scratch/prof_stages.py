@@ -28,4 +28,4 @@ for name, fn in (('nister', lambda x: ops.solve_nister5(x, path=PATH)),):
     fn(smp); torch.cuda.synchronize()
     lib.dr_debug_stage_read_fivepoint(buf)
     tot = sum(buf)
-    print(name, 'path', PATH, 'waves (32-sample units)', P * B // 32, 'cycles/wave by stage:', [int(b) // (P * B // 32) for b in buf[:10]] + ['final', int(buf[11]) // (P * B // 32)] + [round(int(buf[i]) / (P * B // 32), 2) for i in (13, 14, 15)], 'max isolation iterations of a wave', int(buf[10]), '| final stage: start', int(buf[16]) // (P * B // 32), 'precheck', int(buf[17]) // (P * B // 32), 'steps', int(buf[18]) // (P * B // 32), 'verify+store', int(buf[19]) // (P * B // 32), 'identity', int(buf[20]) // (P * B // 32))
+    print(name, 'path', PATH, 'waves (32-sample units)', P * B // 32, 'cycles/wave by stage:', [int(b) // (P * B // 32) for b in buf[:10]] + ['final', int(buf[11]) // (P * B // 32)] + [round(int(buf[i]) / (P * B // 32), 2) for i in (13, 14, 15)], 'max isolation iterations of a wave', int(buf[10]), '| final stage: start', int(buf[16]) // (P * B // 32), 'precheck', int(buf[17]) // (P * B // 32), 'steps', int(buf[18]) // (P * B // 32), 'verify+store', int(buf[19]) // (P * B // 32), 'identity', int(buf[20]) // (P * B // 32), '| degenerate lanes', int(buf[21]), 'waves with one', int(buf[22]), 'by leading coefficient (lane x member)', int(buf[23]), 'by remainder', int(buf[24]))

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/r5o
+O=$PWD/gpurun_out/r5o
+for v in "" k3nofb; do
+lib=""; [ -n "$v" ] && lib=$PWD/scratch/libdransac_$v.so
+DRANSAC_LIB=$lib DRANSAC_SCREEN_SHORT=0 timeout 300 python bench.py --steps 200 --warmup 20 --no-configs --no-cpu-baseline --no-extras --profile-kernels > $O/bench_$v.json 2> $O/bench_$v.err
+python -c "
+import json; d=json.load(open('$O/bench_$v.json')); print('lib=${v:-tree}', round(d['value']/1e6,2), 'M  step', round(d['ms_per_step'],4), 'K3', d['kernel_breakdown_ms']['K3_solver'])"
+done

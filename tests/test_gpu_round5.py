@@ -287,3 +287,32 @@ def test_screened_sampler_with_large_logit_offsets_equals_the_unscreened_kernel(
     a = ops.gumbel_topk(logits, B, k, 1.0, None, 9, soft=False, screen=True)["idx"]
     b = ops.gumbel_topk(logits, B, k, 1.0, None, 9, soft=False, screen=False)["idx"]
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------- K1, short rows: the screened register kernel
+@pytest.mark.parametrize("N,B,k", [(2000, 1024, 5), (2048, 256, 3), (1000, 64, 5), (500, 1024, 1), (2000, 1024, 4)])
+def test_screened_short_row_sampler_equals_the_unscreened_kernel(dev, N, B, k):
+    """dr_gumbel_topk_gather_gated_f32 with a screening workspace (round 5): only the points whose Philox word can lift them to
+    logsumexp(logits) - ln(11 + k) are evaluated -- index sets and gathered samples equal to the unscreened register kernel's, bit for
+    bit, for ordinary, sharply peaked, flat and shifted logits (flat rows: thousands of candidates -> the unscreened path inside)"""
+    from differentiable_ransac_amd import ops, synth
+    P = 3
+    d = synth.batch_two_view(P, N, seed0=21)
+    m = d["matches"].to(dev)
+    gen = torch.Generator().manual_seed(N + k)
+    variants = {"synthetic": d["logits"], "peaked": torch.randn(P, N, generator=gen) * 8.0,
+                "flat": torch.zeros(P, N), "shifted": d["logits"] + 700.0,
+                "few_finite": torch.full((P, N), -1e4).index_fill_(1, torch.arange(0, N, 97), 0.0)}
+    for name, lg in variants.items():
+        lg = lg.to(dev).contiguous()
+        for seed in (1, 12345678901234567):
+            ia, sa = ops.gumbel_topk_gather(m, lg, B, k, 1.0, seed, screen=True)
+            ib, sb = ops.gumbel_topk_gather(m, lg, B, k, 1.0, seed, screen=False)
+            assert torch.equal(ia, ib) and torch.equal(sa, sb), (name, seed)
+    # and against the oracle on the reported noise, through the general kernel's noise output
+    lg = d["logits"].to(dev)
+    r = ops.gumbel_topk(lg, B, k, 1.0, None, 5, want_noise=True)
+    ia, _ = ops.gumbel_topk_gather(m, lg, B, k, 1.0, 5, screen=True)
+    assert torch.equal(ia, r["idx"])
+    io, _, _ = O.gumbel_topk(d["logits"][0], r["gumbel"][0].cpu(), 1.0, k)
+    assert torch.equal(ia[0].cpu().long(), io)
