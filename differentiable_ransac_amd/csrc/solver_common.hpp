@@ -1010,7 +1010,13 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
     roots[i] = (i < count) ? r : 0.0;
   }
 #if DR_K3_STURM_FALLBACK
-  degenerate = degenerate && ok;
+  // (1 + z^D is the polynomial the callers hand to lanes WITHOUT a sample -- partial blocks, few samples per block on small grids,
+  // rank-deficient systems: its chain loses eight degrees at once and it has no real root: nothing to look for.  Forgetting this
+  // sent every idle lane of a one-pair call through the fallback: 30 -> 189 us.)
+  bool dummy = true;
+#pragma unroll
+  for (int i = 1; i < D; ++i) dummy = dummy && c[i] == 0.0;
+  degenerate = degenerate && ok && !dummy;
 #ifdef DR_PROFILE_STAGES
   if (D == 10) { if (degenerate) atomicAdd(&::dr::g_stage_cycles[21], 1ull); if (lane == 0 && __any(degenerate)) atomicAdd(&::dr::g_stage_cycles[22], 1ull); }
 #endif
