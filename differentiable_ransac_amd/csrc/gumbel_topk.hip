@@ -305,14 +305,20 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
 // 7.7, everything else 42-48), this kernel 60.0 us (everything else: 29); train mode 88.1 -> 74.4 us.
 constexpr int kFastGroups = 8;   // groups per lane: 64 lanes x 8 groups x 4 elements = 2048
 
+// train mode, K2 fused: the correspondence times the straight-through weight (1 - y) + y (gumbel_sampler.py:40: y_hard -
+// y_soft.detach() + y_soft at a selected point), the arithmetic of gather_fwd_kernel
+__device__ __forceinline__ float4 straight_through(float4 m, float y) {
+  const float st = (1.0f - y) + y;
+  return make_float4(m.x * st, m.y * st, m.z * st, m.w * st);
+}
+
 // kScreen (round 5, index-only mode): the screening words of the long-row kernel for SHORT rows.  A point can only be among the k
 // winners if its score reaches T = logsumexp(logits) - ln(lambda), i.e. if its Philox word reaches a per-point threshold that
-// depends on the pair's logits only (gumbel_screen_short_kernel: screen_tb [P,N] words, screen_T [P]).  A lane compares the 32
-// words of its elements against their thresholds -- no logarithm, no logit -- parks the words in LDS, and the wave then evaluates
-// only the ~lambda elements that passed, one per lane and round (lambda = 11 + k: two or three rounds), exactly as the unscreened
-// kernel would have (same word, same logit, same rounding): the winners are ranked among them by (value, index).  A row with
-// fewer than k evaluated scores >= T (4e-4 of the rows at lambda = 16), or more candidates than the list holds, takes the
-// unscreened path below.  Per row ~520 vector instructions instead of ~890: Philox stays, 32 x (two logarithms + adds) go.
+// depends on the pair's logits only (gumbel_screen_short_kernel: screen_tb [P,N] words, screen_T [P]).  The wave compares the 64
+// words of an element slot against their thresholds -- no logarithm -- and only the lanes that pass (~lambda = 11 + k elements of
+// the row) evaluate their score, exactly as the unscreened kernel would have (same word, same logit, same rounding): the winners
+// are ranked among them by (value, index).  A row with fewer than k evaluated scores >= T (4e-4 of the rows at lambda = 16), or
+// more candidates than the list holds, takes the unscreened path below.
 template <bool kSoft, bool kScreen = false>
 __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(const float *__restrict__ logits, uint64_t seed,
                                                                              int B, int N, int k, int32_t *__restrict__ idx,
@@ -329,7 +335,6 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   static_assert(!(kSoft && kScreen), "the soft-max statistics need every element's score");
   __shared__ float s_val[kRowsPerBlock][kMaxCand];
   __shared__ int s_idx[kRowsPerBlock][kMaxCand];
-  __shared__ __align__(16) uint32_t s_words[kScreen ? kRowsPerBlock : 1][kScreen ? kFastGroups * 64 * 4 : 4];
 #if DR_K1_PASSB_ATOMIC
   __shared__ int s_cnt[kRowsPerBlock];
 #endif
@@ -351,36 +356,46 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   if constexpr (kScreen) {
     const float Tf = screen_T[p];
     if (Tf != INFINITY) {   // (non-finite logits, or a threshold beyond the margin's reach: the pair is not screened)
+      // One element SLOT (group i, component j) at a time: the wave compares the slot's 64 words with their thresholds (one
+      // v_cmp; the result is a wave mask in SGPRs) and, only if some lane passed (~40 % of the slots at lambda = 16), those lanes
+      // transform THEIR word -- a register with a static index -- add the logit they hold and append the score to the wave's
+      // list.  No word is parked anywhere, no load depends on a hit (first version, `s_words`: 32 KiB of LDS per block and a
+      // global logit load per evaluation round -- slower than the unscreened kernel although it issued 40 % less).
       const uint4 *tb4 = reinterpret_cast<const uint4 *>(screen_tb + (size_t)p * N);
-      uint32_t *wst = s_words[wv];
-      uint32_t hit = 0;
+      int ncand = 0, reach = 0;
+      uint4 t_nx = lane < groups ? tb4[lane] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      float4 l_nx = lane < groups ? lg[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < kFastGroups; ++i) {
+        if (64 * i >= groups) break;   // wave-uniform
         const int q = lane + 64 * i;
-        if (q < groups) {
-          uint32_t r[4];
-          Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
-          const uint4 t = tb4[q];
-          hit |= (r[0] >= t.x ? 1u : 0u) << (4 * i);
-          hit |= (r[1] >= t.y ? 1u : 0u) << (4 * i + 1);
-          hit |= (r[2] >= t.z ? 1u : 0u) << (4 * i + 2);
-          hit |= (r[3] >= t.w ? 1u : 0u) << (4 * i + 3);
-          *reinterpret_cast<uint4 *>(wst + (i * 64 + lane) * 4) = make_uint4(r[0], r[1], r[2], r[3]);
+        const bool inb = q < groups;
+        const uint4 t4 = t_nx;
+        const float4 l4v = l_nx;
+        if (i + 1 < kFastGroups) {     // the next group's thresholds and logits are requested before this group's Philox rounds
+          const int qn = q + 64;
+          t_nx = qn < groups ? tb4[qn] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+          l_nx = qn < groups ? lg[qn] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-      }
-      int ncand = 0, reach = 0;
-      while (__any(hit != 0)) {
-        const bool has = hit != 0;
-        const int e = has ? __builtin_ctz(hit) : 0;
-        hit &= hit - 1;
-        const int n = 4 * (lane + 64 * (e >> 2)) + (e & 3);
-        const uint32_t word = wst[((e >> 2) * 64 + lane) * 4 + (e & 3)];      // the lane's own slot: program order
-        const float gv = logits[(size_t)p * N + (has ? n : 0)] + gumbel_from_bits(word);
-        const unsigned long long bal = __ballot(has);
-        const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
-        if (has && pos < kMaxCand) { cand_val[pos] = gv; cand_idx[pos] = n; }
-        ncand += __popcll(bal);
-        reach += __popcll(__ballot(has && gv >= Tf));
+        uint32_t r[4];
+        Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+        const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        const float ll[4] = {l4v.x, l4v.y, l4v.z, l4v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool has = inb && r[j] >= tt[j];
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);   // (the compare's own mask: __ballot adds a select + compare)
+          if (bal) {
+            float gv = -INFINITY;
+            if (has) {
+              gv = ll[j] + gumbel_from_bits(r[j]);
+              const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+              if (pos < kMaxCand) { cand_val[pos] = gv; cand_idx[pos] = 4 * q + j; }
+            }
+            ncand += __popcll(bal);
+            reach += __popcll(__builtin_amdgcn_ballot_w64(has && gv >= Tf));
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -557,7 +572,11 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
     }
     if (win) {
       idx[row * k + pos] = ci;
-      if (kSoft) y_sel[row * k + pos] = exp_t<float>(cv - wmx) * inv_sm;
+      if (kSoft) {
+        const float y = exp_t<float>(cv - wmx) * inv_sm;
+        y_sel[row * k + pos] = y;
+        if (gather_dst) gather_dst[row * k + pos] = straight_through(gather_src[(size_t)p * N + ci], y);
+      }
       if (!kSoft && gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + ci];
     }
   } else {
@@ -593,7 +612,11 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
       int pos = 0;
       for (int r = 0; r < k; ++r) pos += won[r] < me;
       idx[row * k + pos] = me;
-      if (kSoft) y_sel[row * k + pos] = exp_t<float>(mg - wmx) * inv_sm;
+      if (kSoft) {
+        const float y = exp_t<float>(mg - wmx) * inv_sm;
+        y_sel[row * k + pos] = y;
+        if (gather_dst) gather_dst[row * k + pos] = straight_through(gather_src[(size_t)p * N + me], y);
+      }
       if (!kSoft && gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + me];
     }
   }
@@ -669,6 +692,61 @@ __global__ __launch_bounds__(256) void gumbel_screen_kernel(const float *__restr
   constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);
   // G >= a  <=>  u >= exp(-exp(-a)),  u = fl(fl24(w) * 2^-32 c + tiny)  (gumbel_from_bits),  a = T - margin - logit_n
   const double a = ((double)Tf - (double)kScreenMargin) - (double)logits[(size_t)p * N + n];
+  const double e = exp(-a);
+  const double us = (e < 745.0) ? exp(-e) : 0.0;
+  double w = floor((us - kTiny) / kScale) - 1024.0;
+  if (!(w == w)) w = 0.0;
+  w = fmin(fmax(w, 0.0), 4294967295.0);
+  tb[(size_t)p * N + n] = (Tf == INFINITY) ? 0xffffffffu : (uint32_t)w;
+}
+
+// (a+b) in ONE launch (round 5): blocks of 1024 threads, one point per thread for the words; every block first derives the pair's
+//     T from the WHOLE row itself -- the same loads, the same order, hence the same value in every block (block 0 publishes it) --
+//     which costs a block ~12 float4 loads and ~50 exponentials per thread at 50 000 points (the row is 200 KB: L2 / MALL hits
+//     after the first block) and saves the partial-sum launch with its dependency: 4.1 + 4.8 us + a graph edge -> one kernel.
+#ifndef DR_K1_SCREEN_FUSED
+#define DR_K1_SCREEN_FUSED 1
+#endif
+__global__ __launch_bounds__(1024) void gumbel_screen_fused_kernel(const float *__restrict__ logits, int N, float lambda,
+                                                                  float *__restrict__ T_out, uint32_t *__restrict__ tb) {
+  __shared__ float s_mx[16], s_sm[16];
+  const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float4 *l4 = reinterpret_cast<const float4 *>(logits + (size_t)p * N);   // N % 4 == 0 (the long-row kernel's condition)
+  const int groups = N >> 2;
+  const int n = blockIdx.x * 1024 + tid;
+  const float mine = n < N ? logits[(size_t)p * N + n] : 0.f;   // requested before the row pass
+  float mx = -INFINITY, sm = 0.f;
+  for (int q0 = tid; q0 < groups; q0 += 4 * 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * 1024;
+      v[u] = q < groups ? l4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float m4 = fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w));
+      if (m4 > mx) { sm *= __expf(mx - m4); mx = m4; }
+      if (mx > -INFINITY) sm += (__expf(v[u].x - mx) + __expf(v[u].y - mx)) + (__expf(v[u].z - mx) + __expf(v[u].w - mx));
+    }
+  }
+  const float wmx = row_max(mx);
+  sm *= (mx == -INFINITY) ? 0.f : __expf(mx - wmx);
+  sm = row_sum(sm);
+  if (lane == 0) { s_mx[wv] = wmx; s_sm[wv] = sm; }
+  __syncthreads();
+  float bm = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) bm = fmaxf(bm, s_mx[w]);
+  float bs = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) bs += (s_mx[w] == -INFINITY) ? 0.f : s_sm[w] * __expf(s_mx[w] - bm);
+  float Tf = bm + __logf(bs) - __logf(lambda);
+  if (!(Tf == Tf) || Tf == INFINITY || Tf == -INFINITY || fabsf(Tf) > 4096.f) Tf = INFINITY;   // as gumbel_screen_kernel
+  if (blockIdx.x == 0 && tid == 0) T_out[p] = Tf;
+  if (n >= N) return;
+  constexpr double kTiny = 1.17549435e-38, kScale = 2.3283064365386963e-10 * (1.0 - 1.1920928955078125e-07 - 1.17549435e-38);
+  const double a = ((double)Tf - (double)kScreenMargin) - (double)mine;
   const double e = exp(-a);
   const double us = (e < 745.0) ? exp(-e) : 0.0;
   double w = floor((us - kTiny) / kScale) - 1024.0;
@@ -959,9 +1037,11 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
   const bool soft = y_sel != nullptr;   // the entry points have checked: y_sel and lse both given, or neither (then no dense outputs)
   if constexpr (sizeof(T) == 4) {
     if (DR_K1_FAST && logits && !gumbel && tau == T(1) && (N & 3) == 0 && N <= 4 * 64 * kFastGroups && !y_soft && !ret && !gumbel_out) {
-      if (soft)
+      if (soft) {
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse, seed_ptr);
+                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst);
+        if (gathered) *gathered = gather_dst != nullptr;
+      }
       else if (screen_ws && k <= 5 && B >= 64) {
         // screened (round 5): workspace = P x N words + P scores
         float *Tw = reinterpret_cast<float *>(screen_ws + (size_t)P * N);
@@ -989,9 +1069,14 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
         // workspace: P x N words + P scores + P x 16 partial sums; lambda = 20 + k: P(fewer than k of a row's points reach T) < 1e-7
         float *Tw = reinterpret_cast<float *>(screen_ws + (size_t)P * N);
         float *part = Tw + P;
-        hipLaunchKernelGGL(gumbel_screen_part_kernel, dim3(kScreenParts, P), dim3(256), 0, st, (const float *)logits, N, part);
-        hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 255) / 256, P), dim3(256), 0, st, (const float *)logits, N, (float)(20 + k),
-                           part, Tw, screen_ws);
+        if (DR_K1_SCREEN_FUSED && (long)((N + 1023) / 1024) * N <= (16L << 20)) {   // (row re-reads bounded: beyond, the two-launch form)
+          hipLaunchKernelGGL(gumbel_screen_fused_kernel, dim3((N + 1023) / 1024, P), dim3(1024), 0, st, (const float *)logits, N,
+                             (float)(20 + k), Tw, screen_ws);
+        } else {
+          hipLaunchKernelGGL(gumbel_screen_part_kernel, dim3(kScreenParts, P), dim3(256), 0, st, (const float *)logits, N, part);
+          hipLaunchKernelGGL(gumbel_screen_kernel, dim3((N + 255) / 256, P), dim3(256), 0, st, (const float *)logits, N, (float)(20 + k),
+                             part, Tw, screen_ws);
+        }
         tb = screen_ws;
         Tp = Tw;
       }
@@ -1031,7 +1116,12 @@ __device__ __forceinline__ float log2_uniform_from_bits(uint32_t bits) {
 template <typename T>
 __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const int32_t *__restrict__ idx,
                                                          const T *__restrict__ lse, const T *__restrict__ a_sel,
-                                                         T *__restrict__ grad_logits, int rows_per_block) {
+                                                         T *__restrict__ grad_logits, int rows_per_block,
+                                                         const T *__restrict__ grad_samples = nullptr,
+                                                         const T *__restrict__ grad_w = nullptr,
+                                                         const T *__restrict__ matches4 = nullptr) {
+  // a_sel == nullptr (round 5): the backward of K2 on the way -- a = <grad_samples[row, j, :], matches[p, idx, :]> (+ grad_w),
+  // four-component correspondences, the arithmetic of gather_bwd_kernel (whose launch and [P,B,k] tensor this replaces)
   // one thread per 4-point group of pair p (one Philox call regenerates its noise); blockIdx.z owns a chunk of
   // `rows_per_block` hypothesis rows (their lse and <y,a> are staged in LDS) and adds its partial sums
   // into grad_logits with one atomicAdd per point: (groups/256) x P x (B/rows_per_block) blocks fill the chip, where a
@@ -1081,7 +1171,15 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(GumbelArgs<T> a, const 
         ls = lse[row];
         if (j < a.k) {
           const int i = idx[row * a.k + j];
-          const T av = a_sel[row * a.k + j];
+          T av;
+          if (a_sel) av = a_sel[row * a.k + j];
+          else {
+            const T *gs = grad_samples + (row * a.k + j) * 4, *m = matches4 + ((size_t)p * a.N + i) * 4;
+            av = T(0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) av += gs[d] * m[d];
+            if (grad_w) av += grad_w[row * a.k + j];
+          }
           // y at the selected index is recomputed from (logit, noise): y = exp(g - lse)
           T nz;
           if (a.gumbel) nz = a.gumbel[row * a.N + i];
@@ -1314,8 +1412,9 @@ __global__ void gather_bwd_kernel(const T *__restrict__ matches, const int32_t *
 template <typename T>
 static int gumbel_bwd_impl(const T *logits, const T *gumbel, uint64_t seed, const uint64_t *seed_ptr, T tau,
                            int P, int B, int N, int k, const int32_t *idx, const T *lse, const T *a_sel,
-                           T *grad_logits, void *stream) {
-  DR_REQUIRE(idx && lse && a_sel && grad_logits, "null pointer");
+                           T *grad_logits, void *stream, const T *grad_samples = nullptr, const T *grad_w = nullptr,
+                           const T *matches4 = nullptr) {
+  DR_REQUIRE(idx && lse && grad_logits && (a_sel || (grad_samples && matches4)), "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && N > 0 && P <= 65535 && k >= 1 && k <= dr::kMaxK && tau > 0, "bad sizes");
   dr::GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
   const size_t smem = sizeof(T) * 256 * 2;
@@ -1334,7 +1433,7 @@ static int gumbel_bwd_impl(const T *logits, const T *gumbel, uint64_t seed, cons
   if (hipMemsetAsync(grad_logits, 0, sizeof(T) * (size_t)P * N, (hipStream_t)stream) != hipSuccess)
     return dr::check_launch("memset");
   hipLaunchKernelGGL((dr::gumbel_bwd_kernel<T>), dim3(gx, P, chunks), dim3(256), smem, (hipStream_t)stream, a, idx,
-                     lse, a_sel, grad_logits, rows_per_block);
+                     lse, a_sel, grad_logits, rows_per_block, grad_samples, grad_w, matches4);
   return dr::check_launch("gumbel_bwd_kernel");
 }
 static int gumbel_bwd_f32_impl(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_ptr, float tau,
@@ -1488,6 +1587,37 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
 int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
                               int B, int N, int k, int32_t *idx, float *samples, void *stream) {
   return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, dr::PairGate(), stream);
+}
+
+// Train mode (round 5): K1 with the soft-max statistics + K2 in one call -- idx, y_sel [P,B,k], lse [P,B] and samples [P,B,k,4] =
+// matches[p, idx] * ((1 - y_sel) + y_sel), the straight-through weights of gumbel_sampler.py:36-40 applied as ransac.py:58-65 does.
+// One launch when the register kernel serves the shape (N <= 2048, N % 4 == 0, tau = 1), sampler + gather launches otherwise.
+int dr_gumbel_topk_gather_soft_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                                   int P, int B, int N, int k, int32_t *idx, float *y_sel, float *lse, float *samples, void *stream) {
+  const float *y_soft = nullptr, *ret = nullptr;
+  DR_REQUIRE(logits && matches && samples && y_sel && lse, "null pointer");
+  DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
+  DR_GUMBEL_CHECK();
+  bool gathered = false;
+  if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, y_sel, lse, nullptr, nullptr, nullptr,
+                                            (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
+                                            reinterpret_cast<float4 *>(samples), &gathered))
+    return rc;
+  if (gathered) return 0;
+  hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
+                     (const float *)y_sel, N, B * k, 4, samples);
+  return dr::check_launch("gather_fwd_kernel");
+}
+
+// ... and its backward in one launch: grad_logits [P,N] from grad_samples [P,B,k,4] (and grad_w [P,B,k] | null, the gradient of the
+// y_sel output) -- dr_gather_bwd's a_sel is formed inside dr_gumbel_topk_bwd's row prologue (no [P,B,k] tensor, no second launch).
+// The correspondences get no gradient here (dr_gather_bwd_f32 serves callers that want one).
+int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                                  int P, int B, int N, int k, const int32_t *idx, const float *lse, const float *grad_samples,
+                                  const float *grad_w, float *grad_logits, void *stream) {
+  DR_REQUIRE(logits && matches && grad_samples, "null pointer");
+  return gumbel_bwd_impl<float>(logits, nullptr, seed, seed_dev, tau, P, B, N, k, idx, lse, nullptr, grad_logits, stream,
+                                grad_samples, grad_w, matches);
 }
 
 // the same for a round > 1 of a multi-round test-mode call: pairs whose iteration counter has reached its bound are skipped

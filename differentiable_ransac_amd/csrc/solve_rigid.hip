@@ -434,6 +434,29 @@ __global__ __launch_bounds__(kU3Threads) void ransac3d_update_kernel(
   const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const T *rs = res + (size_t)p * M;
   const uint8_t *vd = valid ? valid + (size_t)p * M : nullptr;
+  // the thread's first two points are requested BEFORE the arg-min (they do not depend on the winner): the kernel is one
+  // dependent chain -- sums -> winner -> its model -> points -> mask bytes -- and this takes the longest link out of it
+  // (round 5, config 4: 9.1 -> see profiles/r5_kernel_stats_c4.md)
+  const int n_begin = blockIdx.x * pts_per_block, n_end = min(N, n_begin + pts_per_block);
+  T xa[2][6];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = n_begin + tid + u * kU3Threads;
+    if (best_mask && n < n_end) {
+      const T *x = pts + ((size_t)p * N + n) * 6;
+      if constexpr (sizeof(T) == 4) {   // 24-byte records: three 8-byte loads
+        const float2 a = *reinterpret_cast<const float2 *>(x), b = *reinterpret_cast<const float2 *>(x + 2),
+                     c = *reinterpret_cast<const float2 *>(x + 4);
+        xa[u][0] = a.x; xa[u][1] = a.y; xa[u][2] = b.x; xa[u][3] = b.y; xa[u][4] = c.x; xa[u][5] = c.y;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) xa[u][q] = x[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) xa[u][q] = T(0);
+    }
+  }
   T bv = INFINITY;
   int bi = 0x7fffffff;
   for (int m = tid; m < M; m += kU3Threads) {
@@ -469,7 +492,6 @@ __global__ __launch_bounds__(kU3Threads) void ransac3d_update_kernel(
   if (!best_mask) return;
   if (!better) {
     if (first) {   // nothing selected in the first round: the mask is defined (empty), not left uninitialised
-      const int n_begin = blockIdx.x * pts_per_block, n_end = min(N, n_begin + pts_per_block);
       for (int n = n_begin + tid; n < n_end; n += kU3Threads) best_mask[(size_t)p * N + n] = 0;
     }
     return;
@@ -477,9 +499,7 @@ __global__ __launch_bounds__(kU3Threads) void ransac3d_update_kernel(
   T m[12];
 #pragma unroll
   for (int q = 0; q < 12; ++q) m[q] = models[((size_t)p * M + bi) * 16 + q];
-  const int n_begin = blockIdx.x * pts_per_block, n_end = min(N, n_begin + pts_per_block);
-  for (int n = n_begin + tid; n < n_end; n += kU3Threads) {
-    const T *x = pts + ((size_t)p * N + n) * 6;
+  auto inlier = [&](const T *x) {
     T d2 = T(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {     // the operation order of rigid_residual_kernel: the mask equals the winner's row of K4r
@@ -487,17 +507,24 @@ __global__ __launch_bounds__(kU3Threads) void ransac3d_update_kernel(
       const T e = x[3 + i] - pred;
       d2 = fma(e, e, d2);
     }
-    best_mask[(size_t)p * N + n] = d2 < threshold;
+    return d2 < threshold;
+  };
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = n_begin + tid + u * kU3Threads;
+    if (n < n_end) best_mask[(size_t)p * N + n] = inlier(xa[u]);
   }
+  for (int n = n_begin + tid + 2 * kU3Threads; n < n_end; n += kU3Threads) best_mask[(size_t)p * N + n] = inlier(pts + ((size_t)p * N + n) * 6);
 }
 
 template <typename T>
 int ransac3d_update_launch(const T *pts, const T *models, const uint8_t *valid, const T *res, T threshold, int P, int M, int N,
                            const T *best_res_in, const T *best_model_in, T *best_res_out, T *best_model_out,
                            uint8_t *best_mask, int32_t *best_idx, hipStream_t st) {
-  // enough blocks per pair to spread a long point row over the chip, at least 2048 points each
+  // enough blocks per pair to spread a long point row over the chip: 512 points each (two per thread, both requested before the
+  // arg-min) while the launch stays below ~1024 blocks, longer slices beyond
   int nblk = 1;
-  if (best_mask) nblk = max(1, min((N + 2047) / 2048, max(1, 512 / P)));
+  if (best_mask) nblk = max(1, min((N + 511) / 512, max(1, 1024 / P)));
   const int ppb = (N + nblk - 1) / nblk;
   hipLaunchKernelGGL((ransac3d_update_kernel<T>), dim3(nblk, P), dim3(kU3Threads), 0, st, pts, models, valid, res, threshold, M,
                      N, ppb, best_res_in, best_model_in, best_res_out, best_model_out, best_mask, best_idx);

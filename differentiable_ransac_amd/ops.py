@@ -212,10 +212,11 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
 
 import os as _os
 # Round 5: the screened register kernel for rows of <= 2048 points (dr_gumbel_topk_gather_gated_f32 with a workspace) is built,
-# bit-identical (tests/test_gpu_round5.py) and SLOWER than the unscreened one at the shapes measured -- 200.8 vs 164.1 us at 128
-# pairs x 1024 rows x 2000 points, 55.2 vs 44.4 at 32 pairs, 17.8 vs 12.5 at one pair (scratch/ab_k1_screen.py): ~16 of 2000 points
-# pass, but a wave owns ONE row, so what it saves in logarithms it pays in the dependent loads of its 3-4 evaluation rounds and in
-# the 32 KiB of LDS per block its parked words cost in occupancy.  Off unless asked for (screen=True, DRANSAC_SCREEN_SHORT=1).
+# bit-identical (tests/test_gpu_round5.py) and SLOWER than the unscreened one at the shapes measured -- 199.5 vs 164.1 us at 128
+# pairs x 1024 rows x 2000 points, 57.4 vs 45.2 at 32 pairs, 25.6 vs 18.2 at one pair (scratch/ab_k1_screen.py), in both of its forms
+# (words parked in LDS + one evaluation per lane and round: 200.8; slot-wise wave masks, no parking, no dependent load: 199.5):
+# ~16 of 2000 points pass, but Philox (40 % of the row's instructions) cannot be screened and the unscreened transform is 7 vector
+# instructions per element -- a branch per element slot costs what it saves.  Off unless asked for (screen=True, DRANSAC_SCREEN_SHORT=1).
 SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 
 
@@ -326,6 +327,9 @@ def gather_bwd(matches, idx, y_sel, grad_samples, grad_w=None, want_grad_matches
     return a_sel, gm
 
 
+FUSED_SAMPLE_GATHER = _os.environ.get("DRANSAC_FUSED_SAMPLE_GATHER", "1") != "0"   # A/B and tests: off = the two-launch forward / backward of rounds 1-4
+
+
 class SampleGather(torch.autograd.Function):
     """K1+K2 fused at the autograd level: (matches [P,N,c], logits [P,N]) -> samples [P,B,k,c], weights [P,B,k].
 
@@ -338,11 +342,28 @@ class SampleGather(torch.autograd.Function):
         if logits.dtype == torch.float64 and logits.requires_grad and gumbel is None and _dev_seed(seed):
             # refused HERE, not at backward time (round-4 advice): the f64 sampler backward takes a by-value seed or explicit noise
             raise L.DransacError("SampleGather: f64 logits with a device seed have no backward (device seeds serve f32 only)")
-        r = gumbel_topk(logits, B, k, tau, gumbel, seed)
-        samples = gather(matches, r["idx"], r["y_sel"])
+        fused = (FUSED_SAMPLE_GATHER and gumbel is None and logits.dtype == torch.float32 and matches.dtype == torch.float32
+                 and matches.shape[-1] == 4)
+        if fused:
+            # round 5: sampler (soft-max statistics) + gather in ONE launch, and one launch back (dr_gumbel_topk_gather_soft_f32 /
+            # dr_gumbel_topk_gather_bwd_f32): same index sets, weights and samples as the two-launch form, bit for bit
+            matches, logits = matches.contiguous(), logits.contiguous()
+            P, N = logits.shape
+            r = dict(idx=torch.empty((P, B, k), device=logits.device, dtype=torch.int32),
+                     y_sel=torch.empty((P, B, k), device=logits.device, dtype=torch.float32),
+                     lse=torch.empty((P, B), device=logits.device, dtype=torch.float32))
+            samples = torch.empty((P, B, k, 4), device=logits.device, dtype=torch.float32)
+            ds = _dev_seed(seed)
+            L.call("dr_gumbel_topk_gather_soft_f32", ptr(logits), ptr(matches), c_uint64(0 if ds else seed & (2 ** 64 - 1)),
+                   ptr(seed if ds else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(r["idx"]), ptr(r["y_sel"]),
+                   ptr(r["lse"]), ptr(samples), stream())
+        else:
+            r = gumbel_topk(logits, B, k, tau, gumbel, seed)
+            samples = gather(matches, r["idx"], r["y_sel"])
         ctx.save_for_backward(matches, logits, r["idx"], r["y_sel"], r["lse"], gumbel if gumbel is not None else
                               torch.empty(0, device=logits.device))
         ctx.cfg = (tau, seed, gumbel is not None)
+        ctx.fused = fused
         ctx.mark_non_differentiable(r["idx"])
         return samples, r["y_sel"], r["idx"]
 
@@ -354,6 +375,14 @@ class SampleGather(torch.autograd.Function):
         if g_samples is None:
             g_samples = torch.zeros(idx.shape + (matches.shape[-1],), device=matches.device, dtype=matches.dtype)
         tau, seed, has_noise = ctx.cfg
+        if ctx.fused and not ctx.needs_input_grad[0]:
+            P, B, k = idx.shape
+            gl = torch.empty_like(logits)
+            ds = _dev_seed(seed)
+            L.call("dr_gumbel_topk_gather_bwd_f32", ptr(logits), ptr(matches), c_uint64(0 if ds else seed & (2 ** 64 - 1)),
+                   ptr(seed if ds else None), L.c_float(tau), c_int(P), c_int(B), c_int(logits.shape[1]), c_int(k), ptr(idx), ptr(lse),
+                   ptr(g_samples.contiguous()), ptr(None if g_w is None else g_w.contiguous()), ptr(gl), stream())
+            return None, gl, None, None, None, None, None
         a_sel, gm = gather_bwd(matches, idx, y_sel, g_samples, g_w, want_grad_matches=ctx.needs_input_grad[0])
         gl = gumbel_topk_bwd(logits, gumbel if has_noise else None, seed, tau, idx, lse, a_sel)
         return gm, gl, None, None, None, None, None

@@ -125,6 +125,19 @@ int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, u
                                     int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
                                     const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 
+/* Train mode (round 5): K1 WITH the soft-max statistics + K2 in one call (GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42,
+ * followed by `matches * ret` + the mask gather of ransac.py:58-65): idx, y_sel [P,B,k], lse [P,B] as dr_gumbel_topk_fwd_f32 and
+ * samples [P,B,k,4] = matches[p, idx] * ((1 - y_sel) + y_sel) as dr_gather_fwd_f32 (c = 4; 16-byte aligned buffers).  One launch
+ * when the register-resident kernel serves the shape, sampler + gather launches otherwise. */
+int dr_gumbel_topk_gather_soft_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                                   int P, int B, int N, int k, int32_t *idx, float *y_sel, float *lse, float *samples, void *stream);
+/* ... and the backward of the pair in one launch: grad_logits [P,N] from grad_samples [P,B,k,4] and grad_w [P,B,k]
+ * (gradient of the y_sel output; NULL = none) -- dr_gather_bwd_f32's a_sel is formed inside dr_gumbel_topk_bwd_f32's row
+ * prologue.  The correspondences receive no gradient from this entry. */
+int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                                  int P, int B, int N, int k, const int32_t *idx, const float *lse, const float *grad_samples,
+                                  const float *grad_w, float *grad_logits, void *stream);
+
 /* K1, index sets only, in-kernel noise, with an optional screening workspace (round 4; GumbelSoftmaxSampler.sample,
  * samplers/gumbel_sampler.py:25-42, as test mode consumes it: `points[samples != 0]`, ransac.py:65).
  * screen_ws: (N + 32) * P 32-bit words of device memory, 16-byte aligned, or NULL (then = dr_gumbel_topk_fwd_f32 with

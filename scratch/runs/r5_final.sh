@@ -54,3 +54,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/rocprof_pmc_summary.py $O/r5_pmc_fetch_write.md $O/r5_pmc_fetch_write.json --pairs 128 --points 2000 --hyps 1024 $(find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE -name "*results.db")
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+# the headline workload WITH the final refit (K7), per launch; the per-pair drop-in loop, per launch
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_refit -o refit -- python $R/scratch/refit_step.py > $O/prof_refit.log 2>&1; grep "refit=" $O/prof_refit.log
+python $R/tools/rocprof_summary.py $(find $O/prof_refit -name "*results.db" | head -1) $O/r5_kernel_stats_with_refit.md "python scratch/refit_step.py (128 pairs x 2000 points x 1024 hypotheses per step, eager; the first 110 dispatches of a kernel run WITHOUT the refit, the last 110 with it)" last 100
+rm -rf $O/prof_refit
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_dropin -o dropin -- python $R/scratch/dropin_loop.py > $O/prof_dropin.log 2>&1; grep -v amdgpu.ids $O/prof_dropin.log | tail -6
+python $R/tools/rocprof_summary.py $(find $O/prof_dropin -name "*results.db" | head -1) $O/r5_kernel_stats_dropin.md "python scratch/dropin_loop.py (32 pairs one by one through layers.RANSACLayer.forward, test mode, graph replay per pair)" last 2000
+rm -rf $O/prof_dropin
+cd $R; python scratch/dropin_host.py 2>&1 | grep -v amdgpu.ids | tail -12

@@ -316,3 +316,43 @@ def test_screened_short_row_sampler_equals_the_unscreened_kernel(dev, N, B, k):
     assert torch.equal(ia, r["idx"])
     io, _, _ = O.gumbel_topk(d["logits"][0], r["gumbel"][0].cpu(), 1.0, k)
     assert torch.equal(ia[0].cpu().long(), io)
+
+
+@pytest.mark.parametrize("N,B,k,dseed", [(2000, 256, 5, False), (2000, 100, 5, True), (512, 64, 8, False), (2500, 64, 5, False),
+                                         (1001, 32, 3, False)])
+def test_train_sampler_and_gather_in_one_launch_forward_and_backward(dev, N, B, k, dseed):
+    """dr_gumbel_topk_gather_soft_f32 / dr_gumbel_topk_gather_bwd_f32 (round 5: K1 + K2 of train mode in one launch each way)
+    against the two-launch forward / backward of rounds 1-4: identical index sets, weights and samples; gradients to the logits
+    equal to accumulation rounding -- with and without a gradient on the y_sel output, register kernel (N <= 2048, N % 4 == 0) and
+    the shapes that fall back to sampler + gather launches."""
+    from differentiable_ransac_amd import ops
+    P = 3
+    g = torch.Generator().manual_seed(N + B)
+    matches = torch.randn(P, N, 4, generator=g).to(dev)
+    logits0 = (torch.randn(P, N, generator=g) * 2).to(dev)
+    w_s = torch.randn(P, B, k, 4, generator=g).to(dev)
+    w_y = torch.randn(P, B, k, generator=g).to(dev)
+
+    def run(fused, use_y):
+        ops.FUSED_SAMPLE_GATHER = fused
+        try:
+            if dseed:
+                ds = ops.DeviceSeed(1234, dev)
+                seed = ds.next()
+            else:
+                seed = 1234
+            lg = logits0.clone().requires_grad_(True)
+            samples, y_sel, idx = ops.SampleGather.apply(matches, lg, B, k, 1.0, None, seed)
+            loss = (samples * w_s).sum() + ((y_sel * w_y).sum() if use_y else 0.0)
+            loss.backward()
+            return samples.detach(), y_sel.detach(), idx, lg.grad
+        finally:
+            ops.FUSED_SAMPLE_GATHER = True
+
+    for use_y in (False, True):
+        s1, y1, i1, g1 = run(True, use_y)
+        s0, y0, i0, g0 = run(False, use_y)
+        assert torch.equal(i1, i0) and torch.equal(y1, y0) and torch.equal(s1, s0)
+        assert torch.isfinite(g1).all()
+        scale = g0.abs().max()
+        assert (g1 - g0).abs().max() <= 2e-5 * scale, ((g1 - g0).abs().max(), scale)
