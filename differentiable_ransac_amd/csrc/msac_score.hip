@@ -831,9 +831,12 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
       for (int q = 0; q < 9; ++q) best_model[(size_t)p * 9 + q] = m[q];
       // adaptive_iteration_number, ransac.py:202-215
       const double ratio = (double)inl / (double)N;
-      const double prob = 1.0 - pow(ratio, (double)k);
+      const double rk = pow(ratio, (double)k);
+      const double prob = 1.0 - rk;
       double mi = (double)max_iterations;
-      if (!(prob >= 1.0 - eps)) mi = fmax(0.0, log10(1.0 - confidence) / log10(1.0 - pow(ratio, (double)k) + eps));
+      // (round 5, measured and dropped: the thread's correspondences requested before the arg-max, twelve scores in flight instead
+      //  of four -- 15.9 -> 15.9 / 16.1 us at 128 pairs, 10.1 at one pair; without this f64 pow / log10 tail: 15.1 / 9.2 us)
+      if (!(prob >= 1.0 - eps)) mi = fmax(0.0, log10(1.0 - confidence) / log10(1.0 - rk + eps));
       max_iters[p] = fmin((double)max_iterations, mi);
     }
   }
@@ -887,6 +890,8 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
   const bool fast16 = kFast && (N % 16 == 0) && (reinterpret_cast<uintptr_t>(masks) % 16 == 0);
   // few pairs: 16-slot halves so that the grid covers the chip (one-pair calls)
   const bool small_grid = fast16 && (long)P * ((M + kFastTile * kHalves - 1) / (kFastTile * kHalves)) < 512;   // measured: 10.6 us per pair at 3 pairs (16-slot) against 12.4 at 4 pairs (64-slot)
+  // (round 5: 8- and 4-slot halves for one to three pairs measured -- one pair 21.6 / 20.7 / 21.7 us with 16 / 8 / 4 slots, three pairs
+  //  32.5 / 33.9 / 44.3: the one-pair launch is not bound by a half's serial models; 16 stays)
   const int tile = fast16 ? (small_grid ? kSmallGridTile : kFastTile) * kHalves : (kFast ? kFastTile : kModelsPerBlock);
   const int tiles = (M + tile - 1) / tile;
   const int chunks = (N + kChunk - 1) / kChunk;   // kChunk16 == kChunk
