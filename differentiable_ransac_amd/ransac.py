@@ -555,6 +555,10 @@ class BatchedRANSAC(object):
             def have_round(r):
                 return r < rounds and (gumbels is None or noise_of(r) is not None)
 
+            # (round 5, measured and dropped -- scratch/runs/r5_gpu_w.sh, 128 pairs: the solver's waves take every register of their
+            #  SIMD, so next to the sampler the refit kernel takes 300 us instead of 110 and the solver that follows goes 146 -> 192 us
+            #  while refit blocks are still alive: step 0.943 -> 1.015 ms with the refit.  Issued right before the first scoring
+            #  launch instead: 1.063 ms; the same on a high-priority stream: 1.069 ms; up front on a high-priority stream: 1.018.)
             if self.refit and not self.fmat:
                 pre = issue_refit()
             if self.device_termination:

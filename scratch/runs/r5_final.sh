@@ -20,7 +20,8 @@ python - <<PY
 import json
 d=json.load(open("$O/bench_default.json"))
 print("default", d["value"], d["ms_per_step"], d["segments"]["ms_per_step"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["roofline"]["traffic"], d.get("two_batches_in_flight"), d.get("with_final_refit"), d["sampler_topdown"] and d["sampler_topdown"]["value"])
-for k,v in d["configs"].items(): print(k, round(v["ms_per_step"],4), v["issue"][:20], round(v["hypotheses_per_s"]/1e6,1), "eager", round(v["eager_ms_per_step"],4), "graph", v.get("graph_replay_ms_per_step"), v["launch_ms"], v.get("scoring_roofline",{}).get("frac"))
+for k,v in d["configs"].items():
+  if "ms_per_step" in v: print(k, round(v["ms_per_step"],4), v["issue"][:20], round(v["hypotheses_per_s"]/1e6,1), "eager", round(v["eager_ms_per_step"],4), "graph", v.get("graph_replay_ms_per_step"), v["launch_ms"], v.get("scoring_roofline",{}).get("frac"))
 print("fused", d["fused_driver"]["ms_per_step"], d["fused_driver"]["hypotheses_per_s"], d["fused_driver"]["scoring_roofline"])
 print("all_valid", d["k4_all_valid"])
 print("clnet", d["clnet_logits"]["ms_per_step"], d["clnet_logits"]["best_mask_agreement_with_geometric_inliers"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
