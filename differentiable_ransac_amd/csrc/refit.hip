@@ -7,6 +7,7 @@
 // cooperatively (three passes for F: centroid, mean distances, Gram), then wave 0 -- all 64 lanes redundantly, lane 0
 // stores -- runs the same device code as the per-sample solvers (Jacobi eigen-decomposition, five-point pipeline).
 // The ragged inlier sets never leave the device.
+#include <algorithm>
 #include "fivepoint_device.hpp"
 
 namespace dr {
@@ -64,11 +65,25 @@ __device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const 
   __syncthreads();
 }
 
+// Round 5: the stages after the elimination are the minimal solver's wave-cooperative ones (nister_finish_pair: Sturm isolation,
+// refinement and the polish / verification of the candidates dealt out over the wave's lanes) with ONE occupied lane pair -- the
+// one-sample form they replace (derivative-chain root search and up to ten polish + verification passes, one after the other,
+// every lane redundantly) was 86 of the kernel's 120 us.  The price: the minimal solver's register and LDS footprint (one wave per
+// SIMD, 38.9 KB) -- which costs nothing where it matters: a solver wave of the same call takes every register of its SIMD since
+// round 3, so a refit wave never shared a SIMD with one; the sampler's and the scoring kernel's light waves still fit beside it.
+#ifndef DR_REFIT_PAIR_FINISH
+#define DR_REFIT_PAIR_FINISH 1
+#endif
+#if DR_REFIT_PAIR_FINISH
+#define DR_REFIT_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
 // Register budget: 256 per lane (waves_per_eu(2, 2)) although one wave per pair does the work -- the kernel runs on a side
 // stream next to the minimal solver of the same call, whose 1024 waves hold 184 registers each and need every SIMD of
 // the chip; with 346 registers this kernel took a SIMD away from 32 of them (solver 106 -> 168 us).
+#define DR_REFIT_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <typename T>
-__global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(2, 2))) void refit_essential_kernel(const T *__restrict__ matches,
+__global__ __launch_bounds__(kRefT) DR_REFIT_OCC void refit_essential_kernel(const T *__restrict__ matches,
                                                                 const uint8_t *__restrict__ mask, int N,
                                                                 T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];   // [192] five-point workspace, then gram[81] + red[4], wave partials, Jacobi
@@ -110,9 +125,15 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   LaneWs w{lds, 1};   // every lane solves the same system: one shared slot, same-address writes of equal values
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
+#if DR_REFIT_PAIR_FINISH
+  // lane pair 0 holds the sample (lane 0 searches |z| <= 1, lane 1 |z| > 1); the other 31 pairs are empty slots of the wave's
+  // task queues, which is where the pair's brackets and candidates are worked on side by side.  The block's LDS is reused whole.
+  nister_finish_pair<T>(nb, X, ok, lds, lane, 0, lane < 2, models + (size_t)p * 90, valid + (size_t)p * 10, nullptr);
+#else
   // like the minimal solver, two lanes share the sample: even lanes search |z| <= 1 and fill the slots from 0 upwards,
   // odd lanes |z| > 1 from 9 downwards (all 32 lane pairs do the same work; lanes 0 and 1 store)
   nister_finish<T, true>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane < 2, lane & 1);
+#endif
 }
 
 template <typename T>
@@ -191,9 +212,10 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 template <typename T>
 int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, const T *weights, int P, int N, T *models,
                  uint8_t *valid, hipStream_t st) {
-  // five-point workspace (one slot), gram[81] + red[4] (padded to 96), wave partials [4][45], Jacobi V[81] + (c, s, p, q)[4]:
+  // five-point workspace (one slot), gram[81] + red[4] (padded to 96), wave partials [4][45], Jacobi V[81] + (C, S)[9]:
   // 4.6 KB -- with a 162-double slot PER LANE (83 KB) a block left room for only two of the four solver blocks a CU hosts
-  const size_t smem = sizeof(double) * (192 + 96 + 4 * 45 + 81 + 16);
+  size_t smem = sizeof(double) * (192 + 96 + 4 * 45 + 81 + 18);   // (the Jacobi's per-index rotation table: C[9], S[9])
+  if (DR_REFIT_PAIR_FINISH && !fundamental) smem = std::max(smem, sizeof(double) * (size_t)kNisterPairDoubles);   // the solver's workspace, overlaid
   static bool attr_e = false, attr_f = false;
   if (fundamental) {
     if (!attr_f) {

@@ -1229,8 +1229,39 @@ __device__ __forceinline__ int smallest_eigvec9(const double (&A)[9][9], const d
 // -- lanes 0-3 compute the four (c, s), then 36 lanes apply the column updates of A, 36 those of V, 36 the row updates.
 // ~700 cycles per round instead of ~27 k cycles per sweep of the serial register version above; on return the diagonal
 // of A holds the eigenvalues and the columns of V the eigenvectors.  `cs` = 16 doubles of LDS scratch.
+// f64 reciprocal square root / reciprocal from the hardware estimates (v_rsq_f64 / v_rcp_f64, ~26 bits) + two Newton steps: what the
+// rotation angles below need -- finite, well-scaled, positive arguments; none of the scaling / special-case code of sqrt() and "/"
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x, y * y, 1.5);
+  return y * fma(-0.5 * x, y * y, 1.5);
+}
+__device__ __forceinline__ double rcp_nr(double x) {
+  double z = __builtin_amdgcn_rcp(x);
+  z = z * fma(-x, z, 2.0);
+  return z * fma(-x, z, 2.0);
+}
+
+// Round 5: one parallel-order round (four disjoint rotations; index r rests) is TWO phases instead of four: (0) lanes 0..8 work
+// out the rotation of the pair their index belongs to -- partner i' = (2 r - i) mod 9 -- as (C[i], S[i]) with the sign of "p or q"
+// folded into S, by rsq / rcp + Newton instead of three divisions and two square roots; (1) every lane forms its elements of
+// J^T A J (45 lanes: the upper triangle, mirrored on the way out) and of V J directly from the OLD matrices:
+//   A'[i][j] = C[j] (C[i] A[i][j] + S[i] A[i'][j]) + S[j] (C[i] A[i][j'] + S[i] A[i'][j']),   V'[k][j] = C[j] V[k][j] + S[j] V[k][j'].
+// (was: rotation by four lanes, columns of A and V, rows of A -- ~160 issued instructions and four LDS round trips per round
+// against ~70 and three; the refit kernel runs next to the sampler and the solver of the same call and every instruction it
+// issues there waits for the vector ALU)
 __device__ __forceinline__ void jacobi_eig9_wave(double *A, double *V, double *cs, int lane) {
+  double *C = cs, *S = cs + 9;
   for (int i = lane; i < 81; i += 64) V[i] = (i % 10 == 0) ? 1.0 : 0.0;
+  // this lane's element of the upper triangle (lanes 0..44): entry q of the row-major upper triangle -> (ui, uj)
+  int ui = 0, uj = 0;
+  {
+    int rem = lane < 45 ? lane : 0;
+    while (rem >= 9 - ui) { rem -= 9 - ui; ++ui; }
+    uj = ui + rem;
+  }
+  const int f1 = lane + 64;                         // second V element of lanes 0..16
+  const int vk0 = lane / 9, vj0 = lane % 9, vk1 = f1 / 9, vj1 = f1 % 9;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   double prev_off = INFINITY;
@@ -1248,43 +1279,51 @@ __device__ __forceinline__ void jacobi_eig9_wave(double *A, double *V, double *c
     prev_off = off;
 #pragma unroll 1
     for (int r = 0; r < 9; ++r) {
-      if (lane < 4) {
-        const int a = (r + lane + 1) % 9, b = (r + 9 - (lane + 1)) % 9;
-        const int p = min(a, b), q = max(a, b);
-        const double apq = A[p * 9 + q];
-        double c = 1.0, sn = 0.0;
-        if (fabs(apq) > 1e-300) {
-          const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
-          const double t = dsign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          c = 1.0 / sqrt(t * t + 1.0);
-          sn = t * c;
+      if (lane < 9) {
+        const int i = lane, ip = (2 * r - i + 18) % 9;
+        double c = 1.0, ss = 0.0;
+        if (ip != i) {
+          const int p = min(i, ip), q = max(i, ip);
+          const double apq = A[p * 9 + q];
+          if (fabs(apq) > 1e-300) {
+            const double a = A[q * 9 + q] - A[p * 9 + p], b2 = 2.0 * apq;
+            const double r2 = fma(a, a, b2 * b2);
+            const double rr = r2 * rsqrt_nr(r2);                       // sqrt(a^2 + b^2)
+            const double t = (a >= 0 ? b2 : -b2) * rcp_nr(fabs(a) + rr);   // tan(phi) = sgn(theta) / (|theta| + sqrt(theta^2 + 1))
+            c = rsqrt_nr(fma(t, t, 1.0));
+            const double sn = t * c;
+            ss = (i < ip) ? -sn : sn;                                  // column p: c col_p - s col_q ; column q: s col_p + c col_q
+          }
         }
-        cs[4 * lane] = c; cs[4 * lane + 1] = sn;
-        cs[4 * lane + 2] = (double)p; cs[4 * lane + 3] = (double)q;
+        C[i] = c;
+        S[i] = ss;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (lane < 36) {            // columns p, q of A and of V: element row k of rotation pr
-        const int pr = lane / 9, k = lane % 9;
-        const double c = cs[4 * pr], sn = cs[4 * pr + 1];
-        const int p = (int)cs[4 * pr + 2], q = (int)cs[4 * pr + 3];
-        const double akp = A[k * 9 + p], akq = A[k * 9 + q];
-        A[k * 9 + p] = c * akp - sn * akq;
-        A[k * 9 + q] = sn * akp + c * akq;
-        const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
-        V[k * 9 + p] = c * vkp - sn * vkq;
-        V[k * 9 + q] = sn * vkp + c * vkq;
+      double na = 0.0, nv0 = 0.0, nv1 = 0.0;
+      if (lane < 45) {
+        const int i = ui, j = uj, ip = (2 * r - i + 18) % 9, jp = (2 * r - j + 18) % 9;
+        const double ci = C[i], si = S[i], cj = C[j], sj = S[j];
+        const double rij = fma(si, A[ip * 9 + j], ci * A[i * 9 + j]);
+        const double rijp = fma(si, A[ip * 9 + jp], ci * A[i * 9 + jp]);
+        na = fma(sj, rijp, cj * rij);
+      }
+      {
+        const int jp0 = (2 * r - vj0 + 18) % 9;
+        nv0 = fma(S[vj0], V[vk0 * 9 + jp0], C[vj0] * V[vk0 * 9 + vj0]);
+        if (f1 < 81) {
+          const int jp1 = (2 * r - vj1 + 18) % 9;
+          nv1 = fma(S[vj1], V[vk1 * 9 + jp1], C[vj1] * V[vk1 * 9 + vj1]);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (lane < 36) {            // rows p, q of A
-        const int pr = lane / 9, k = lane % 9;
-        const double c = cs[4 * pr], sn = cs[4 * pr + 1];
-        const int p = (int)cs[4 * pr + 2], q = (int)cs[4 * pr + 3];
-        const double apk = A[p * 9 + k], aqk = A[q * 9 + k];
-        A[p * 9 + k] = c * apk - sn * aqk;
-        A[q * 9 + k] = sn * apk + c * aqk;
+      if (lane < 45) {
+        A[ui * 9 + uj] = na;
+        A[uj * 9 + ui] = na;
       }
+      V[lane] = nv0;
+      if (f1 < 81) V[f1] = nv1;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }

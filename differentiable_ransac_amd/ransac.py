@@ -421,6 +421,7 @@ class BatchedRANSAC(object):
         self.eps = eps
         self.fmat = solver in ("f8", "f7")
         self._side = None
+        self._gap = None         # scratch word of the one-launch dispatch gap in front of the sampler (see __call__)
         self._dev_seed = None
         self._seed_queue = []
 
@@ -526,13 +527,14 @@ class BatchedRANSAC(object):
         with torch.no_grad():
             # threshold normalisation (ransac.py:49-53) + per-pair state in one launch
             use_K = K1 is not None and not self.fmat
-            st, thr = ops.ransac_init(P, N, self.max_iterations, self.threshold, K1 if use_K else None,
-                                      K2 if use_K else None, dev, dt)
             all_masks = None
             matches = matches.contiguous()
             # The essential-matrix refit candidate (Nister on ALL points, ransac.py:157-165) depends on the matches only:
-            # it is issued up front on a side stream (32 latency-bound blocks, register budget chosen so that the minimal
-            # solver's waves still find room on the same SIMDs) and joins before the final scoring.
+            # it is issued on a side stream and joins before the final scoring -- and it is issued FIRST, before the state set-up
+            # (round 5): a refit block wants a whole SIMD's registers and 38.9 KB of LDS on its CU, and once the sampler's 32 768
+            # light workgroups are in the queue it does not get them until the sampler's grid runs dry (measured at 128 pairs:
+            # launched 6 us after the sampler it ran 15 -> 241 us for 52 us of work, and the solver behind it started 56 us late
+            # on the SIMDs it held).
             pre = None
 
             def issue_refit():
@@ -544,6 +546,22 @@ class BatchedRANSAC(object):
                     if not torch.cuda.is_current_stream_capturing():
                         matches.record_stream(self._side)
                 return out_
+            if self.refit and not self.fmat:
+                pre = issue_refit()
+            st, thr = ops.ransac_init(P, N, self.max_iterations, self.threshold, K1 if use_K else None,
+                                      K2 if use_K else None, dev, dt)
+            if pre is not None and P * self.B >= 65536:
+                # Dispatch order (round 5): a refit block wants a whole SIMD's registers and 38.9 KB of LDS on its CU; once the
+                # sampler's 32 768 light workgroups are in the queue it does not get them until the sampler's grid runs dry.
+                # The refit waits for this stream's earlier work through an event and lost that race by half a microsecond
+                # (rocprofv3, 128 pairs: sampler dispatched at 5.4 us, refit at 5.9 -- it then ran 232 us for 57 us of work and the
+                # solver behind it started 56 us late on the SIMDs it still held: step 0.947 -> 1.018 ms with the refit).  One
+                # tiny launch in front of the sampler lets the refit's 128 blocks in first: refit 57 us, sampler 178 -> 191 us,
+                # solver 146 us, step 0.996 ms.  (Set-up AND refit on the side stream with this stream waiting for the set-up:
+                # refit first as well, but 57 us between two steps instead of 17: 1.043 ms.)
+                if self._gap is None:
+                    self._gap = ops.DeviceSeed(0, dev)
+                self._gap.next()
             # Rounds are pipelined: the hypotheses of round r+1 (sampler + solver, latency-bound, independent of round r's
             # outcome) are issued on a second stream before round r is scored, so they run under K4/K6 and under the
             # host's "does any pair continue?" read-back.  If round r ends the loop they are simply dropped.
@@ -555,12 +573,8 @@ class BatchedRANSAC(object):
             def have_round(r):
                 return r < rounds and (gumbels is None or noise_of(r) is not None)
 
-            # (round 5, measured and dropped -- scratch/runs/r5_gpu_w.sh, 128 pairs: the solver's waves take every register of their
-            #  SIMD, so next to the sampler the refit kernel takes 300 us instead of 110 and the solver that follows goes 146 -> 192 us
-            #  while refit blocks are still alive: step 0.943 -> 1.015 ms with the refit.  Issued right before the first scoring
-            #  launch instead: 1.063 ms; the same on a high-priority stream: 1.069 ms; up front on a high-priority stream: 1.018.)
-            if self.refit and not self.fmat:
-                pre = issue_refit()
+            # (round 5, measured and dropped -- scratch/runs/r5_gpu_w.sh, 128 pairs: the refit issued right before the first
+            #  scoring launch instead of up front: step with refit 1.015 -> 1.063 ms; the same on a high-priority stream: 1.069 ms.)
             if self.device_termination:
                 if rounds > 16:
                     raise ValueError("device_termination issues every round: max_iterations / ransac_batch_size must be <= 16")
