@@ -13,6 +13,7 @@
 namespace dr {
 
 constexpr int kRefT = 256;
+constexpr int kRefitPairFinishMinPairs = 16;   // launches of fewer pairs keep the light final stage (see refit_essential_kernel)
 
 __device__ __forceinline__ double block_sum(double v, double *red /* [4] */) {
   v = wave_sum(v);
@@ -71,19 +72,12 @@ __device__ __forceinline__ void gram_accumulate(const T *__restrict__ mt, const 
 // every lane redundantly) was 86 of the kernel's 120 us.  The price: the minimal solver's register and LDS footprint (one wave per
 // SIMD, 38.9 KB) -- which costs nothing where it matters: a solver wave of the same call takes every register of its SIMD since
 // round 3, so a refit wave never shared a SIMD with one; the sampler's and the scoring kernel's light waves still fit beside it.
-#ifndef DR_REFIT_PAIR_FINISH
-#define DR_REFIT_PAIR_FINISH 1
-#endif
-#if DR_REFIT_PAIR_FINISH
-#define DR_REFIT_OCC __attribute__((amdgpu_waves_per_eu(1, 1)))
-#else
-// Register budget: 256 per lane (waves_per_eu(2, 2)) although one wave per pair does the work -- the kernel runs on a side
-// stream next to the minimal solver of the same call, whose 1024 waves hold 184 registers each and need every SIMD of
-// the chip; with 346 registers this kernel took a SIMD away from 32 of them (solver 106 -> 168 us).
-#define DR_REFIT_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
-template <typename T>
-__global__ __launch_bounds__(kRefT) DR_REFIT_OCC void refit_essential_kernel(const T *__restrict__ matches,
+// kPairFinish is chosen per launch: calls of a few pairs (the drop-in's one pair per call, where the refit hides behind the whole
+// chain anyway) keep the light one-sample form -- 256 registers, 4.6 KB of LDS; same-box A/B of the per-pair loop: 0.208-0.211 ms
+// per pair with it, 0.214-0.217 with the heavy form -- batched calls take the fast one.
+// (register budget of the light form: 256 per lane, waves_per_eu(2, 2), although one wave per pair does the work)
+template <typename T, bool kPairFinish>
+__global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(kPairFinish ? 1 : 2, kPairFinish ? 1 : 2))) void refit_essential_kernel(const T *__restrict__ matches,
                                                                 const uint8_t *__restrict__ mask, int N,
                                                                 T *__restrict__ models, uint8_t *__restrict__ valid) {
   extern __shared__ __align__(16) double lds[];   // [192] five-point workspace, then gram[81] + red[4], wave partials, Jacobi
@@ -125,15 +119,15 @@ __global__ __launch_bounds__(kRefT) DR_REFIT_OCC void refit_essential_kernel(con
   LaneWs w{lds, 1};   // every lane solves the same system: one shared slot, same-address writes of equal values
   double X[6][10];
   const bool ok = constraints_reduce<NisterOrder, 4>(e, w, 1.0, X);
-#if DR_REFIT_PAIR_FINISH
-  // lane pair 0 holds the sample (lane 0 searches |z| <= 1, lane 1 |z| > 1); the other 31 pairs are empty slots of the wave's
-  // task queues, which is where the pair's brackets and candidates are worked on side by side.  The block's LDS is reused whole.
-  nister_finish_pair<T>(nb, X, ok, lds, lane, 0, lane < 2, models + (size_t)p * 90, valid + (size_t)p * 10, nullptr);
-#else
-  // like the minimal solver, two lanes share the sample: even lanes search |z| <= 1 and fill the slots from 0 upwards,
-  // odd lanes |z| > 1 from 9 downwards (all 32 lane pairs do the same work; lanes 0 and 1 store)
-  nister_finish<T, true>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane < 2, lane & 1);
-#endif
+  if constexpr (kPairFinish) {
+    // lane pair 0 holds the sample (lane 0 searches |z| <= 1, lane 1 |z| > 1); the other 31 pairs are empty slots of the wave's
+    // task queues, which is where the pair's brackets and candidates are worked on side by side.  The block's LDS is reused whole.
+    nister_finish_pair<T>(nb, X, ok, lds, lane, 0, lane < 2, models + (size_t)p * 90, valid + (size_t)p * 10, nullptr);
+  } else {
+    // like the minimal solver, two lanes share the sample: even lanes search |z| <= 1 and fill the slots from 0 upwards,
+    // odd lanes |z| > 1 from 9 downwards (all 32 lane pairs do the same work; lanes 0 and 1 store)
+    nister_finish<T, true>(nb, X, ok, models + (size_t)p * 90, valid + (size_t)p * 10, lane < 2, lane & 1);
+  }
 }
 
 template <typename T>
@@ -214,9 +208,8 @@ int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, const 
                  uint8_t *valid, hipStream_t st) {
   // five-point workspace (one slot), gram[81] + red[4] (padded to 96), wave partials [4][45], Jacobi V[81] + (C, S)[9]:
   // 4.6 KB -- with a 162-double slot PER LANE (83 KB) a block left room for only two of the four solver blocks a CU hosts
-  size_t smem = sizeof(double) * (192 + 96 + 4 * 45 + 81 + 18);   // (the Jacobi's per-index rotation table: C[9], S[9])
-  if (DR_REFIT_PAIR_FINISH && !fundamental) smem = std::max(smem, sizeof(double) * (size_t)kNisterPairDoubles);   // the solver's workspace, overlaid
-  static bool attr_e = false, attr_f = false;
+  const size_t smem = sizeof(double) * (192 + 96 + 4 * 45 + 81 + 18);   // (the Jacobi's per-index rotation table: C[9], S[9])
+  static bool attr_e = false, attr_p = false, attr_f = false;
   if (fundamental) {
     if (!attr_f) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_fundamental_kernel<T>),
@@ -224,13 +217,21 @@ int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, const 
       attr_f = true;
     }
     hipLaunchKernelGGL((refit_fundamental_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, weights, N, models, valid);
+  } else if (P >= kRefitPairFinishMinPairs) {
+    const size_t smem_p = std::max(smem, sizeof(double) * (size_t)kNisterPairDoubles);   // the solver's workspace, overlaid
+    if (!attr_p) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_essential_kernel<T, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p);
+      attr_p = true;
+    }
+    hipLaunchKernelGGL((refit_essential_kernel<T, true>), dim3(P), dim3(kRefT), smem_p, st, matches, mask, N, models, valid);
   } else {
     if (!attr_e) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_essential_kernel<T>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_essential_kernel<T, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_e = true;
     }
-    hipLaunchKernelGGL((refit_essential_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, N, models, valid);
+    hipLaunchKernelGGL((refit_essential_kernel<T, false>), dim3(P), dim3(kRefT), smem, st, matches, mask, N, models, valid);
   }
   return check_launch("refit_kernel");
 }

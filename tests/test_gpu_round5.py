@@ -356,3 +356,40 @@ def test_train_sampler_and_gather_in_one_launch_forward_and_backward(dev, N, B, 
         assert torch.isfinite(g1).all()
         scale = g0.abs().max()
         assert (g1 - g0).abs().max() <= 2e-5 * scale, ((g1 - g0).abs().max(), scale)
+
+
+def test_batched_essential_refit_with_the_wave_cooperative_final_stage(dev):
+    """K7 at >= 16 pairs per launch: the refit kernel's stages after the elimination are the minimal solver's wave-cooperative ones
+    (round 5; launches of fewer pairs keep the one-sample form tested in test_gpu_solvers.py).  Against the reference's own
+    non-minimal golden vector (replicated), the f64 oracle on synthetic pairs, and the small-launch form on the same pairs."""
+    from differentiable_ransac_amd import ops, synth
+    from tests.conftest import load_golden
+    g = load_golden("nister_nonminimal")
+    for dt, tol in ((torch.float64, 1e-6), (torch.float32, TOL)):
+        m = g["matches"].to(dt).unsqueeze(0).repeat(16, 1, 1).to(dev)
+        E, valid = ops.refit_essential(m)
+        for p in (0, 7, 15):
+            d = O.match_solution_sets(E[p].cpu().double(), valid[p].cpu(), g["models"], torch.ones(10, dtype=torch.bool))
+            assert d.numel() >= 1 and d.max() < tol
+    P, N = 20, 2000
+    data = synth.batch_two_view(P, N, seed0=900)
+    E, valid = ops.refit_essential(data["matches"].to(dev))
+    for p in range(P):
+        Eo, ok, real = O.nister_5pt(data["matches"][p].double().unsqueeze(0))
+        fw = O.match_solution_sets(E[p].cpu().double(), valid[p].cpu(), Eo[0], real[0])
+        bw = O.match_solution_sets(Eo[0], real[0], E[p].cpu().double(), valid[p].cpu())
+        assert fw.numel() == bw.numel() and (fw.numel() == 0 or max(fw.max(), bw.max()) < TOL), p
+    # the same pairs through launches of five (the light form): same solution sets
+    for p0 in (0, 5):
+        Es, vs = ops.refit_essential(data["matches"][p0:p0 + 5].to(dev))
+        for q in range(5):
+            assert int(vs[q].sum()) == int(valid[p0 + q].sum())
+            fw = O.match_solution_sets(Es[q].cpu().double(), vs[q].cpu(), E[p0 + q].cpu().double(), valid[p0 + q].cpu())
+            assert fw.numel() == 0 or fw.max() < TOL
+    # masked, ragged over the pairs
+    mask = torch.rand(P, N, generator=torch.Generator().manual_seed(2)) > 0.5
+    Em, vm = ops.refit_essential(data["matches"].to(dev), mask.to(dev))
+    for p in (0, 11, 19):
+        Esol, vsol = ops.solve_nister5(data["matches"][p][mask[p]].unsqueeze(0).to(dev))
+        fw = O.match_solution_sets(Em[p].cpu().double(), vm[p].cpu(), Esol[0].cpu().double(), vsol[0].cpu())
+        assert int(vm[p].sum()) == int(vsol[0].sum()) and (fw.numel() == 0 or fw.max() < TOL)
