@@ -559,8 +559,8 @@ class BatchedRANSAC(object):
                 # tiny launch in front of the sampler lets the refit's 128 blocks in first: refit 57 us, sampler 178 -> 191 us,
                 # solver 146 us, step 0.996 ms.  (Set-up AND refit on the side stream with this stream waiting for the set-up:
                 # refit first as well, but 57 us between two steps instead of 17: 1.043 ms.)
-                if self._gap is None:
-                    self._gap = ops.DeviceSeed(0, dev)
+                if self._gap is None or self._gap.state.device != matches.device:
+                    self._gap = ops.DeviceSeed(0, matches.device)
                 self._gap.next()
             # Rounds are pipelined: the hypotheses of round r+1 (sampler + solver, latency-bound, independent of round r's
             # outcome) are issued on a second stream before round r is scored, so they run under K4/K6 and under the
