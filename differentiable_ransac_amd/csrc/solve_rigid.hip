@@ -237,6 +237,16 @@ __global__ __launch_bounds__(kRThreads) void rigid_residual_kernel(const T *__re
 #ifndef DR_K4R_16
 #define DR_K4R_16 1
 #endif
+#ifndef DR_K4R_PTS
+#define DR_K4R_PTS 8    // points per lane of the packed kernel: 8 (round 5) or 16 (rounds 2-4).  Config 4, same box, in the step
+                        // (scratch/runs/r5_gpu_ab.sh, r5_gpu_ac.sh): launch 46.1 -> 43.4 us under rocprofv3 (0.281 -> 0.298 of HBM),
+                        // step 0.1335 -> 0.1297 ms; 76 registers = six waves per SIMD instead of three; an occupancy hint of
+                        // seven waves: 0.1323, of eight (spills): 0.153
+#endif
+#ifndef DR_K4R_GROUP8
+#define DR_K4R_GROUP8 1  // models per scalar fetch of the 8-point form (1: 0.1296, 2: 0.1300-0.1305, 3: 0.1305, 4: 0.1306, 8: 0.1402 ms):
+                         // at six waves per SIMD the scalar-cache round trip of a model hides behind the other waves
+#endif
 #ifndef DR_K4R_TILE
 #define DR_K4R_TILE 0    // > 0: fixed models per block (A/B builds); 0: chosen per launch so that the grid is whole rounds of blocks
 #endif
@@ -254,10 +264,14 @@ __device__ __forceinline__ v2r rsplat(float a) { return (v2r){a, a}; }
 #else
 #define DR_K4R_OCC
 #endif
-__global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_f32_16(const float *__restrict__ pts, const float *__restrict__ models,
+// kPts (round 5): 16 points per lane (96 point registers, 138 in all: three waves per SIMD) or 8 (48 / ~90: five waves per SIMD, an
+// 8-byte mask store per lane and model instead of a 16-byte one, the per-model reduction shared by half as many points)
+template <int kPts>
+__global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_f32_pk(const float *__restrict__ pts, const float *__restrict__ models,
                                                                            float threshold, int M, int N, float *__restrict__ res_sum,
                                                                            uint8_t *__restrict__ masks, int chunks_per_block,
                                                                            int use_atomic, int tile) {
+  constexpr int kChunk = kR16Threads * kPts;
   __shared__ float part[kR16Threads / 64][kR16MaxTile];
   const int p = blockIdx.z, m0 = blockIdx.x * tile;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -269,24 +283,24 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
   const v2r thr2 = rsplat(threshold);
   const int c_begin = blockIdx.y * chunks_per_block;
   for (int c = c_begin; c < c_begin + chunks_per_block; ++c) {
-    if (c * kR16Chunk >= N) break;
-    const int n0 = c * kR16Chunk + tid * kR16Pts;
-    const bool have = n0 < N;   // N % 16 == 0: a lane's points are all inside or all outside
+    if (c * kChunk >= N) break;
+    const int n0 = c * kChunk + tid * kPts;
+    const bool have = n0 < N;   // N % kPts == 0: a lane's points are all inside or all outside
     // points in PAIRS (component 0 / 1 = points 2 j / 2 j + 1 of the lane): the loop below is written in packed form, so the
     // compiler has no operand pairs to assemble per model (its own vectoriser spent 178 v_mov per model doing that)
-    v2r xp[kR16Pts / 2][6];
+    v2r xp[kPts / 2][6];
     {
-      float x[kR16Pts * 6];   // 16 points x 6 floats = 24 float4 per lane, contiguous
+      float x[kPts * 6];   // kPts points x 6 floats = 24 / 12 float4 per lane, contiguous
       // lanes past the end read the row's first points instead (unconditional loads issue back to back; a predicated load
       // each waited for the one before: 24 memory round trips per chunk) -- their results are never stored or summed
       const float4 *src = reinterpret_cast<const float4 *>(pt + (size_t)(have ? n0 : 0) * 6);
 #pragma unroll
-      for (int v = 0; v < 24; ++v) {
+      for (int v = 0; v < kPts * 6 / 4; ++v) {
         const float4 w = src[v];
         x[4 * v] = w.x; x[4 * v + 1] = w.y; x[4 * v + 2] = w.z; x[4 * v + 3] = w.w;
       }
 #pragma unroll
-      for (int j = 0; j < kR16Pts / 2; ++j)
+      for (int j = 0; j < kPts / 2; ++j)
 #pragma unroll
         for (int d = 0; d < 6; ++d) xp[j][d] = (v2r){x[12 * j + d], x[12 * j + 6 + d]};
     }
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
     // models in groups of kGroup: the 12 coefficients of all of them are requested from the scalar cache together (one
     // round trip per group instead of one per model: the compiler puts `s_waitcnt lgkmcnt(0)` right behind any s_load whose
     // destination shares an SGPR pair with a live splat operand, so a hand-written "prefetch the next model" is not one)
-    constexpr int kGroup = DR_K4R_GROUP;
+    constexpr int kGroup = kPts == 8 ? DR_K4R_GROUP8 : DR_K4R_GROUP;
 #pragma unroll 1
     for (int mg = 0; mg < mcount; mg += kGroup) {
       float mm[kGroup][12];
@@ -310,9 +324,9 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
         const bool live = ml < mcount;    // wave-uniform; a tail slot re-evaluates the tile's last model and drops the result
         const float (&m)[12] = mm[u];
         v2r acc2 = (v2r){0.f, 0.f};
-        uint32_t wq[4];
+        uint32_t wq[kPts / 4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < kPts / 4; ++g) {
           uint32_t sb[4];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -342,7 +356,10 @@ __global__ __launch_bounds__(kR16Threads) DR_K4R_OCC void rigid_residual_kernel_
           wq[g] = ((lo2 | hi2) >> 5) & 0x01010101u;   // top byte = sign, exponent bits 7..1: exponent bit 6 sits at bit 5
         }
         float acc = acc2[0] + acc2[1];
-        if (have && live) *reinterpret_cast<uint4 *>(mrow + (size_t)ml * N + (uint32_t)n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+        if (have && live) {
+          if constexpr (kPts == 16) *reinterpret_cast<uint4 *>(mrow + (size_t)ml * N + (uint32_t)n0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+          else *reinterpret_cast<uint2 *>(mrow + (size_t)ml * N + (uint32_t)n0) = make_uint2(wq[0], wq[1]);
+        }
         acc = wave_sum_lane63(have ? acc : 0.f);
         if (lane == 63 && live) atomicAdd(&part[wv][ml], acc);   // ds_add_f32, no return: the wave does not wait for its own LDS round trip (the plain += was a ds_read + s_waitcnt + ds_write per model)
       }
@@ -365,18 +382,21 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
   if constexpr (sizeof(T) == 4) {
     // (thresholds below 1e-12 would put `thr - d2` near the bit-6 exponent test's blind spot: general kernel)
     if (DR_K4R_16 && masks && N % 16 == 0 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0 && threshold > T(1e-12)) {
-      // One block = (pair, model tile, 2048-point chunk); every block of a launch takes the same time (tile x chunk
-      // evaluations), so the launch takes ceil(blocks / resident blocks) block times: 3 200 blocks on 1 536 resident ones
-      // (138 registers: three waves per SIMD, six 2-wave blocks per CU) are THREE rounds for 2.08 rounds of work.  The tile is
-      // therefore chosen per launch: the largest grid that is a whole number of rounds -- at C4 (one pair, 25 chunks) 61
-      // tiles of 34 models = 1 525 blocks, one round.
+      // One block = (pair, model tile, point chunk); every block of a launch takes the same time (tile x chunk evaluations), so
+      // the launch takes ceil(blocks / resident blocks) block times: 3 200 blocks on 1 536 resident ones (138 registers: three
+      // waves per SIMD, six 2-wave blocks per CU) are THREE rounds for 2.08 rounds of work.  The tile is therefore chosen per
+      // launch: the largest grid that is a whole number of rounds -- at C4 (one pair, 25 chunks of 2048 points) 61 tiles of 34
+      // models = 1 525 blocks, one round.
+      constexpr int kPts = DR_K4R_PTS;
+      constexpr int kChunkL = kR16Threads * kPts;
       static int resident = 0;
       if (!resident) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident = (DR_K4R_WAVES == 4 ? 8 : 6) * max(cus, 1);
+        // resident 2-wave blocks per CU: 16 points = 138 registers = three waves per SIMD; 8 points = 76 registers = six
+        resident = (DR_K4R_WAVES > 0 ? 2 * DR_K4R_WAVES : (kPts == 8 ? 12 : 6)) * max(cus, 1);
       }
-      const int chunks = (N + kR16Chunk - 1) / kR16Chunk;
+      const int chunks = (N + kChunkL - 1) / kChunkL;
       int ny = chunks;                      // one chunk per block whenever the row is longer than a chunk (atomics across them)
       int tile = DR_K4R_TILE;
       if (tile <= 0) {
@@ -391,9 +411,9 @@ int rigid_residual_launch(const T *pts, const T *models, T threshold, int P, int
       const int cpb = 1;
       const int use_atomic = ny > 1 || sums_zeroed;   // (pre-zeroed sums are added to, never stored over)
       if (use_atomic && !sums_zeroed && hipMemsetAsync(res_sum, 0, sizeof(T) * (size_t)P * M, st) != hipSuccess) return check_launch("memset");
-      hipLaunchKernelGGL(rigid_residual_kernel_f32_16, dim3(tiles, ny, P), dim3(kR16Threads), 0, st, (const float *)pts,
+      hipLaunchKernelGGL((rigid_residual_kernel_f32_pk<kPts>), dim3(tiles, ny, P), dim3(kR16Threads), 0, st, (const float *)pts,
                          (const float *)models, (float)threshold, M, N, (float *)res_sum, masks, cpb, use_atomic, tile);
-      return check_launch("rigid_residual_kernel_f32_16");
+      return check_launch("rigid_residual_kernel_f32_pk");
     }
   }
   const int tiles = (M + kRModels - 1) / kRModels;
