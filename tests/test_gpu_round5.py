@@ -393,3 +393,28 @@ def test_batched_essential_refit_with_the_wave_cooperative_final_stage(dev):
         Esol, vsol = ops.solve_nister5(data["matches"][p][mask[p]].unsqueeze(0).to(dev))
         fw = O.match_solution_sets(Em[p].cpu().double(), vm[p].cpu(), Esol[0].cpu().double(), vsol[0].cpu())
         assert int(vm[p].sum()) == int(vsol[0].sum()) and (fw.numel() == 0 or fw.max() < TOL)
+
+
+def test_graph_replay_of_a_chip_filling_call_with_the_final_refit(dev):
+    """64 pairs x 1024 hypotheses with K7: the refit is issued first on its side stream, one tiny launch in front of the sampler lets
+    its blocks onto the chip before the sampler's 16 384 workgroups (round 5), the >= 16-pair form of the refit kernel runs -- the
+    whole call captured in a HIP graph and replayed equals the eager driver with the same seeds, call after call"""
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.graphs import GraphedStep
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    P, N, B = 64, 2000, 1024
+    d = synth.batch_two_view(P, N, seed0=60)
+    m, lg, K1, K2 = (d[k].to(dev) for k in ("matches", "logits", "K1", "K2"))
+    kw = dict(ransac_batch_size=B, train=False, threshold=0.75, max_iterations=B, seed=5, keep_masks=False, refit=True)
+    eager = BatchedRANSAC("nister", **kw)
+    graphed = BatchedRANSAC("nister", **kw).device_seeds(dev)
+    warm = 3
+    for _ in range(warm):
+        eager(m, lg, K1, K2)
+    step = GraphedStep(lambda: graphed(m, lg, K1, K2), warmup=warm)
+    for r in range(3):
+        want = eager(m, lg, K1, K2)
+        got = step()
+        for key in ("model", "mask", "score", "inliers"):
+            assert torch.equal(want[key], got[key]), (key, r)
+    assert eager._gap is not None and graphed._gap is not None      # the dispatch gap was taken (P x B >= 65 536)
