@@ -110,7 +110,7 @@ def test_graph_replay_of_the_3d_driver_equals_the_eager_driver(dev):
     from differentiable_ransac_amd import synth
     from differentiable_ransac_amd.graphs import GraphedStep
     from differentiable_ransac_amd.ransac import BatchedRANSAC3D
-    P, N, B = 2, 4096, 128                     # 4096 points: the one-pass sampler kernel, 16-point residual kernel
+    P, N, B = 2, 4096, 128                     # 4096 points: the one-pass sampler kernel, the packed residual kernel
     items = [synth.rigid_pair(p, N) for p in range(P)]
     m = torch.stack([i["matches"] for i in items]).to(dev)
     lg = torch.stack([i["logits"] for i in items]).to(dev)
@@ -125,4 +125,10 @@ def test_graph_replay_of_the_3d_driver_equals_the_eager_driver(dev):
         want, got = eager(m, lg), step()
         for key in want:
             if torch.is_tensor(want[key]):
-                assert torch.equal(want[key], got[key]), (key, r)
+                if key == "residual":
+                    # the residual sum of a model is accumulated over the point chunks with float atomics: four chunks of 1024
+                    # points here (round 5: eight points per lane; two chunks of 2048 -- a commutative pair -- before), so the last
+                    # bit depends on the order in which the blocks arrive
+                    assert torch.allclose(want[key], got[key], rtol=1e-6, atol=0.0), (key, r)
+                else:
+                    assert torch.equal(want[key], got[key]), (key, r)
