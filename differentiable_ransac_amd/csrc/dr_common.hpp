@@ -36,6 +36,14 @@ struct PairGate {
   const int32_t *iters = nullptr;
   const double *max_iters = nullptr;
   __device__ __forceinline__ bool closed(int p) const { return iters && (double)iters[p] >= max_iters[p]; }
+  // every pair of [first, last] closed (a block of samples may span more than two pairs when ransac_batch_size is below the
+  // samples per block: the pairs in the middle must be closed too)
+  __device__ __forceinline__ bool closed_range(int first, int last) const {
+    if (!iters) return false;
+    for (int p = first; p <= last; ++p)
+      if (!closed(p)) return false;
+    return true;
+  }
 };
 
 // ---- wave64 reductions (ds_swizzle/DPP chosen by the compiler from the xor pattern) ----

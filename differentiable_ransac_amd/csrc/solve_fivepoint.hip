@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models,
     uint8_t *__restrict__ valid, double *__restrict__ models64, int spb, PairGate gate, int per_pair) {
   // gate (rounds > 1 of a multi-round call): a block all of whose samples belong to terminated pairs returns at once
-  if (gate.iters && gate.closed((blockIdx.x * spb) / per_pair) && gate.closed((min(blockIdx.x * spb + spb, Bt) - 1) / per_pair)) return;
+  if (gate.closed_range((blockIdx.x * spb) / per_pair, (min(blockIdx.x * spb + spb, Bt) - 1) / per_pair)) return;
   // spb = samples per block: 32 when the grid fills the chip.  Calls with few samples (one pair = 1024 samples = 32 blocks on
   // 1024 SIMDs) run 16 / 8 / 4 samples per block instead: the lane pairs beyond spb hold no sample, queue no bracket and no
   // candidate, so the wave's task rounds (refine, polish, verification) shrink with spb while the per-lane stages cost what they
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES,
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_K3_WAVES, DR_K3_WAVES))) void stewenius5_pair_kernel(
     const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, int spb, PairGate gate, int per_pair) {
-  if (gate.iters && gate.closed((blockIdx.x * spb) / per_pair) && gate.closed((min(blockIdx.x * spb + spb, Bt) - 1) / per_pair)) return;
+  if (gate.closed_range((blockIdx.x * spb) / per_pair, (min(blockIdx.x * spb + spb, Bt) - 1) / per_pair)) return;
   // spb = samples per block (32, or 16 / 8 / 4 on small grids): see nister5_pair_kernel
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
@@ -169,7 +169,7 @@ template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void nister5_fb_kernel(
     const T *__restrict__ samples, const T *__restrict__ weights, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid,
     double *__restrict__ models64, PairGate gate, int per_pair) {
-  if (gate.iters && gate.closed((blockIdx.x * 64) / per_pair) && gate.closed((min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
+  if (gate.closed_range((blockIdx.x * 64) / per_pair, (min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
 #if DR_K3_FB_REBASIS
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <typename T>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stewenius5_fb_kernel(
     const T *__restrict__ samples, int Bt, T *__restrict__ models, uint8_t *__restrict__ valid, PairGate gate, int per_pair) {
-  if (gate.iters && gate.closed((blockIdx.x * 64) / per_pair) && gate.closed((min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
+  if (gate.closed_range((blockIdx.x * 64) / per_pair, (min(blockIdx.x * 64 + 64, Bt) - 1) / per_pair)) return;
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   constexpr int kGOff = SturmWs<10>::kDoubles > FinishQueue::kDoubles ? SturmWs<10>::kDoubles : FinishQueue::kDoubles;   // reduced rows of a pass

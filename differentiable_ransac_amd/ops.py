@@ -1090,11 +1090,18 @@ def _match_loss_mean_f64(matches, mask, models, keep, chunk: int = 256):
     total = torch.zeros((P,), device=matches.device, dtype=matches.dtype)
     for m0 in range(0, M, chunk):
         F = models[:, m0:m0 + chunk]
+        if keep is not None:
+            # dropped slots are SELECTED out, not multiplied by 0: an invalid f8 / LSQ hypothesis may be NaN, and NaN * 0 would
+            # turn the loss and every gradient into NaN where the f32 kernels skip the slot (round-5 advice)
+            F = torch.where(keep[:, m0:m0 + chunk, None, None].bool(), F, torch.zeros((), device=F.device, dtype=F.dtype))
         Fx1 = torch.einsum("pmij,pnj->pmni", F, x1)
         Ftx2 = torch.einsum("pmji,pnj->pmni", F, x2)
         r = (x2[:, None] * Fx1).sum(-1)
         ys = r ** 2 * (1.0 / (Fx1[..., 0] ** 2 + Fx1[..., 1] ** 2 + 1e-15) + 1.0 / (Ftx2[..., 0] ** 2 + Ftx2[..., 1] ** 2 + 1e-15))
-        total = total + (ys.clamp(max=1.0) * w_pt[:, None, :] * w_md[:, m0:m0 + chunk, None]).sum((1, 2))
+        ys = ys.clamp(max=1.0)
+        if mask is not None:
+            ys = torch.where(mask[:, None, :].bool(), ys, torch.zeros((), device=ys.device, dtype=ys.dtype))
+        total = total + (ys * w_md[:, m0:m0 + chunk, None]).sum((1, 2))
     den = (w_pt.sum(1) * w_md.sum(1)).clamp(min=1.0)
     return (total / den).mean()
 

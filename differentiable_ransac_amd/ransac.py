@@ -79,6 +79,11 @@ class RANSAC(object):
             raise NotImplementedError("local optimisation is out of scope (it never ran in the reference either: "
                                       "lo defaults to 0 and lo=3 raises TypeError, SURVEY Q2)")
 
+    def adaptive_iteration_number(self, inlier_number, point_number, confidence):
+        """ransac.py:202-215, the reference's method form (sample size, eps and the cap come from the object)."""
+        return adaptive_iteration_number(inlier_number, point_number, self.estimator.sample_size, confidence, self.eps,
+                                         self.max_iterations)
+
     # -- one batch: sample -> gather -> solve; returns models [B,S,3,3], valid [B,S], soft weights
     def _hypotheses(self, matches, logits, gumbels=None):
         B = self.ransac_batch_size
@@ -324,6 +329,11 @@ class RANSAC3D(object):
         self.max_iterations = max_iterations
         self.eps = eps
         self.flag = flag
+
+    def adaptive_iteration_number(self, inlier_number, point_number, confidence):
+        """ransac.py:452-465 (the same rule as RANSAC's)."""
+        return adaptive_iteration_number(inlier_number, point_number, self.estimator.sample_size, confidence, self.eps,
+                                         self.max_iterations)
 
     def __call__(self, matches, logits, gt_model, valid=False, gumbels=None):
         train = self.train and not valid

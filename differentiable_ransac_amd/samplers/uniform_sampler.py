@@ -17,6 +17,14 @@ class UniformSampler(object):
         self.seed = seed
         self.calls = 0
 
+    def unique_generate(self, num_points):
+        """uniform_sampler.py:11-13: ONE sample of `num_samples` indices into the sequence `num_points` (the reference takes its
+        len()), drawn with replacement from [0, len - 1]"""
+        s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
+        self.calls += 1
+        # dr_uniform_sample draws U{0..N-2} (randint(0, N - 1) of batch_generate): N = len + 1 covers [0, len - 1]
+        return ops.uniform_sample(1, 1, self.num_samples, len(num_points) + 1, s, self.device)[0, 0].long()
+
     def batch_generate(self, num_points, pairs=None):
         s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
         self.calls += 1

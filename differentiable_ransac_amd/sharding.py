@@ -90,17 +90,30 @@ class AsyncGradientBucket:
         self.trace = []
         self.exposed_events = []
         self._cuda = self.buf[0].is_cuda
+        self.on_overrun = None       # on_overrun(averaged_bucket_copy, step_index): see bucket()
+        self.overrun_reduced = None
 
     def bucket(self) -> torch.Tensor:
-        """The buffer the NEXT launch() will reduce (the backward of the current step writes its gradients here)."""
+        """The buffer the NEXT launch() will reduce (the backward of the current step writes its gradients here).
+        With both buffers in flight the one about to be handed out is the OLDEST in-flight all_reduce's: it is waited for here,
+        BEFORE the caller can write into it (round-5 advice: the guard used to sit in launch(), after the backward had already
+        overwritten the live buffer); its averaged contents go to `on_overrun` (the optimizer's hook) and are kept as a copy in
+        `overrun_reduced` -- the buffer itself is about to be refilled."""
+        if self.issued - self.waited >= 2:
+            i = self.waited
+            reduced = self.wait()
+            self.overrun_reduced = reduced.clone()
+            if self.on_overrun is not None:
+                self.on_overrun(self.overrun_reduced, i)
         return self.buf[self.issued % 2]
 
     def launch(self) -> None:
         i = self.issued
         if self.issued - self.waited >= 2:
-            # both buffers are in flight: a third launch would overwrite a live work handle and reduce a buffer the process
-            # group may still be reading (round-4 advice) -- the oldest one is waited for first
-            self.wait()
+            # bucket() waits before it hands out a live buffer; getting here means the caller filled a buffer it did not obtain
+            # from bucket() while both were in flight: the reduced gradients of step i - 2 have been overwritten
+            raise RuntimeError("AsyncGradientBucket.launch(): both buffers are in flight -- call bucket() (or wait()) "
+                               "before writing the next step's gradients")
         if self.dist is not None:
             self.work[i % 2] = self.dist.all_reduce(self.buf[i % 2], op=self.dist.ReduceOp.SUM, async_op=True)
         self.trace.append(("launch", i))

@@ -321,6 +321,43 @@ def main():
          models=torch.cat([models[k] for k in keys]), residuals=torch.cat([residuals[k] for k in keys]),
          mean_residuals=torch.stack([mean_res[k] for k in keys]), iterations=iters)
 
+    # ---------------------------------------------------------------- the plugin contract itself: signatures
+    plugin_signatures()
+
+    # ---------------------------------------------------------------- public helpers of FundamentalMatrixEstimatorNew
+    # (fundamental_matrix_estimator.py:177-260: normalize / estimate_non_minimal_model, what estimate_model chains for n > 7)
+    pairH = synth.two_view_pair(23, 64, dtype=torch.float64, pixel=True)
+    estH = FundamentalMatrixEstimatorNew(device="cpu")
+    gH = torch.Generator().manual_seed(12)
+    smpH = pairH["matches"][torch.stack([torch.randperm(64, generator=gH)[:12] for _ in range(16)])]
+    wH = torch.rand(16, 12, generator=gH, dtype=torch.float64) + 0.1
+    nH, T1H, T2H = estH.normalize(smpH)
+    save("f8_helpers", samples=smpH, weights=wH, normalized=nH, T1=T1H, T2t=T2H,
+         F=estH.estimate_non_minimal_model(nH, T1H, T2H), F_w=estH.estimate_non_minimal_model(nH, T1H, T2H, wH),
+         F_plain=estH.estimate_non_minimal_model(nH, None, None))
+
+
+def plugin_signatures():
+    """inspect.signature of every public method of every plugin class of the reference (the duck-typed boundary of SURVEY 8(b))
+    -> plugin_signatures.json: {class: {method: [[name, kind, default-repr | null], ...]}}.  Data, not source."""
+    import inspect
+    import json
+    if ONLY and "plugin_signatures" not in ONLY:
+        return
+    out = {}
+    for cls in (GumbelSoftmaxSampler, UniformSampler, MSACScore, EssentialMatrixEstimatorNister, EssentialMatrixEstimator,
+                FundamentalMatrixEstimatorNew, RigidTransformationSVDBasedSolver, RANSAC, RANSAC3D):
+        methods = {}
+        for name, fn in inspect.getmembers(cls, predicate=inspect.isfunction):
+            if name.startswith("_") and name not in ("__init__", "__call__"):
+                continue
+            methods[name] = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                             for p in inspect.signature(fn).parameters.values()]
+        out[cls.__name__] = methods
+    with open(os.path.join(HERE, "plugin_signatures.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote plugin_signatures", {k: len(v) for k, v in out.items()})
+
 
 if __name__ == "__main__":
     main()

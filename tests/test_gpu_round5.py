@@ -30,8 +30,9 @@ def test_two_phase_fivepoint_vs_oracle(dev, solver):
     Eo, ok, real = O.nister_5pt(smp.cpu().double())
     fw, bw = _set_dist(E[ok], valid[ok], Eo[ok], real[ok])
     assert fw.quantile(0.995) < TOL and bw.quantile(0.995) < TOL, (fw.max(), bw.max())
-    assert (fw > TOL).float().mean() < 2e-3 and (bw > TOL).float().mean() < 2e-3
-    assert abs(int(valid.sum()) - int(real[ok].sum())) <= 8
+    # round 6: the bars of the lane-pair test (test_gpu_solvers.py: 1e-3, +-4) -- the kernel on the headline path is held to them too
+    assert (fw > TOL).float().mean() < 1e-3 and (bw > TOL).float().mean() < 1e-3
+    assert abs(int(valid.sum()) - int(real[ok].sum())) <= 4
 
 
 @pytest.mark.parametrize("rows", [1, 33, 64, 97, 4096])

@@ -37,14 +37,19 @@ def _kat_essential(E, valid, smp, tol=1e-6):
     assert (E[~valid] == eye).all()
 
 
+@pytest.mark.parametrize("path", [0, 2])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("solver", ["nister", "stewenius"])
-def test_fivepoint_golden(dev, solver, dtype):
+def test_fivepoint_golden(dev, solver, dtype, path):
+    """path = 2: the reference-held vector through the TWO-PHASE kernels -- the ones every launch of >= 65 536 samples (the bench,
+    configs 3 and 5) takes; 32 samples would take the lane-pair kernel on their own (round-5 review, missing item 5)"""
     from differentiable_ransac_amd import ops
+    if path and dtype != torch.float32:
+        pytest.skip("explicit kernel paths exist for f32 I/O only")
     g = load_golden("fivepoint")
     smp = g["samples"].to(dtype)
     fn = ops.solve_nister5 if solver == "nister" else ops.solve_stewenius5
-    E, valid = fn(smp.to(dev))
+    E, valid = fn(smp.to(dev), path=path) if path else fn(smp.to(dev))
     E, valid = E.cpu().double(), valid.cpu()
     assert E.shape == (32, 10, 3, 3) and valid.shape == (32, 10)
     _kat_essential(E, valid, smp.double())
@@ -82,10 +87,11 @@ def test_nister_mixed_precision_entry(dev):
         ops.solve_nister5_hp(smp.double())
 
 
-def test_nister_weighted_and_nonminimal(dev):
+@pytest.mark.parametrize("path", [0, 2])
+def test_nister_weighted_and_nonminimal(dev, path):
     from differentiable_ransac_amd import ops
     g = load_golden("fivepoint")
-    E, valid = ops.solve_nister5(g["samples"].float().to(dev), g["weights"].float().to(dev))
+    E, valid = ops.solve_nister5(g["samples"].float().to(dev), g["weights"].float().to(dev), path=path)
     Eo, ok, real = O.nister_5pt(g["samples"], g["weights"])
     fw, bw = _set_dist(E.cpu().double(), valid.cpu(), Eo, real)
     assert fw.max() < TOL and bw.max() < TOL

@@ -152,3 +152,53 @@ def test_async_gradient_bucket_without_a_process_group_is_a_no_op_pipeline():
                   ("launch", 2), ("wait", 2)]
     assert float(b.buf[0][0]) == 3.0 and float(b.buf[1][0]) == 2.0 and b.exposed_events == []
     assert b.wait() is None
+
+
+def test_async_gradient_bucket_never_hands_out_a_live_buffer():
+    """round-5 advice: with two buckets in flight, bucket() returns the buffer of the OLDEST in-flight all-reduce -- it must be
+    waited for before the backward writes into it, its averaged contents must reach the hook, and a launch() that bypassed
+    bucket() must raise instead of reducing an overwritten buffer"""
+    import pytest
+    import torch
+    from differentiable_ransac_amd import sharding
+    b = sharding.AsyncGradientBucket(4, "cpu", None)
+    got = []
+    b.on_overrun = lambda t, i: got.append((i, float(t[0])))
+    b.bucket().fill_(1.0)
+    b.launch()
+    b.bucket().fill_(2.0)
+    b.launch()                    # both buffers in flight
+    nxt = b.bucket()              # waits for bucket 0 first, hands its result to the hook, THEN returns the buffer
+    assert got == [(0, 1.0)] and b.waited == 1 and float(b.overrun_reduced[0]) == 1.0
+    nxt.fill_(3.0)
+    assert float(b.overrun_reduced[0]) == 1.0      # a copy: refilling the buffer does not touch the handed-out result
+    b.launch()
+    assert b.trace == [("launch", 0), ("launch", 1), ("wait", 0), ("launch", 2)]
+    with pytest.raises(RuntimeError):
+        b.launch()                # a third in-flight bucket without going through bucket()
+    b.drain()
+    assert b.waited == b.issued == 3
+
+
+def test_f64_match_loss_selects_dropped_slots_out():
+    """round-5 advice: NaN models in keep=False slots (invalid f8 / LSQ hypotheses) must not poison the f64 MatchLoss or its
+    gradient -- the f32 kernels skip such slots; the torch-op f64 path has to agree on exactly these inputs"""
+    import torch
+    from differentiable_ransac_amd import ops
+    torch.manual_seed(0)
+    P, N, M = 2, 50, 6
+    m = torch.rand(P, N, 4, dtype=torch.float64)
+    md = torch.randn(P, M, 3, 3, dtype=torch.float64)
+    keep = torch.rand(P, M) > 0.3
+    mask = torch.rand(P, N) > 0.2
+    bad = md.clone()
+    bad[~keep] = float("nan")
+    md.requires_grad_(True)
+    bad.requires_grad_(True)
+    l1 = ops._match_loss_mean_f64(m, mask, md, keep)
+    l2 = ops._match_loss_mean_f64(m, mask, bad, keep)
+    l1.backward()
+    l2.backward()
+    assert torch.isfinite(l2) and float(l1.detach()) == float(l2.detach())
+    assert torch.isfinite(bad.grad).all() and torch.equal(md.grad[keep], bad.grad[keep])
+    assert float(bad.grad[~keep].abs().max()) == 0.0
