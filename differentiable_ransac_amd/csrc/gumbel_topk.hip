@@ -46,7 +46,19 @@ struct GumbelArgs {
   T tau;
   int P, B, N, k;
   const uint64_t *seed_ptr;   // optional: the seed lives in device memory (captured graphs: one word updated per replay)
+  // sub > 0 (round 6, super-rounds of the test-mode drivers): the B rows are ceil(B / sub) consecutive SUB-BATCHES of `sub` rows, the
+  // batches a batch-by-batch loop would have drawn one call after the other: row b draws what row b % sub of the call with the seed
+  // `seed + b / sub` draws (the drivers' per-call seeds are consecutive integers)
+  int sub;
 };
+// Philox key and row counter of row b (see GumbelArgs::sub); wave-uniform
+__device__ __forceinline__ void sub_batch_row(uint64_t &seed, int &bq, int b, int sub) {
+  bq = b;
+  if (sub > 0) {
+    seed += (uint64_t)(b / sub);
+    bq = b % sub;
+  }
+}
 
 template <typename T> __device__ __forceinline__ T gumbel_from_bits_t(uint32_t bits);
 template <> __device__ __forceinline__ float gumbel_from_bits_t<float>(uint32_t bits) { return gumbel_from_bits(bits); }
@@ -72,7 +84,7 @@ __device__ __forceinline__ void load_group(const GumbelArgs<T> &a, int p, int b,
     }
   } else {
     uint32_t r[4];
-    Philox::gen(a.seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+    Philox::gen(a.seed, (uint32_t)q, (uint32_t)(a.sub > 0 ? b % a.sub : b), (uint32_t)p, 0u, r);   // (a.seed: advanced by b / sub at kernel entry)
 #pragma unroll
     for (int j = 0; j < 4; ++j) noise[j] = gumbel_from_bits_t<T>(r[j]);
   }
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
   T *gcache = reinterpret_cast<T *>(reinterpret_cast<int *>(reinterpret_cast<T *>(smem_raw) + (size_t)kRowsPerBlock * kMaxCand) +
                                     kRowsPerBlock * kMaxCand) + (size_t)wv * groups * 4;
   if (b >= a.B) return;  // whole wave exits together (no block-level barrier is used below)
+  if (a.sub > 0) a.seed += (uint64_t)(b / a.sub);
   const size_t row = ((size_t)p * a.B + b);
 
   // ---------------- pass A: online soft-max + lane maximum
@@ -329,7 +342,8 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
                                                                              float4 *__restrict__ gather_dst = nullptr,
                                                                              PairGate gate = PairGate(),
                                                                              const uint32_t *__restrict__ screen_tb = nullptr,
-                                                                             const float *__restrict__ screen_T = nullptr) {
+                                                                             const float *__restrict__ screen_T = nullptr,
+                                                                             int sub = 0) {
   // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
   if (gate.closed(blockIdx.y)) return;   // this pair has terminated (block-uniform): its rows keep what the last round drew
   static_assert(!(kSoft && kScreen), "the soft-max statistics need every element's score");
@@ -347,6 +361,8 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
   if (b >= B) return;   // whole wave exits together (no block-level barrier is used below)
+  int bq;
+  sub_batch_row(seed, bq, b, sub);
   const int groups = N >> 2;
   const size_t row = (size_t)p * B + b;
   const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
           l_nx = qn < groups ? lg[qn] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         uint32_t r[4];
-        Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+        Philox::gen(seed, (uint32_t)q, (uint32_t)bq, (uint32_t)p, 0u, r);
         const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
         const float ll[4] = {l4v.x, l4v.y, l4v.z, l4v.w};
 #pragma unroll
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
     const int q = lane + 64 * i;
     if (q < groups) {
       uint32_t r[4];
-      Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+      Philox::gen(seed, (uint32_t)q, (uint32_t)bq, (uint32_t)p, 0u, r);
       const float4 l = lg[q];
       g[i][0] = l.x + gumbel_from_bits(r[0]);
       g[i][1] = l.y + gumbel_from_bits(r[1]);
@@ -833,7 +849,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
                                                                                float *__restrict__ y_sel, float *__restrict__ lse_out,
                                                                                const uint64_t *__restrict__ seed_ptr,
                                                                                const uint32_t *__restrict__ screen_tb = nullptr,
-                                                                               const float *__restrict__ screen_T = nullptr) {
+                                                                               const float *__restrict__ screen_T = nullptr, int sub = 0) {
   // screen_tb / screen_T (index-only mode): per point the smallest Philox word that can still lift the point to the score T
   // (gumbel_screen_kernel).  A step of the wave whose 256 words all stay below their thresholds is skipped after Philox + four
   // integer compares: no logits, no logarithms, no insertion.  Steps with a candidate are evaluated in full, for every lane, so
@@ -849,6 +865,8 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
   const int part = kW > 1 ? wv : 0;
   const int p = blockIdx.y, b = kW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * kRowsPerBlock + wv);
   if (b >= B) return;   // kW > 1: block-uniform (one row per block), so the barrier below is reached by all or none
+  int bq;
+  sub_batch_row(seed, bq, b, sub);
   const int groups = N >> 2;
   const size_t row = (size_t)p * B + b;
   const float4 *lg = reinterpret_cast<const float4 *>(logits + (size_t)p * N);
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
     for (int q = lane + 64 * part; q < groups; q += 64 * kW, tcur = tnext) {
       if (screen && q + 64 * kW < groups) tnext = tb4[q + 64 * kW];
       uint32_t r[4];
-      Philox::gen(seed, (uint32_t)q, (uint32_t)b, (uint32_t)p, 0u, r);
+      Philox::gen(seed, (uint32_t)q, (uint32_t)bq, (uint32_t)p, 0u, r);
       if (screen) {
         const uint4 t = tcur;
         if (!__ballot(r[0] >= t.x || r[1] >= t.y || r[2] >= t.z || r[3] >= t.w)) continue;
@@ -1009,26 +1027,27 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_stream_kernel(
 template <int K>
 static void stream_launch(bool soft, dim3 grid, dim3 block, hipStream_t st, const float *logits, uint64_t seed, int B, int N, int k,
                           int32_t *idx, float *y_sel, float *lse, const uint64_t *seed_ptr, const uint32_t *tb = nullptr,
-                          const float *Tp = nullptr) {
+                          const float *Tp = nullptr, int sub = 0) {
   // few rows: four waves per row (one row per block) -- the wave-per-row grid would leave the SIMDs at <= 4 waves each
   const long rows = (long)grid.y * B;
   if (DR_K1_STREAM_SPLIT && rows <= 4096 && N >= 4 * 64 * 4 * 4) {
     const dim3 g2(B, grid.y);
     if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
-    else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr, tb, Tp);
+    else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, kRowsPerBlock>), g2, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr, tb, Tp, sub);
     return;
   }
   if (soft) hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, true, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr);
-  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr, tb, Tp);
+  else hipLaunchKernelGGL((gumbel_topk_stream_kernel<K, false, 1>), grid, block, 0, st, logits, seed, B, N, k, idx, y_sel, lse, seed_ptr, tb, Tp, sub);
 }
 
 template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
                       const uint64_t *seed_ptr = nullptr, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr,
-                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr, PairGate gate = PairGate()) {
+                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr, PairGate gate = PairGate(), int sub = 0) {
+  // sub (index-only mode, in-kernel noise): rows per sub-batch of a super-round (GumbelArgs::sub); 0 = one batch
   if (gathered) *gathered = false;
-  GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr};
+  GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr, sub};
   const int groups = (N + 3) / 4;
   const size_t base = (size_t)kRowsPerBlock * kMaxCand * (sizeof(T) + sizeof(int));
   const size_t cache = (size_t)kRowsPerBlock * groups * 4 * sizeof(T);
@@ -1048,13 +1067,14 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
         hipLaunchKernelGGL(gumbel_screen_short_kernel, dim3(P), dim3(256), 0, st, (const float *)logits, N, (float)(11 + k), Tw, screen_ws);
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false, true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
                            (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate, (const uint32_t *)screen_ws,
-                           (const float *)Tw);
+                           (const float *)Tw, sub);
         if (gathered) *gathered = gather_dst != nullptr;
       }
       else
       {
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate);
+                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate, (const uint32_t *)nullptr,
+                           (const float *)nullptr, sub);
         if (gathered) *gathered = gather_dst != nullptr;
       }
       return check_launch("gumbel_topk_fast_kernel");
@@ -1080,8 +1100,8 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
         tb = screen_ws;
         Tp = Tw;
       }
-      if (k <= 3) stream_launch<3>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr, tb, Tp);
-      else stream_launch<5>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr, tb, Tp);
+      if (k <= 3) stream_launch<3>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr, tb, Tp, sub);
+      else stream_launch<5>(soft, grid, block, st, (const float *)logits, seed, B, N, k, idx, (float *)y_sel, (float *)lse, seed_ptr, tb, Tp, sub);
       return check_launch("gumbel_topk_stream_kernel");
     }
   }
@@ -1364,7 +1384,10 @@ __global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_
 // (what the drivers compute on the host per call; here a captured graph advances it by itself at every replay)
 __global__ void seed_next_kernel(uint64_t *__restrict__ state, uint64_t *__restrict__ out, int n = 1) {
   // n > 1: the seeds of the next n calls at once (a multi-round call draws one per round: one launch instead of n)
-  if (blockIdx.x == 0 && threadIdx.x < (unsigned)n) out[threadIdx.x] = state[0] * 0x9E3779B97F4A7C15ull + state[1] + threadIdx.x;
+  if (blockIdx.x == 0) {
+    const uint64_t s0 = state[0] * 0x9E3779B97F4A7C15ull + state[1];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = s0 + (uint64_t)i;
+  }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) state[1] += (uint64_t)n;
 }
@@ -1524,7 +1547,7 @@ int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream) {
 }
 int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream) {
   DR_REQUIRE(state && seeds_out, "null pointer");
-  DR_REQUIRE(n >= 1 && n <= 64, "1 <= n <= 64 seeds per launch");
+  DR_REQUIRE(n >= 1 && n <= 65536, "1 <= n <= 65536 seeds per launch");
   hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seeds_out, n);
   return dr::check_launch("seed_next_kernel");
 }
@@ -1568,7 +1591,7 @@ int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N
 // ransac.py:65).  One launch when the register kernel serves the shape, sampler + gather launches otherwise.
 static int gumbel_topk_gather_impl(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
                                    int B, int N, int k, int32_t *idx, float *samples, dr::PairGate gate, void *stream,
-                                   uint32_t *screen_ws = nullptr) {
+                                   uint32_t *screen_ws = nullptr, int sub = 0) {
   const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
   DR_REQUIRE(logits && matches && samples, "null pointer");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
@@ -1576,7 +1599,7 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
   bool gathered = false;
   if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
                                             (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
-                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate))
+                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate, sub))
     return rc;
   if (gathered) return 0;
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
@@ -1626,15 +1649,19 @@ int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uin
 // screen_ws (optional, (N + 32) * P words, 16-byte aligned; round 5): short rows (N <= 2048, N % 4 == 0, tau = 1, k <= 5, B >= 64)
 // then take the SCREENED register kernel -- per point the smallest Philox word that can lift it to the score logsumexp - ln(11 + k),
 // only the ~16 points of a row that pass are evaluated; the index sets are those of the unscreened kernel, bit for bit.
+// sub (round 6): > 0 = the B rows are consecutive sub-batches of `sub` rows -- row b draws what row b % sub of a call with the seed
+// (seed | *seed_dev) + b / sub draws: one launch samples what ceil(B / sub) calls of a batch-by-batch loop sample (dr_ransac_update's
+// `sub_models` walks them in order); 0 = one batch.  Soft (train-mode) outputs have no sub-batch form.
 int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                                     int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                                    const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
+                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, void *stream) {
   DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
+  DR_REQUIRE(sub >= 0, "sub-batch size");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(screen_ws) & 15) == 0, "workspace alignment");
   dr::PairGate gate;
   gate.iters = gate_iters;
   gate.max_iters = gate_max_iters;
-  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws);
+  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws, sub);
 }
 
 // K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 32) * P words, 16-byte aligned): long rows

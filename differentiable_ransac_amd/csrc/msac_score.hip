@@ -759,88 +759,153 @@ __global__ __launch_bounds__(kThreads) void refit_accept_kernel(const T *__restr
 // (ransac.py:109-144 and adaptive_iteration_number :202-215).  One 1024-thread block per pair.
 constexpr int kUpdThreads = 1024;
 
+// sub_models (round 6): 0 / >= M = the M models are ONE batch.  Otherwise they are ceil(M / sub_models) consecutive SUB-BATCHES of
+// sub_models models (= B hypotheses each) -- the batches the loop of ransac.py:55-144 would have scored one call after the other --
+// and the kernel WALKS them in order with that loop's own rule: stop when iters >= max_iters, arg-max of the sub-batch, better-test,
+// best mask / inlier count, new max_iters, iters += B.  State after the launch = state after that many iterations of the loop.
+constexpr int kUpdMaxSub = 512;   // sub-batches per launch
+
+template <typename T>
+__device__ __forceinline__ void argmax_merge(T &bv, int &bi, T ov, int oi) {
+  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
     const T *__restrict__ matches, const T *__restrict__ models, const uint8_t *__restrict__ valid,
     const T *__restrict__ scores, const T *__restrict__ thr, int M, int N, int B, int k, double confidence,
     double eps, int max_iterations, T *__restrict__ best_score, T *__restrict__ best_model,
     uint8_t *__restrict__ best_mask, int32_t *__restrict__ best_inliers, int32_t *__restrict__ iters,
-    double *__restrict__ max_iters) {
+    double *__restrict__ max_iters, int sub_models) {
   __shared__ T s_val[kUpdThreads / kWave];
   __shared__ int s_idx[kUpdThreads / kWave];
   __shared__ int s_cnt[kUpdThreads / kWave];
+  __shared__ T s_sub_val[kUpdMaxSub];
+  __shared__ int s_sub_idx[kUpdMaxSub];
+  __shared__ double s_mi;
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int it0 = iters[p];
-  if ((double)it0 >= max_iters[p]) return;  // this pair has terminated (uniform across the block)
+  int it = iters[p];
+  double mi = max_iters[p];
+  if ((double)it >= mi) return;  // this pair has terminated (uniform across the block)
   const T *sc = scores + (size_t)p * M;
   const uint8_t *vd = valid ? valid + (size_t)p * M : nullptr;
-  T bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int m0 = tid; m0 < M; m0 += 4 * kUpdThreads) {
-    T v[4];
-    bool ok[4];
+  const int msub = (sub_models > 0 && sub_models < M) ? sub_models : M;
+  const int R = (M + msub - 1) / msub;
+  constexpr int kWaves = kUpdThreads / kWave;
+  if (R <= kWaves) {
+    // few sub-batches (R = 1: the one batch): kWaves / R waves share a sub-batch, every load of the launch in flight at once --
+    // two sub-batches of 10 240 scores cost what one costs
+    const int wps = kWaves / R, j = wv / wps, part = wv - j * wps;
+    T bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (j < R) {
+      const int lo = j * msub, hi = min(M, lo + msub), step = wps * kWave;
+      for (int m0 = lo + part * kWave + lane; m0 < hi; m0 += 4 * step) {
+        T v[4];
+        bool ok[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int m = m0 + u * kUpdThreads;
-      v[u] = m < M ? sc[m] : T(0);
-      ok[u] = m < M && (!vd || vd[m]);
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * step;
+          v[u] = m < hi ? sc[m] : T(0);
+          ok[u] = m < hi && (!vd || vd[m]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * step;
+          if (ok[u] && v[u] == v[u] && (v[u] > bv || (v[u] == bv && m < bi))) { bv = v[u]; bi = m; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int m = m0 + u * kUpdThreads;
-      if (ok[u] && v[u] == v[u] && (v[u] > bv || (v[u] == bv && m < bi))) { bv = v[u]; bi = m; }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    T ov = __shfl_xor(bv, o, 64);
-    int oi = __shfl_xor(bi, o, 64);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
-  __syncthreads();
-  bv = s_val[0]; bi = s_idx[0];
-#pragma unroll
-  for (int w = 1; w < kUpdThreads / kWave; ++w)
-    if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
-  const bool have = bi != 0x7fffffff;
-  const bool better = have && (bv > best_score[p] || it0 == 0);   // ransac.py:116
-  if (better) {
-    T m[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) m[q] = models[((size_t)p * M + bi) * 9 + q];
-    const T t = T(1.5) * thr[p];
-    const T inv_thr2 = T(1) / (t * t);
-    int cnt = 0;
-    for (int n = tid; n < N; n += kUpdThreads) {
-      const T *q = matches + ((size_t)p * N + n) * 4;
-      const bool in = sampson_s<T>(m, q[0], q[1], q[2], q[3], inv_thr2) < T(0);
-      best_mask[(size_t)p * N + n] = in;
-      cnt += in;
-    }
-    cnt = wave_sum(cnt);
-    if (lane == 0) s_cnt[wv] = cnt;
+    if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
     __syncthreads();
-    if (tid == 0) {
-      int inl = 0;
+    if (tid < R) {
+      bv = s_val[tid * wps]; bi = s_idx[tid * wps];
+      for (int w = 1; w < wps; ++w) argmax_merge(bv, bi, s_val[tid * wps + w], s_idx[tid * wps + w]);
+      s_sub_val[tid] = bv;
+      s_sub_idx[tid] = bi;
+    }
+  } else {
+    // many small sub-batches: a wave per sub-batch (first arg-max over its valid, non-NaN models), four scores in flight per lane
+    for (int j = wv; j < R; j += kWaves) {
+      const int lo = j * msub, hi = min(M, lo + msub);
+      T bv = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int m0 = lo + lane; m0 < hi; m0 += 4 * kWave) {
+        T v[4];
+        bool ok[4];
 #pragma unroll
-      for (int w = 0; w < kUpdThreads / kWave; ++w) inl += s_cnt[w];
-      best_inliers[p] = inl;
-      best_score[p] = bv;
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * kWave;
+          v[u] = m < hi ? sc[m] : T(0);
+          ok[u] = m < hi && (!vd || vd[m]);
+        }
 #pragma unroll
-      for (int q = 0; q < 9; ++q) best_model[(size_t)p * 9 + q] = m[q];
-      // adaptive_iteration_number, ransac.py:202-215
-      const double ratio = (double)inl / (double)N;
-      const double rk = pow(ratio, (double)k);
-      const double prob = 1.0 - rk;
-      double mi = (double)max_iterations;
-      // (round 5, measured and dropped: the thread's correspondences requested before the arg-max, twelve scores in flight instead
-      //  of four -- 15.9 -> 15.9 / 16.1 us at 128 pairs, 10.1 at one pair; without this f64 pow / log10 tail: 15.1 / 9.2 us)
-      if (!(prob >= 1.0 - eps)) mi = fmax(0.0, log10(1.0 - confidence) / log10(1.0 - rk + eps));
-      max_iters[p] = fmin((double)max_iterations, mi);
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * kWave;
+          if (ok[u] && v[u] == v[u] && (v[u] > bv || (v[u] == bv && m < bi))) { bv = v[u]; bi = m; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
+      if (lane == 0) { s_sub_val[j] = bv; s_sub_idx[j] = bi; }
     }
   }
-  if (tid == 0) iters[p] = it0 + B;
+  __syncthreads();
+  T bs = best_score[p];
+  const T t = T(1.5) * thr[p];
+  const T inv_thr2 = T(1) / (t * t);
+  for (int j = 0; j < R; ++j) {
+    if ((double)it >= mi) break;                                 // ransac.py:55 (block-uniform: every thread holds the same it / mi)
+    const T bv = s_sub_val[j];
+    const int bi = s_sub_idx[j];
+    const bool have = bi != 0x7fffffff;
+    const bool better = have && (bv > bs || it == 0);           // ransac.py:116
+    if (better) {
+      T m[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) m[q] = models[((size_t)p * M + bi) * 9 + q];
+      int cnt = 0;
+      for (int n = tid; n < N; n += kUpdThreads) {
+        const T *q = matches + ((size_t)p * N + n) * 4;
+        const bool in = sampson_s<T>(m, q[0], q[1], q[2], q[3], inv_thr2) < T(0);
+        best_mask[(size_t)p * N + n] = in;
+        cnt += in;
+      }
+      cnt = wave_sum(cnt);
+      __syncthreads();                                           // (s_cnt / s_mi of the previous sub-batch have been read)
+      if (lane == 0) s_cnt[wv] = cnt;
+      __syncthreads();
+      if (tid == 0) {
+        int inl = 0;
+#pragma unroll
+        for (int w = 0; w < kUpdThreads / kWave; ++w) inl += s_cnt[w];
+        best_inliers[p] = inl;
+        best_score[p] = bv;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) best_model[(size_t)p * 9 + q] = m[q];
+        // adaptive_iteration_number, ransac.py:202-215
+        const double ratio = (double)inl / (double)N;
+        const double rk = pow(ratio, (double)k);
+        const double prob = 1.0 - rk;
+        double nmi = (double)max_iterations;
+        // (round 5, measured and dropped: the thread's correspondences requested before the arg-max, twelve scores in flight instead
+        //  of four -- 15.9 -> 15.9 / 16.1 us at 128 pairs, 10.1 at one pair; without this f64 pow / log10 tail: 15.1 / 9.2 us)
+        if (!(prob >= 1.0 - eps)) nmi = fmax(0.0, log10(1.0 - confidence) / log10(1.0 - rk + eps));
+        nmi = fmin((double)max_iterations, nmi);
+        max_iters[p] = nmi;
+        s_mi = nmi;
+      }
+      bs = bv;
+      if (R > 1) {                                               // the next sub-batch's stop test needs the new bound
+        __syncthreads();
+        mi = s_mi;
+      }
+    }
+    it += B;
+  }
+  if (tid == 0) iters[p] = it;
 }
 
 // ---- K6 state set-up: the normalised threshold of ransac.py:49-53 and the per-pair test-mode state, one launch ----
@@ -1023,26 +1088,28 @@ int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double 
 int dr_ransac_update_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
                          const float *thr, int P, int M, int N, int B, int k, double confidence, double eps,
                          int max_iterations, float *best_score, float *best_model, uint8_t *best_mask,
-                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, int sub_models, void *stream) {
   DR_REQUIRE(matches && models && scores && thr && best_score && best_model && best_mask && best_inliers && iters &&
                  max_iters, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && B > 0 && k > 0, "bad sizes");
+  DR_REQUIRE(sub_models >= 0 && (sub_models == 0 || (M + sub_models - 1) / sub_models <= dr::kUpdMaxSub), "sub-batches per launch");
   hipLaunchKernelGGL((dr::ransac_update_kernel<float>), dim3(P), dim3(dr::kUpdThreads), 0, (hipStream_t)stream,
                      matches, models, valid, scores, thr, M, N, B, k, confidence, eps, max_iterations, best_score,
-                     best_model, best_mask, best_inliers, iters, max_iters);
+                     best_model, best_mask, best_inliers, iters, max_iters, sub_models);
   return dr::check_launch("ransac_update_kernel");
 }
 
 int dr_ransac_update_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,
                          const double *thr, int P, int M, int N, int B, int k, double confidence, double eps,
                          int max_iterations, double *best_score, double *best_model, uint8_t *best_mask,
-                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, int sub_models, void *stream) {
   DR_REQUIRE(matches && models && scores && thr && best_score && best_model && best_mask && best_inliers && iters &&
                  max_iters, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && B > 0 && k > 0, "bad sizes");
+  DR_REQUIRE(sub_models >= 0 && (sub_models == 0 || (M + sub_models - 1) / sub_models <= dr::kUpdMaxSub), "sub-batches per launch");
   hipLaunchKernelGGL((dr::ransac_update_kernel<double>), dim3(P), dim3(dr::kUpdThreads), 0, (hipStream_t)stream,
                      matches, models, valid, scores, thr, M, N, B, k, confidence, eps, max_iterations, best_score,
-                     best_model, best_mask, best_inliers, iters, max_iters);
+                     best_model, best_mask, best_inliers, iters, max_iters, sub_models);
   return dr::check_launch("ransac_update_kernel");
 }
 

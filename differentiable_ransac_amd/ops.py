@@ -109,16 +109,20 @@ def ransac_init(P: int, N: int, max_iterations: int, threshold: float, K1: Optio
 
 
 def ransac_update(state: RansacState, matches, models, valid, scores, thr, B: int, k: int, confidence: float = 0.999,
-                  eps: float = 1e-5) -> None:
-    """K6 fused (dr_ransac_update): arg-max, best-model bookkeeping and adaptive termination, in place, one launch."""
+                  eps: float = 1e-5, sub_models: int = 0) -> None:
+    """K6 fused (dr_ransac_update): arg-max, best-model bookkeeping and adaptive termination, in place, one launch.
+    sub_models > 0: the M models are consecutive sub-batches of B hypotheses (sub_models models each), walked in order with the
+    stop rule of ransac.py:55-144 -- the state afterwards is the batch-by-batch loop's."""
     P, N, _ = matches.shape
     M = models.shape[1]
+    if sub_models and M > sub_models * 512:
+        raise L.DransacError("ransac_update: at most 512 sub-batches per launch")
     v = None if valid is None else valid.contiguous().view(torch.uint8)
     L.call(f"dr_ransac_update_{L.suffix(matches.dtype)}", ptr(matches), ptr(models.contiguous()), ptr(v),
            ptr(scores.contiguous()), ptr(thr), c_int(P), c_int(M), c_int(N), c_int(B), c_int(k),
            L.c_double(confidence), L.c_double(eps), c_int(state.max_iterations), ptr(state.best_score),
            ptr(state.best_model), ptr(state.best_mask), ptr(state.best_inliers), ptr(state.iters), ptr(state.max_iters),
-           stream())
+           c_int(int(sub_models)), stream())
 
 
 # ------------------------------------------------------------------------------------------ K1 / K1u / K2
@@ -140,10 +144,16 @@ class DeviceSeed:
         L.call("dr_seed_next", ptr(self.state), ptr(out), stream())
         return out
 
-    def next_n(self, n: int):
-        """the seeds of the next n calls from ONE launch (a multi-round call draws one per round): list of n one-word tensors"""
+    def next_block(self, n: int) -> torch.Tensor:
+        """the seeds of the next n calls from ONE launch (a multi-round call draws one per batch) as one [n] tensor of CONSECUTIVE
+        integers: seeds[i:i + 1] is what next() would have returned for call i"""
         out = torch.empty(n, dtype=torch.int64, device=self.state.device)
         L.call("dr_seed_next_n", ptr(self.state), ptr(out), c_int(n), stream())
+        return out
+
+    def next_n(self, n: int):
+        """next_block(n) as a list of n one-word tensors"""
+        out = self.next_block(n)
         return [out[i:i + 1] for i in range(n)]
 
 
@@ -221,10 +231,12 @@ SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 
 
 def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None,
-                       screen: Optional[bool] = None):
+                       screen: Optional[bool] = None, sub: int = 0):
     """K1 (index sets only, in-kernel noise) + K2 in one call: matches [P,N,4] f32, logits [P,N] f32 ->
     (idx [P,B,k] int32 ascending, samples [P,B,k,4] = matches[p, idx]).  What test mode asks of sampler + gather
-    (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor."""
+    (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor.
+    sub > 0 (super-rounds): the B rows are consecutive sub-batches of `sub` rows; row b draws what row b % sub of the call with
+    seed + b // sub draws (the drivers' per-call seeds are consecutive integers)."""
     if matches.dtype != torch.float32 or logits.dtype != torch.float32 or matches.shape[-1] != 4:
         raise L.DransacError("gumbel_topk_gather: f32 two-view correspondences [P,N,4]")
     matches, logits = matches.contiguous(), logits.contiguous()
@@ -236,10 +248,11 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
     want_screen = SCREEN_SHORT_ROWS if screen is None else screen
     ws = (torch.empty((P, N + 32), device=logits.device, dtype=torch.int32)
           if want_screen and N <= 2048 and N % 4 == 0 and tau == 1.0 and k <= 5 and B >= 64 else None)
-    if gate is not None or ws is not None:     # (gate: a later round of a multi-round call, terminated pairs are skipped)
+    if gate is not None or ws is not None or sub:     # (gate: a later round of a multi-round call, terminated pairs are skipped)
         L.call("dr_gumbel_topk_gather_gated_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
                ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
-               ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters), stream())
+               ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters),
+               c_int(0 if sub >= B else int(sub)), stream())
         return idx, samples
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
            ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples), stream())

@@ -8,6 +8,7 @@ only sequence launches and keep the (tiny) per-pair state.
 """
 from __future__ import annotations
 
+import collections
 import math
 from typing import Dict
 
@@ -71,10 +72,19 @@ class RANSAC(object):
         self.eps = eps
         self._soft0 = None       # y_soft of hypothesis 0 of the last batch (weighted F refit, ransac.py:151-153)
         self.fused = True        # test mode with this package's own plugins: run on the device-resident batched driver
-        self.graph = True        # ... and, when a call is at most 8 batches, as ONE replayed HIP graph per call (_GraphedCall)
+        self.graph = True        # ... and, when a call is at most 8 device rounds, as ONE replayed HIP graph per call (_GraphedCall)
+        # hypotheses per device round of the replayed call (BatchedRANSAC.super_hypotheses): the first 2048 hypotheses -- however many
+        # batches of `ransac_batch_size` that is -- then everything `max_iterations` still allows in rounds of 4096, walked batch by
+        # batch on the device with the loop's own stop rule: `-rbs 64 / 5000` is two device rounds, like `-rbs 1024`.  One pair
+        # leaves the chip empty, so a device round of 2048 hypotheses costs 15-20 us more than one of 1024 while a second round
+        # costs 70-90: measured per pair at 2000 points, 32 pairs of 36 % inliers (24 of them need a second batch of 1024), ms:
+        #   (1024, 1024) 0.210 | (1024, 1024, 4096) 0.189 | (2048, 4096) 0.148 | (2048, 1024, 4096) 0.156 | (3072, 2048) 0.157 |
+        #   (5120,) 0.168; with ransac_batch_size = 64: 0.221 | 0.198 | 0.154 | 0.165 | 0.165 | 0.175   (scratch/runs/r6_gpu_e.sh)
+        self.graph_hypotheses = (2048, 4096)
+        self.max_graphs = 8      # replayed calls kept (one per point count and device), least recently used evicted
         self._fast = None
         self._fast_cfg = None
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()
         if lo:
             raise NotImplementedError("local optimisation is out of scope (it never ran in the reference either: "
                                       "lo defaults to 0 and lo=3 raises TypeError, SURVEY Q2)")
@@ -134,10 +144,12 @@ class RANSAC(object):
         models = models.reshape(nb, S, 3, 3)
         return models, torch.isfinite(models).flatten(2).all(-1)
 
-    def _make_fast(self, solver, seed=0):
-        return BatchedRANSAC(solver, ransac_batch_size=self.ransac_batch_size, train=False, threshold=self.threshold,
-                             confidence=self.confidence, max_iterations=self.max_iterations, tau=self.sampler.tau,
-                             weighted=self.weighted, refit=True, eps=self.eps, seed=seed)
+    def _make_fast(self, solver, seed=0, super_hypotheses=None):
+        drv = BatchedRANSAC(solver, ransac_batch_size=self.ransac_batch_size, train=False, threshold=self.threshold,
+                            confidence=self.confidence, max_iterations=self.max_iterations, tau=self.sampler.tau,
+                            weighted=self.weighted, refit=True, eps=self.eps, seed=seed)
+        drv.super_hypotheses = super_hypotheses
+        return drv
 
     def _fused_solver(self):
         """Name of the BatchedRANSAC solver equivalent to this object's plugins, or None (custom plugins, uniform
@@ -166,19 +178,26 @@ class RANSAC(object):
         if solver is not None and matches.is_cuda:
             cfg = (solver, self.ransac_batch_size, self.threshold, self.confidence, self.max_iterations, self.sampler.tau,
                    self.weighted, self.eps)
+            cfg = cfg + (self.graph_hypotheses,)
             if self._fast_cfg != cfg:     # public attributes may change between calls (sweeps)
-                self._fast, self._graphs, self._fast_cfg = None, {}, cfg
-            rounds = max(1, math.ceil(self.max_iterations / self.ransac_batch_size))
-            if (self.graph and gumbels is None and rounds <= 8 and matches.dtype == torch.float32 and not self.weighted
-                    and not torch.cuda.is_current_stream_capturing()):
+                self._fast, self._graphs, self._fast_cfg = None, collections.OrderedDict(), cfg
+                self._graph_rounds = len(self._make_fast(solver, super_hypotheses=self.graph_hypotheses).plan())
+            if (self.graph and gumbels is None and matches.dtype == torch.float32 and not self.weighted
+                    and not torch.cuda.is_current_stream_capturing() and self._graph_rounds <= 8):
                 # The reference calls this object one pair at a time (model_cl.py:488-490, test.py:38): ~25 launches of 5-30 us
                 # per pair.  Round 5: the whole call -- threshold, every round, the adaptive stop taken on the device, refit --
                 # is captured once per (point count, device) and replayed: one graph launch + one staging copy per pair.
+                # Round 6: device rounds of `graph_hypotheses` hypotheses, whatever `ransac_batch_size` is.
                 key = (matches.shape[0], matches.device.index)
                 g = self._graphs.get(key)
                 if g is None:
-                    g = self._graphs[key] = _GraphedCall(self._make_fast(solver, seed=self.sampler._next_seed()),
+                    while len(self._graphs) >= max(1, self.max_graphs):      # bounded: variable-N inputs re-capture, the oldest goes
+                        self._graphs.popitem(last=False)
+                    g = self._graphs[key] = _GraphedCall(self._make_fast(solver, seed=self.sampler._next_seed(),
+                                                                         super_hypotheses=self.graph_hypotheses),
                                                          matches.shape[0], matches.device)
+                else:
+                    self._graphs.move_to_end(key)
                 return g(matches, logits, K1, K2)
             if self._fast is None:
                 self._fast = self._make_fast(solver)
@@ -288,6 +307,7 @@ class _GraphedCall(object):
         self.K2 = torch.eye(3, device=device).unsqueeze(0).clone()
         self.matches[0, :, :2] = torch.rand(N, 2, device=device)      # something solvable for the warm-up calls
         self.matches[0, :, 2:] = self.matches[0, :, :2] + 0.01 * torch.rand(N, 2, device=device)
+        self._eye = None
         self.step = GraphedStep(self._run, warmup=2)
 
     def _run(self):
@@ -301,7 +321,14 @@ class _GraphedCall(object):
         dst = [self.matches[0], self.logits[0]]
         if K1 is not None and K2 is not None:
             src += [K1.to(device=matches.device, dtype=torch.float32).reshape(3, 3), K2.to(device=matches.device, dtype=torch.float32).reshape(3, 3)]
-            dst += [self.K1[0], self.K2[0]]
+        else:
+            # no intrinsics: the eager path hands None to dr_ransac_init (threshold used as is).  The captured call always normalises
+            # with the staged K1 / K2, so identity goes in -- f = (1 + 1 + 1 + 1) / 4 = 1, threshold unchanged, exactly -- instead of
+            # whatever the previous pair left in the buffers (round-5 advice)
+            if self._eye is None:
+                self._eye = torch.eye(3, device=matches.device)
+            src += [self._eye, self._eye]
+        dst += [self.K1[0], self.K2[0]]
         torch._foreach_copy_(dst, src)
         packed = self.step().clone()
         model = packed[:36].view(torch.float32).view(3, 3)
@@ -409,7 +436,7 @@ class BatchedRANSAC(object):
         # whole call -- however many rounds the data ask for -- is capturable in one HIP graph.  Costs a handful of empty
         # launches per unneeded round; meant for few rounds (max_iterations / ransac_batch_size <= 8), refused above 16.
         self.device_termination = False
-        self.sync_every = max(1, 256 // max(1, ransac_batch_size))   # rounds between termination read-backs
+        self.sync_every = None   # device rounds between termination read-backs; None = max(1, 256 // hypotheses per device round)
         self._pipe = None
         self.solver = solver
         self.k, self.S = self._SOLVERS[solver]
@@ -434,16 +461,67 @@ class BatchedRANSAC(object):
         self._gap = None         # scratch word of the one-launch dispatch gap in front of the sampler (see __call__)
         self._dev_seed = None
         self._seed_queue = []
+        # Super-rounds (round 6, test mode).  The loop of ransac.py:55-144 runs `ransac_batch_size` hypotheses per iteration of a
+        # Python loop; with the reference's default of 64 a call is up to 79 iterations of four launches each.  A DEVICE round here is
+        # R consecutive batches at once: the sampler draws row b of the round with the noise of row b % B of batch b // B (per-call
+        # seeds are consecutive integers), solver and scoring see R * B hypotheses, and dr_ransac_update walks the R sub-batches IN
+        # ORDER with the loop's own stop rule -- (model, mask, score, iterations) are those of the batch-by-batch loop, bit for bit,
+        # whatever R is; hypotheses behind the stop are speculative work.  (h_0, h_1, ...) = hypotheses per device round, the last
+        # entry repeated; None = automatic: rounds of 1024 hypotheses when ransac_batch_size is below 1024,
+        # one batch per round otherwise; False = always one batch per round (the host loop of rounds 1-5).
+        self.super_hypotheses = None
 
     def _next_seed(self):
         if self._dev_seed is not None:       # seeds advanced on the device (device_seeds(): graph-capturable steps)
             self.calls += 1
-            if self._seed_queue:             # drawn ahead for every round of this call by ONE launch (device_termination)
-                return self._seed_queue.pop(0)
+            if self._seed_queue:             # drawn ahead for every batch of this call by ONE launch (device_termination)
+                blk, pos = self._seed_queue
+                self._seed_queue = (blk, pos + 1) if pos + 1 < blk.shape[0] else []
+                return blk[pos:pos + 1]
             return self._dev_seed.next()
         s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
         self.calls += 1
         return s
+
+    def _next_seeds(self, R):
+        """the seed of the next batch of a device round of R batches; the R - 1 batches behind it take the consecutive seeds
+        (consumed here: a batch-by-batch driver with the same base seed draws the same hypotheses)"""
+        if R == 1:
+            return self._next_seed()
+        if self._dev_seed is not None:
+            self.calls += R
+            if self._seed_queue:
+                blk, pos = self._seed_queue
+                self._seed_queue = (blk, pos + R) if pos + R < blk.shape[0] else []
+                return blk[pos:pos + 1]
+            return self._dev_seed.next_block(R)[:1]
+        s = (self.seed * 0x9E3779B97F4A7C15 + self.calls) & (2 ** 64 - 1)
+        self.calls += R
+        return s
+
+    def plan(self, n_batches=None, dtype=torch.float32):
+        """Batches per device round of a test-mode call (see `super_hypotheses`): a list summing to the number of batches the loop
+        of ransac.py:55 can run at most, ceil(max_iterations / ransac_batch_size)."""
+        if n_batches is None:
+            n_batches = max(1, math.ceil(self.max_iterations / self.B))
+        sh = self.super_hypotheses
+        one = [1] * n_batches
+        if sh is False or self.train or self.sampling != "gumbel" or self.keep_masks or dtype != torch.float32:
+            return one
+        if self.weighted and self.solver == "f8" and self.refit:
+            return one          # the weighted refit wants the row-0 soft weights of the LAST batch a pair ran: batch by batch
+        if sh is None:
+            if self.B >= 1024:
+                return one
+            sh = (1024, 1024)
+        # (dr_ransac_update walks at most 512 sub-batches per launch)
+        sizes = [min(512, max(1, int(h) // self.B)) for h in sh]
+        out, left = [], n_batches
+        while left > 0:
+            r = min(left, sizes[min(len(out), len(sizes) - 1)])
+            out.append(r)
+            left -= r
+        return out
 
     def device_seeds(self, device):
         """From the next call on the per-call seed is computed on the device (ops.DeviceSeed) -- the same sequence of seeds,
@@ -457,9 +535,31 @@ class BatchedRANSAC(object):
         """matches [P,N,4], logits [P,N] -> models [P,B,S,3,3], valid [P,B,S], idx [P,B,k] (differentiable w.r.t. logits)."""
         return self._hypotheses(matches, logits, gumbels)[:3]
 
-    def _hypotheses(self, matches, logits, gumbels=None, gate=None):
+    def _hypotheses(self, matches, logits, gumbels=None, gate=None, R=1):
         """hypotheses() + the (seed, noise) pair of the draw when the weighted refit will need row 0's soft weights again
-        (returned, not stashed on self: two rounds are in flight on two streams when `pipeline` is on), else None."""
+        (returned, not stashed on self: two rounds are in flight on two streams when `pipeline` is on), else None.
+        R > 1 (test mode, see `super_hypotheses`): R consecutive batches in one go -> models [P, R * B, S, 3, 3]; explicit noise is the
+        R batches' tensors concatenated along the hypothesis axis."""
+        if R > 1:
+            Bq = R * self.B
+            if gumbels is None and matches.dtype == torch.float32 and logits.dtype == torch.float32 and matches.shape[-1] == 4:
+                idx, samples = ops.gumbel_topk_gather(matches, logits, Bq, self.k, self.tau, self._next_seeds(R), gate=gate, sub=self.B)
+            else:
+                if gumbels is None:
+                    raise ValueError("super-rounds with in-kernel noise serve f32 two-view correspondences (plan() says so)")
+                idx = ops.gumbel_topk(logits, Bq, self.k, self.tau, gumbels, self._next_seeds(R), soft=False)["idx"]
+                samples = ops.gather(matches, idx)
+            if self.solver in ("nister", "stewenius"):
+                if gate is not None and self.k == 5 and samples.dtype == torch.float32:
+                    models, valid = ops.solve_essential_gated(samples, self.solver, gate)
+                else:
+                    models, valid = ops.solve_essential(samples, None, self.solver)
+            elif self.solver == "f8":
+                F, v = ops.solve_fundamental8(samples, None)
+                models, valid = F.unsqueeze(2), v.unsqueeze(2)
+            else:
+                models, valid = ops.solve_f7(samples)
+            return models, valid, idx, None
         if self.weighted and self.solver == "f8" and not self.train and self.refit:
             # the weighted LSQ refit (ransac.py:151-153) needs y_soft of hypothesis 0 of the LAST batch a pair ran: the seed is
             # handed back so that __call__ can re-draw that one row (ops.soft_weights_row0).  weighted=1 implies the Gumbel
@@ -546,6 +646,11 @@ class BatchedRANSAC(object):
             # launched 6 us after the sampler it ran 15 -> 241 us for 52 us of work, and the solver behind it started 56 us late
             # on the SIMDs it held).
             pre = None
+            # device rounds (see `super_hypotheses`): plan[i] batches of B hypotheses in round i
+            n_batches = rounds if gumbels is None else min(rounds, len(gumbels))
+            plan = self.plan(n_batches, dt) if n_batches > 0 else []
+            first = [sum(plan[:i]) for i in range(len(plan))]         # index of the first batch of device round i
+            rounds = len(plan)
 
             def issue_refit():
                 if self._side is None:
@@ -560,7 +665,7 @@ class BatchedRANSAC(object):
                 pre = issue_refit()
             st, thr = ops.ransac_init(P, N, self.max_iterations, self.threshold, K1 if use_K else None,
                                       K2 if use_K else None, dev, dt)
-            if pre is not None and P * self.B >= 65536:
+            if pre is not None and plan and P * self.B * plan[0] >= 65536:
                 # Dispatch order (round 5): a refit block wants a whole SIMD's registers and 38.9 KB of LDS on its CU; once the
                 # sampler's 32 768 light workgroups are in the queue it does not get them until the sampler's grid runs dry.
                 # The refit waits for this stream's earlier work through an event and lost that race by half a microsecond
@@ -578,39 +683,45 @@ class BatchedRANSAC(object):
             main = torch.cuda.current_stream()
 
             def noise_of(r):
-                return None if gumbels is None else (gumbels[r] if r < len(gumbels) else None)
+                if gumbels is None:
+                    return None
+                if plan[r] == 1:
+                    return gumbels[first[r]]
+                return torch.cat(list(gumbels[first[r]:first[r] + plan[r]]), dim=1)
 
             def have_round(r):
-                return r < rounds and (gumbels is None or noise_of(r) is not None)
+                return r < rounds
+
+            def sub_of(r):      # dr_ransac_update's sub_models: the round's models are plan[r] batches of B x S
+                return self.B * self.S if plan[r] > 1 else 0
 
             # (round 5, measured and dropped -- scratch/runs/r5_gpu_w.sh, 128 pairs: the refit issued right before the first
             #  scoring launch instead of up front: step with refit 1.015 -> 1.063 ms; the same on a high-priority stream: 1.069 ms.)
             if self.device_termination:
                 if rounds > 16:
-                    raise ValueError("device_termination issues every round: max_iterations / ransac_batch_size must be <= 16")
+                    raise ValueError("device_termination issues every round: at most 16 device rounds per call (see super_hypotheses)")
                 want_w = bool(self.weighted and self.solver == "f8" and self.refit)
                 last_w = torch.zeros((P, N), device=dev, dtype=dt) if want_w else None
-                if self._dev_seed is not None and rounds > 1 and gumbels is None:
-                    self._seed_queue = self._dev_seed.next_n(rounds)
+                if self._dev_seed is not None and n_batches > 1 and gumbels is None:
+                    self._seed_queue = (self._dev_seed.next_block(n_batches), 0)    # consecutive seeds, one per BATCH
                 for r in range(rounds):
-                    if not have_round(r):
-                        break
                     gate = st if r > 0 else None
-                    models, valid, _, row0 = self._hypotheses(matches, logits, noise_of(r), gate=gate)
+                    models, valid, _, row0 = self._hypotheses(matches, logits, noise_of(r), gate=gate, R=plan[r])
                     if want_w:
                         w0 = ops.soft_weights_row0(logits, self.k, self.tau, row0[1], row0[0])
                         last_w = torch.where((st.iters.double() < st.max_iters)[:, None], w0, last_w)
-                    flat = models.reshape(P, self.B * self.S, 3, 3)
+                    flat = models.reshape(P, -1, 3, 3)
                     scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks, valid=valid.reshape(P, -1),
                                                    gate=gate)
                     if self.keep_masks:
                         all_masks = masks
                     ops.ransac_update(st, matches, flat, valid.reshape(P, -1), scores, thr, self.B, self.k, self.confidence,
-                                      self.eps)
+                                      self.eps, sub_models=sub_of(r))
+                self._seed_queue = []
                 return self._finish(st, matches, thr, pre, last_w, all_masks)
             ahead = None
             if have_round(0):
-                h = self._hypotheses(matches, logits, noise_of(0))
+                h = self._hypotheses(matches, logits, noise_of(0), R=plan[0])
                 ahead = (h[0], h[1], h[3])
             r = 0
             want_w = bool(self.weighted and self.solver == "f8" and self.refit)   # (the 7-point solver takes no weights)
@@ -623,30 +734,31 @@ class BatchedRANSAC(object):
                         self._pipe = torch.cuda.Stream(device=dev)
                     self._pipe.wait_stream(main)          # inputs (and, for explicit noise, the caller's tensors) are ready
                     with torch.cuda.stream(self._pipe):
-                        h = self._hypotheses(matches, logits, noise_of(r + 1))
+                        h = self._hypotheses(matches, logits, noise_of(r + 1), R=plan[r + 1])
                         ahead = (h[0], h[1], h[3])
                 if want_w:
                     # pairs still iterating in this round take this round's row-0 soft weights; terminated pairs keep theirs
                     # ("the last batch sampled", per pair)
                     w0 = ops.soft_weights_row0(logits, self.k, self.tau, row0[1], row0[0])
                     last_w = torch.where((st.iters.double() < st.max_iters)[:, None], w0, last_w)
-                flat = models.reshape(P, self.B * self.S, 3, 3)
+                flat = models.reshape(P, -1, 3, 3)
                 scores, masks = ops.msac_score(matches, flat, thr, want_masks=self.keep_masks, valid=valid.reshape(P, -1))
                 if self.keep_masks:
                     all_masks = masks
                 # K6: arg-max, "better?" test, best mask / inlier count and the adaptive stop of ransac.py:135-142, on the device
                 ops.ransac_update(st, matches, flat, valid.reshape(P, -1), scores, thr, self.B, self.k, self.confidence,
-                                  self.eps)
+                                  self.eps, sub_models=sub_of(r))
                 r += 1
                 if not have_round(r):
                     break
                 # host read-back "does any pair continue?" only when another round could follow, and for small batches
                 # only every few rounds (pairs that have terminated are frozen on the device by K6, so a round issued
                 # after the last pair stopped changes nothing)
-                if r % self.sync_every == 0 and not bool((st.iters.double() < st.max_iters).any()):
+                sync_every = max(1, 256 // max(1, self.B * plan[r - 1])) if self.sync_every is None else self.sync_every
+                if r % sync_every == 0 and not bool((st.iters.double() < st.max_iters).any()):
                     break
                 if ahead is None:
-                    h = self._hypotheses(matches, logits, noise_of(r))
+                    h = self._hypotheses(matches, logits, noise_of(r), R=plan[r])
                     ahead = (h[0], h[1], h[3])
                 else:
                     main.wait_stream(self._pipe)

@@ -121,9 +121,13 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
  * `_gated` solver entries below) */
 /* screen_ws (optional; (N + 32) * P words, 16-byte aligned): rows of <= 2048 points then take the screened register kernel -- only
  * the points whose Philox word can lift them to logsumexp(logits) - ln(11 + k) are evaluated (same index sets, bit for bit). */
+/* sub (round 6, super-rounds): > 0 = the B rows are ceil(B / sub) consecutive SUB-BATCHES of `sub` rows, the batches the loop of
+ * ransac.py:55-144 draws one call after the other: row b gets the noise of row b % sub of a call keyed (seed | *seed_dev) + b / sub
+ * (the drivers' per-call seeds are consecutive integers), so ONE launch samples what ceil(B / sub) calls of that loop sample and
+ * dr_ransac_update(sub_models = sub * S) walks them in order.  0 = one batch. */
 int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                                     int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                                    const int32_t *gate_iters, const double *gate_max_iters, void *stream);
+                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, void *stream);
 
 /* Train mode (round 5): K1 WITH the soft-max statistics + K2 in one call (GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42,
  * followed by `matches * ret` + the mask gather of ransac.py:58-65): idx, y_sel [P,B,k], lse [P,B] as dr_gumbel_topk_fwd_f32 and
@@ -386,15 +390,19 @@ int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double 
  *         best_inliers <- model b (mask recomputed), max_iters[p] = min(max_iterations,
  *         log10(1-confidence) / log10(1 - (inliers/N)^k + eps))   (computed in f64);
  *     iters[p] += B.
- *   The caller initialises best_score = 0, iters = 0, max_iters = max_iterations (dr_ransac_init does). */
+ *   The caller initialises best_score = 0, iters = 0, max_iters = max_iterations (dr_ransac_init does).
+ *   sub_models (round 6): 0 (or >= M) = the M models are one batch of B hypotheses.  0 < sub_models < M: they are ceil(M / sub_models)
+ *   consecutive sub-batches of B hypotheses each (at most 512), and the steps above are applied to one sub-batch after the other, IN
+ *   ORDER, stopping as the loop of ransac.py:55 does when iters[p] >= max_iters[p]: the state after the launch is the state that loop
+ *   reaches on the same hypotheses batch by batch -- the reference's `-rbs 64` costs the launches of `-rbs 1024`. */
 int dr_ransac_update_f32(const float *matches, const float *models, const uint8_t *valid, const float *scores,
                          const float *thr, int P, int M, int N, int B, int k, double confidence, double eps,
                          int max_iterations, float *best_score, float *best_model, uint8_t *best_mask,
-                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, int sub_models, void *stream);
 int dr_ransac_update_f64(const double *matches, const double *models, const uint8_t *valid, const double *scores,
                          const double *thr, int P, int M, int N, int B, int k, double confidence, double eps,
                          int max_iterations, double *best_score, double *best_model, uint8_t *best_mask,
-                         int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+                         int32_t *best_inliers, int32_t *iters, double *max_iters, int sub_models, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  final refit, RANSAC.__call__ ransac.py:148-195, batched over pairs (one cooperative block per pair, the ragged

@@ -5,13 +5,15 @@ sys.path.insert(0, ROOT)
 import torch
 from differentiable_ransac_amd import layers, synth
 dev = torch.device('cuda:0')
-pairs, N, B = 32, 2000, 1024
+pairs, N, B = 32, 2000, int(os.environ.get("DROPIN_RBS", 1024))
 d = synth.batch_two_view(pairs, N)
 m, lg, K1, K2 = (d[k].to(dev) for k in ("matches", "logits", "K1", "K2"))
 im = torch.tensor([1000.0, 1000.0], device=dev)
 opt = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=B, tr=False, weighted=0, threshold=0.75, precision=1, device=str(dev))
 layer = layers.RANSACLayer(opt)
 layer.estimator.graph = os.environ.get("DROPIN_GRAPH", "1") == "1"
+if os.environ.get("DROPIN_HYPS"):
+    layer.estimator.graph_hypotheses = tuple(int(x) for x in os.environ["DROPIN_HYPS"].split(","))
 def one_pass():
     return [layer(m[p], lg[p], K1[p], K2[p], im, im, None)[0] for p in range(pairs)]
 for _ in range(3): one_pass()

@@ -120,6 +120,32 @@ def test_device_termination_equals_the_host_loop(dev, solver):
         assert min(its) < max(its), its                     # the pairs really stop after different numbers of batches
 
 
+@pytest.mark.parametrize("solver,B", [("nister", 8), ("stewenius", 8), ("nister", 2)])
+def test_device_termination_with_solver_blocks_spanning_many_pairs(dev, solver, B):
+    """round-5 advice (medium): with ransac_batch_size below half a solver block a block of samples spans three or more pairs; the
+    gate must look at EVERY pair of the block, not only at the first and the last -- here 2304 pairs x 8 (or 2) samples
+    (32- / 8-sample blocks = four pairs each) laid out closed | open | open | closed after the first round"""
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    P = 2304
+    items = [synth.two_view_pair(300 + q, 64, inlier_ratio=(0.95, 0.4, 0.4, 0.95)[q % 4], noise=1e-4) for q in range(8)]
+    st = lambda k: torch.stack([items[p % 8][k] for p in range(P)]).to(dev)
+    m, lg, K1, K2 = st("matches"), st("logits"), st("K1"), st("K2")
+    kw = dict(ransac_batch_size=B, threshold=0.75, max_iterations=4 * B, seed=5, refit=False)
+    host = BatchedRANSAC(solver, **kw)
+    devt = BatchedRANSAC(solver, **kw)
+    devt.device_termination = True
+    a = host(m, lg, K1, K2)
+    b = devt(m, lg, K1, K2)
+    for key in ("model", "mask", "score", "inliers", "iterations"):
+        assert torch.equal(a[key], b[key]), key
+    its = a["iterations"].view(-1, 4)
+    assert int(its.min()) < 4 * B and int(its.max()) == 4 * B
+    # the layout the bug needs: blocks whose edge pairs have stopped while a middle pair has not
+    edge_closed = (its[:, 0] < 4 * B) & (its[:, 3] < 4 * B) & ((its[:, 1] == 4 * B) | (its[:, 2] == 4 * B))
+    assert int(edge_closed.sum()) > 50, int(edge_closed.sum())
+
+
 def test_dropin_ransac_replays_a_graph_per_call(dev):
     """RANSAC.__call__ (test mode, this package's plugins, max_iterations <= 8 batches) = one replayed HIP graph per pair:
     pair after pair the results of a BatchedRANSAC with the same base seed, seeds and termination on the device, run eagerly;

@@ -43,8 +43,17 @@ def test_batched_ransac_configuration_errors():
     with pytest.raises(KeyError):
         BatchedRANSAC("dlt")
     rn = BatchedRANSAC("f8", ransac_batch_size=64)
-    assert (rn.k, rn.S, rn.fmat, rn.sync_every) == (8, 1, True, 4)
-    assert BatchedRANSAC("nister", ransac_batch_size=1024).sync_every == 1
+    assert (rn.k, rn.S, rn.fmat, rn.sync_every) == (8, 1, True, None)
+    # round 6: device rounds of 1024 hypotheses when the batch is smaller (ceil(5000 / 64) = 79 batches), one batch per round otherwise
+    assert rn.plan() == [16, 16, 16, 16, 15] and sum(rn.plan()) == 79
+    rn.super_hypotheses = (1024, 4096)
+    assert rn.plan() == [16, 63]
+    rn.super_hypotheses = False
+    assert rn.plan() == [1] * 79
+    assert BatchedRANSAC("nister", ransac_batch_size=1024).plan() == [1] * 5
+    assert BatchedRANSAC("f8", ransac_batch_size=64, weighted=1).plan() == [1] * 79       # weighted refit: batch by batch
+    assert BatchedRANSAC("nister", ransac_batch_size=1, max_iterations=5000).plan()[0] == 512   # dr_ransac_update's cap
+    assert BatchedRANSAC("nister", ransac_batch_size=1024).sync_every is None      # = max(1, 256 // hypotheses per device round)
 
 
 def test_ops_refuse_cpu_tensors_without_touching_the_gpu():
