@@ -8,6 +8,7 @@
 // stores -- runs the same device code as the per-sample solvers (Jacobi eigen-decomposition, five-point pipeline).
 // The ragged inlier sets never leave the device.
 #include <algorithm>
+#include <cstdlib>
 #include "fivepoint_device.hpp"
 
 namespace dr {
@@ -203,6 +204,17 @@ __global__ __launch_bounds__(kRefT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   }
 }
 
+// A/B knob (DRANSAC_REFIT_PAIR_MIN): launches of at least this many pairs take the wave-cooperative final stage
+static inline int refit_pair_finish_min_pairs() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("DRANSAC_REFIT_PAIR_MIN");
+    v = e ? atoi(e) : kRefitPairFinishMinPairs;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+
 template <typename T>
 int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, const T *weights, int P, int N, T *models,
                  uint8_t *valid, hipStream_t st) {
@@ -217,7 +229,7 @@ int refit_launch(bool fundamental, const T *matches, const uint8_t *mask, const 
       attr_f = true;
     }
     hipLaunchKernelGGL((refit_fundamental_kernel<T>), dim3(P), dim3(kRefT), smem, st, matches, mask, weights, N, models, valid);
-  } else if (P >= kRefitPairFinishMinPairs) {
+  } else if (P >= refit_pair_finish_min_pairs()) {
     const size_t smem_p = std::max(smem, sizeof(double) * (size_t)kNisterPairDoubles);   // the solver's workspace, overlaid
     if (!attr_p) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_essential_kernel<T, true>),

@@ -8,6 +8,7 @@
 // element index each lane uses (e*512 bytes is a multiple of the 256-byte bank row).
 #pragma once
 #include "dr_common.hpp"
+#include "sturm_eval_asm.hpp"
 
 namespace dr {
 
@@ -525,6 +526,17 @@ __device__ __forceinline__ void real_roots_half_wave(const double (&c)[D + 1], b
 // same as the idealised derivative chain misses).  The isolated roots are then refined by the SAME wave-wide task rounds on p
 // (bisection + Newton on a bracket with a sign change), so the final accuracy is the one of the level-D tasks.
 // ------------------------------------------------------------------------------------------------
+#ifndef DR_K3_VAR_SCHED
+#define DR_K3_VAR_SCHED 0
+#endif
+// 1 (round 6): the chain evaluation of the isolation step as one hand-scheduled asm block (sturm_eval_asm.hpp): bit-identical roots,
+// 66 instead of ~130 instructions per evaluation; Nister 159.7 -> 156.3 us, Stewenius 192.6 -> 189.2 us at 131 072 samples (same box)
+#ifndef DR_K3_VAR_ASM
+#define DR_K3_VAR_ASM 1
+#endif
+#ifndef DR_K3_TASK_ESTRIN
+#define DR_K3_TASK_ESTRIN 0
+#endif
 template <int D>
 struct SturmWs {
   double *lo, *hi;     // D x 64 each: entry e of lane l at [e * 64 + l]; after the refine tasks lo holds the root
@@ -536,6 +548,35 @@ struct SturmWs {
       : lo(ws), hi(ws + D * 64), vv(reinterpret_cast<uint32_t *>(ws + 2 * D * 64)), q(ws + 2 * D * 64 + D * 64 / 2),
         queue(reinterpret_cast<uint16_t *>(ws + 2 * D * 64 + D * 64 / 2 + (D + 1) * 64)) {}
 };
+
+// Estrin's scheme for the refine tasks (round 6, DR_K3_TASK_ESTRIN): a bracket's bisection / Newton steps are one dependent chain per
+// task, and a wave alone on its SIMD waits ~8.5 clocks for every dependent v_fma_f64 -- Horner's rule for degree 10 is ten of them in
+// a row.  Pairing the coefficients (q0 + q1 x) + x^2 (q2 + q3 x) ... costs three squarings and three more FMAs and is four levels deep.
+template <int D>
+__device__ __forceinline__ double estrin_eval(const double (&q)[D + 1], double x) {
+  static_assert(D == 10, "written out for the degree-10 polynomials of the five-point solvers");
+  const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+  const double a0 = __builtin_fma(q[1], x, q[0]), a1 = __builtin_fma(q[3], x, q[2]), a2 = __builtin_fma(q[5], x, q[4]);
+  const double a3 = __builtin_fma(q[7], x, q[6]), a4 = __builtin_fma(q[9], x, q[8]);
+  const double b0 = __builtin_fma(a1, x2, a0), b1 = __builtin_fma(a3, x2, a2), b2 = __builtin_fma(q[10], x2, a4);
+  const double c0 = __builtin_fma(b1, x4, b0);
+  return __builtin_fma(b2, x8, c0);
+}
+// value and derivative: p' = sum (j + 1) q[j + 1] x^j, degree 9, by the same pairing
+template <int D>
+__device__ __forceinline__ void estrin_eval_d(const double (&q)[D + 1], double x, double &fx, double &dfx) {
+  static_assert(D == 10, "written out for the degree-10 polynomials of the five-point solvers");
+  const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+  const double a0 = __builtin_fma(q[1], x, q[0]), a1 = __builtin_fma(q[3], x, q[2]), a2 = __builtin_fma(q[5], x, q[4]);
+  const double a3 = __builtin_fma(q[7], x, q[6]), a4 = __builtin_fma(q[9], x, q[8]);
+  const double b0 = __builtin_fma(a1, x2, a0), b1 = __builtin_fma(a3, x2, a2), b2 = __builtin_fma(q[10], x2, a4);
+  fx = __builtin_fma(b2, x8, __builtin_fma(b1, x4, b0));
+  const double e0 = __builtin_fma(2.0 * q[2], x, q[1]), e1 = __builtin_fma(4.0 * q[4], x, 3.0 * q[3]);
+  const double e2 = __builtin_fma(6.0 * q[6], x, 5.0 * q[5]), e3 = __builtin_fma(8.0 * q[8], x, 7.0 * q[7]);
+  const double e4 = __builtin_fma(10.0 * q[10], x, 9.0 * q[9]);
+  const double g0 = __builtin_fma(e1, x2, e0), g1 = __builtin_fma(e3, x2, e2);
+  dfx = __builtin_fma(e4, x8, __builtin_fma(g1, x4, g0));
+}
 
 // the refine rounds: root_tasks with the bracket ends in separate arrays and the polynomial always of degree D
 template <int D, int R>
@@ -563,9 +604,13 @@ __device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const double m = 0.5 * (a[r] + b[r]);
+#if DR_K3_TASK_ESTRIN
+        const double fx = estrin_eval<D>(qq[r], m);
+#else
         double fx = qq[r][D];
 #pragma unroll
         for (int k = D - 1; k >= 0; --k) fx = fx * m + qq[r][k];
+#endif
         const bool left = (fx < 0) == neg[r], hit = fx == 0.0;   // a midpoint that IS the root closes the bracket on it
         a[r] = (left || hit) ? m : a[r];
         b[r] = (left && !hit) ? b[r] : m;
@@ -577,12 +622,17 @@ __device__ __forceinline__ void sturm_tasks(const SturmWs<D> &ws, int total, int
     for (int it = 0; it < kNewt; ++it) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+#if DR_K3_TASK_ESTRIN
+        double fx, dfx;
+        estrin_eval_d<D>(qq[r], y[r], fx, dfx);
+#else
         double fx = qq[r][D], dfx = 0;
 #pragma unroll
         for (int k = D - 1; k >= 0; --k) {
           dfx = dfx * y[r] + fx;
           fx = fx * y[r] + qq[r][k];
         }
+#endif
         const bool left = (fx < 0) == neg[r];
         a[r] = left ? y[r] : a[r];
         b[r] = left ? b[r] : y[r];
@@ -817,13 +867,27 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
   auto variations = [&](double x) -> unsigned {
     // all Horner chains advance together (step i touches every polynomial that still has a coefficient left): eleven independent
     // dependency chains instead of one after the other
+#if DR_K3_VAR_ASM
+    if constexpr (D == 10) {
+      // round 6: the 55 FMAs as one hand-scheduled asm block (csrc/sturm_eval_asm.hpp), the sign bits by v_alignbit_b32
+      const unsigned w = sturm_signs10(F, x);
+      const unsigned ch = (w ^ (w >> 1)) & ((1u << D) - 1u);
+      return (unsigned)__popc(ch) | ((w & 1u) << 4);
+    }
+#endif
     double val[D + 1];
 #pragma unroll
     for (int k = 0; k <= D; ++k) val[k] = F[k][D - k];
 #pragma unroll
-    for (int i = 1; i <= D; ++i)
+    for (int i = 1; i <= D; ++i) {
 #pragma unroll
       for (int k = 0; k + i <= D; ++k) val[k] = val[k] * x + F[k][D - k - i];
+#if DR_K3_VAR_SCHED
+      // round 6: the scheduler, short of registers, otherwise runs the chains one after the other (a dependent v_fma_f64 every
+      // ~8.5 clocks at one wave per SIMD instead of an independent one every ~4.3): nothing moves across a Horner level
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     unsigned w = 0;
 #pragma unroll
     for (int k = 0; k <= D; ++k) w |= ((unsigned)__double2hiint(val[k]) >> 31) << k;
