@@ -113,15 +113,23 @@ def batched_forward(opt, points, weights, K1, K2, im_size1=None, im_size2=None, 
                                max_iterations=max_iters, weighted=opt.weighted)
     pts = points
     if opt.fmat:
-        pts = points.clone()
-        for p in range(P):
-            pts[p, :, 0:2] = denormalize_pts(points[p, :, 0:2], im_size1[p])
-            pts[p, :, 2:4] = denormalize_pts(points[p, :, 2:4], im_size2[p])
+        # cv_utils.denormalize_pts (:35-45) for all pairs at once: pts * max(im_size) + (width / 2, height / 2), the maximum taken
+        # ON THE DEVICE (round 5 looped over the pairs with Python's max() on device tensors: one synchronisation per pair and image)
+        def denorm(xy, im):
+            im = im.to(xy)
+            return xy * im.max(-1).values[:, None, None] + torch.stack((im[:, 1] / 2, im[:, 0] / 2), -1)[:, None, :]
+        pts = torch.cat((denorm(points[..., 0:2], im_size1), denorm(points[..., 2:4], im_size2)), -1)
     t0 = time.time()
     if opt.tr:
         chosen, keep = driver(pts, weights, K1, K2, gt_model=gt)
-        ret = [chosen[p][keep[p]] for p in range(P)]
+        # The reference's `ret` is ragged (per pair the models that survived, model_cl.py:240-242).  ONE read-back for the whole
+        # batch -- the per-pair counts -- instead of a boolean-mask gather (= a synchronisation) per pair: a stable sort moves every
+        # pair's kept models to the front in their original order, the per-pair results are views of that tensor.
+        counts = keep.sum(1)
+        order = torch.argsort((~keep).to(torch.uint8), dim=1, stable=True)
+        packed = torch.gather(chosen, 1, order[:, :, None, None].expand(-1, -1, 3, 3))
+        ret = [packed[p, :n] for p, n in enumerate(counts.tolist())]
     else:
         out = driver(pts, weights, K1, K2)
-        ret = [out["model"][p] for p in range(P)]
+        ret = list(out["model"].unbind(0))
     return ret, (time.time() - t0) / P

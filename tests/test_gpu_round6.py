@@ -180,3 +180,53 @@ def test_reference_test_run_through_super_rounds(dev, name):
     assert (O.canonical(out["model"][0].cpu().double()) - O.canonical(mo)).abs().max() < 1e-4
     assert abs(int(out["iterations"][0]) - int(g["iterations"])) <= 2 * B
     assert abs(int(out["mask"][0].sum()) - int(g["best_mask"].sum())) <= 3
+
+
+def test_batched_forward_has_no_per_pair_synchronisation(dev):
+    """layers.batched_forward (model_cl.py:240-242,488-511 as one call): train mode hands out the ragged per-pair model lists from ONE
+    read-back, the F branch de-normalises all pairs in one expression -- no aten::nonzero / aten::item per pair in a profiler trace of
+    a 32-pair call; the lists equal the per-pair boolean-mask gathers, gradients flow to the logits"""
+    import types
+    from torch.profiler import ProfilerActivity, profile
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.layers import batched_forward, denormalize_pts
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    P, N, B = 32, 512, 64
+    data = synth.batch_two_view(P, N, seed0=130)
+    m, lg, K1, K2, gt = (data[k].to(dev) for k in ("matches", "logits", "K1", "K2", "gt_E"))
+    opt = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=B, tr=True, weighted=0, threshold=0.75, precision=1, device="cuda")
+    drv = BatchedRANSAC("nister", ransac_batch_size=B, train=True, threshold=0.75, max_iterations=100, seed=4)
+    lg_a = lg.clone().requires_grad_(True)
+    batched_forward(opt, m, lg_a, K1, K2, gt=gt, driver=drv)             # warm-up (first-call attributes, allocator)
+    drv.calls = 0
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        ret, _ = batched_forward(opt, m, lg_a, K1, K2, gt=gt, driver=drv)
+    names = [e.name for e in prof.events()]
+    assert names.count("aten::nonzero") == 0, names.count("aten::nonzero")
+    assert names.count("aten::item") + names.count("aten::_local_scalar_dense") <= 2 * 2     # the ONE counts.tolist()
+    # the same call by hand: boolean-mask gather per pair
+    drv.calls = 0
+    chosen, keep = drv(m, lg, K1, K2, gt_model=gt)
+    assert len(ret) == P
+    for p in range(P):
+        assert torch.equal(ret[p], chosen[p][keep[p]]), p
+    torch.cat(ret).square().sum().backward()
+    assert torch.isfinite(lg_a.grad).all() and float(lg_a.grad.abs().sum()) > 0
+    # F branch, test mode: the vectorised de-normalisation = cv_utils.denormalize_pts per pair
+    dpx = synth.batch_two_view(4, 256, seed0=140)
+    im1 = torch.tensor([[480.0, 640.0], [600.0, 800.0], [1000.0, 1000.0], [768.0, 1024.0]], device=dev)
+    im2 = im1.flip(0).contiguous()
+    norm = dpx["matches"].to(dev) / 1000.0
+    optf = types.SimpleNamespace(fmat=True, sampler=3, ransac_batch_size=64, tr=False, weighted=0, threshold=0.75, precision=1, device="cuda")
+    seen = {}
+
+    class Spy(BatchedRANSAC):
+        def __call__(self, pts, *a, **k):
+            seen["pts"] = pts
+            return super().__call__(pts, *a, **k)
+    retf, _ = batched_forward(optf, norm, dpx["logits"].to(dev), None, None, im1, im2,
+                              driver=Spy("f8", ransac_batch_size=64, threshold=0.75, max_iterations=128))
+    assert len(retf) == 4 and retf[0].shape == (3, 3)
+    for p in range(4):
+        want = torch.cat((denormalize_pts(norm[p, :, 0:2], im1[p]), denormalize_pts(norm[p, :, 2:4], im2[p])), -1)
+        assert torch.equal(seen["pts"][p], want), p

@@ -103,3 +103,72 @@ def test_world_size_two_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _worker8(rank, world, port, q):
+    """BASELINE configs[4] at its own world size: 256 pairs -> 32 per rank, one flat bucket of 622 616 f32, overlapped"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = 256
+        lo, hi = sharding.pair_range(P, rank, world)
+        assert hi - lo == 32 and lo == 32 * rank
+        # every pair is owned exactly once: gather the owners of the job's pairs
+        own = torch.zeros(P, dtype=torch.int64)
+        own[lo:hi] = 1
+        dist.all_reduce(own)
+        assert own.tolist() == [1] * P
+        # a per-pair result (the pair's index, computed on the owning rank) gathered back in pair order
+        got = sharding.gather_results(torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 9), P, dist)
+        assert got.shape == (P, 9) and torch.equal(got[:, 0], torch.arange(P, dtype=torch.float32))
+        # whole-job throughput: sum of the ranks' hypotheses over the slowest rank's time
+        hyps, secs = sharding.job_throughput(32 * 1024, 1.0 + 0.1 * rank, dist)
+        assert abs(secs - 1.7) < 1e-12 and abs(hyps - 256 * 1024 / 1.7) < 1e-6
+        # hypothesis split over 8 ranks (P < G): best score per pair over the ranks, ties to the lowest rank, NaN never wins
+        sc = torch.tensor([float(rank), float(7 - rank), 3.0, float("nan") if rank != 5 else 0.25])
+        md = torch.full((4, 3, 3), float(rank))
+        s, m, w = sharding.merge_best(sc, md, (), dist)[:3]
+        assert w.tolist() == [7, 0, 0, 5] and s.tolist() == [7.0, 7.0, 3.0, 0.25]
+        assert torch.equal(m[:, 0, 0], w.float())
+        assert len({sharding.hypothesis_seed(11, r) for r in range(world)}) == world
+        # the train step's bucket, asynchronously, over 8 ranks: mean of (rank + 1) * (i + 1) over the ranks = 4.5 (i + 1)
+        bucket = sharding.AsyncGradientBucket(622616, "cpu", dist)
+        n = [0]
+
+        def fake_step():
+            bucket.bucket().fill_(float((rank + 1) * (n[0] + 1)))
+            n[0] += 1
+        reduced = []
+        step = sharding.OverlappedStep(fake_step, bucket, on_reduced=lambda t, i: reduced.append((i, float(t[0]), float(t[-1]))))
+        for _ in range(3):
+            step()
+        bucket.drain()
+        tr = bucket.trace
+        for i in range(2):
+            assert tr.index(("enqueued", i + 1)) < tr.index(("wait", i)) < tr.index(("launch", i + 1)), tr
+        assert reduced == [(0, 4.5, 4.5), (1, 9.0, 9.0)], reduced
+        assert float(bucket.buf[0][0]) == 13.5
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        assert int(one.item()) == world
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_eight_gloo():
+    """the target world size of BASELINE configs[4] (8 ranks x 32 pairs) on CPU processes"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(8)], res
