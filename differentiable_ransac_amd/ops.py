@@ -230,13 +230,19 @@ import os as _os
 SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 
 
+# Round 6: the exponential-race form of the index-only sampler (one logarithm per element; dr_gumbel_topk_gather_gated_f32's race_ws).
+# Same top-k up to the rounding of near-ties; off = the two-logarithm form of rounds 1-5 (A/B runs, tests: DRANSAC_K1_RACE=0).
+K1_RACE = _os.environ.get("DRANSAC_K1_RACE", "1") != "0"
+
+
 def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None,
-                       screen: Optional[bool] = None, sub: int = 0):
+                       screen: Optional[bool] = None, sub: int = 0, race: Optional[bool] = None):
     """K1 (index sets only, in-kernel noise) + K2 in one call: matches [P,N,4] f32, logits [P,N] f32 ->
     (idx [P,B,k] int32 ascending, samples [P,B,k,4] = matches[p, idx]).  What test mode asks of sampler + gather
     (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor.
     sub > 0 (super-rounds): the B rows are consecutive sub-batches of `sub` rows; row b draws what row b % sub of the call with
-    seed + b // sub draws (the drivers' per-call seeds are consecutive integers)."""
+    seed + b // sub draws (the drivers' per-call seeds are consecutive integers).
+    race (None = the module default K1_RACE): the one-logarithm exponential-race form of the same top-k (rows of <= 2048 points)."""
     if matches.dtype != torch.float32 or logits.dtype != torch.float32 or matches.shape[-1] != 4:
         raise L.DransacError("gumbel_topk_gather: f32 two-view correspondences [P,N,4]")
     matches, logits = matches.contiguous(), logits.contiguous()
@@ -248,11 +254,13 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
     want_screen = SCREEN_SHORT_ROWS if screen is None else screen
     ws = (torch.empty((P, N + 32), device=logits.device, dtype=torch.int32)
           if want_screen and N <= 2048 and N % 4 == 0 and tau == 1.0 and k <= 5 and B >= 64 else None)
-    if gate is not None or ws is not None or sub:     # (gate: a later round of a multi-round call, terminated pairs are skipped)
+    want_race = (K1_RACE if race is None else race) and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
+    rws = torch.empty((P, N + 32), device=logits.device, dtype=torch.float32) if want_race else None
+    if gate is not None or ws is not None or sub or rws is not None:     # (gate: a later round of a multi-round call, terminated pairs are skipped)
         L.call("dr_gumbel_topk_gather_gated_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
                ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
                ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters),
-               c_int(0 if sub >= B else int(sub)), stream())
+               c_int(0 if sub >= B else int(sub)), ptr(rws), stream())
         return idx, samples
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
            ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples), stream())

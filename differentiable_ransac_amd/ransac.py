@@ -849,10 +849,10 @@ class BatchedRANSAC3D(object):
                 if matches.dtype == torch.float32:
                     # K2 + K3r in one launch (samples read through the index sets), the round's residual sums cleared on the way
                     # the residual sums are ACCUMULATED (atomics: order-nondeterministic in the last bits) into a buffer that
-                    # dr_solve_rigid_gather_f32 clears; outside a graph capture it also starts from zeros, so that an error
-                    # between the two launches can never leave garbage sums (round-4 advice; under capture: no extra node)
-                    alloc = torch.empty if torch.cuda.is_current_stream_capturing() else torch.zeros
-                    res = alloc((P, self.B), device=matches.device, dtype=torch.float32)
+                    # dr_solve_rigid_gather_f32 clears.  (Rounds 4-5 also zero-filled it outside a graph capture -- a 5 us torch fill
+                    # launch per round in the eager step, round-5 review; an error between the two launches raises, so nobody reads
+                    # the buffer then.)
+                    res = torch.empty((P, self.B), device=matches.device, dtype=torch.float32)
                     model, valid = ops.solve_rigid_gather(matches, idx, self.flag, zero_sums=res)
                     res, masks = ops.rigid_residual(matches, model, self.threshold, self.keep_masks, res=res)
                 else:

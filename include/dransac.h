@@ -125,9 +125,14 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
  * ransac.py:55-144 draws one call after the other: row b gets the noise of row b % sub of a call keyed (seed | *seed_dev) + b / sub
  * (the drivers' per-call seeds are consecutive integers), so ONE launch samples what ceil(B / sub) calls of that loop sample and
  * dr_ransac_update(sub_models = sub * S) walks them in order.  0 = one batch. */
+/* race_ws (round 6; optional, (N + 32) * P floats, 16-byte aligned, not together with screen_ws): rows of <= 2048 points (N % 4 == 0,
+ * tau == 1) then rank key_n = exp(lmax - logit_n) * log2 u_n instead of logit_n - ln(-ln u_n) -- the exponential-race form of the
+ * same top-k (gumbel_sampler.py:30-36), ONE logarithm per element; the per-pair weights are written into the workspace by a
+ * prologue launch.  Same index sets up to the rounding of near-ties (measured: tests/test_gpu_round6.py); pairs whose logits are
+ * not all finite or span more than 80 keep the two-logarithm form. */
 int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                                     int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, void *stream);
+                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream);
 
 /* Train mode (round 5): K1 WITH the soft-max statistics + K2 in one call (GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42,
  * followed by `matches * ret` + the mask gather of ransac.py:58-65): idx, y_sel [P,B,k], lse [P,B] as dr_gumbel_topk_fwd_f32 and

@@ -7,15 +7,17 @@ variants = {'base': [], 'general': ['-DDR_K1_FAST=0'], 'nolog': ['-DDR_K1_NOISE_
             'philox0_nolog': ['-DDR_PHILOX_ROUNDS=0', '-DDR_K1_NOISE_EXPERIMENT=1']}
 if '--build' in sys.argv:
     for name, flags in variants.items():
+        if [a for a in sys.argv[1:] if not a.startswith('--')] and name not in sys.argv: continue
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast', *flags,
                                '-Iinclude', '-o', f'scratch/libk1_{name}.so', 'differentiable_ransac_amd/csrc/gumbel_topk.hip', 'differentiable_ransac_amd/csrc/dr_core.hip'])
     sys.exit(0)
 import torch
 from differentiable_ransac_amd import synth
-dev = 'cuda'; P, N, B, k = 32, 2000, 1024, 5
+dev = 'cuda'; P, N, B, k = int(os.environ.get('AB_K1_PAIRS', 32)), 2000, 1024, 5
 lg = synth.batch_two_view(P, N)['logits'].to(dev)
 idx = torch.empty(P, B, k, device=dev, dtype=torch.int32); ys = torch.empty(P, B, k, device=dev); lse = torch.empty(P, B, device=dev)
-for name in variants:
+names = [a for a in sys.argv[1:] if not a.startswith('--')] or list(variants)
+for name in names:
     lib = ctypes.CDLL(os.path.abspath(f'scratch/libk1_{name}.so'))
     cp = lambda t: ctypes.c_void_p(t.data_ptr())
     for mode, (a_y, a_l) in (('index sets only (test mode)', (None, None)), ('with soft-max statistics (train mode)', (cp(ys), cp(lse)))):

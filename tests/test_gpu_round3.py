@@ -74,6 +74,10 @@ def test_bench_plain_launch_two_ranks_on_one_gpu():
         assert rec["collective_ms"] is not None
         if mode == "train":
             assert rec["collective_ms"] > 0 and rec["grad_finite"]
+            # round 6: the line says which pairs every rank owned and that step i + 1 was enqueued before the wait on bucket i
+            part = rec["pair_partition"]
+            assert part["total_pairs"] == 16 and part["ranges"] == [[0, 8], [8, 16]] and part["covers_once"] and part["equals_pair_range"]
+            assert rec["overlap_trace_ok"] is True
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -206,7 +206,7 @@ def test_batched_forward_has_no_per_pair_synchronisation(dev):
     assert names.count("aten::item") + names.count("aten::_local_scalar_dense") <= 2 * 2     # the ONE counts.tolist()
     # the same call by hand: boolean-mask gather per pair
     drv.calls = 0
-    chosen, keep = drv(m, lg, K1, K2, gt_model=gt)
+    chosen, keep = drv(m, lg.clone().requires_grad_(True), K1, K2, gt_model=gt)     # (the same autograd path: logits that require grad)
     assert len(ret) == P
     for p in range(P):
         assert torch.equal(ret[p], chosen[p][keep[p]]), p
@@ -230,3 +230,39 @@ def test_batched_forward_has_no_per_pair_synchronisation(dev):
     for p in range(4):
         want = torch.cat((denormalize_pts(norm[p, :, 0:2], im1[p]), denormalize_pts(norm[p, :, 2:4], im2[p])), -1)
         assert torch.equal(seen["pts"][p], want), p
+
+
+def test_one_logarithm_sampler_draws_the_same_index_sets(dev):
+    """K1 in the exponential-race form (round 6: key = exp(lmax - logit) * log2 u, one logarithm per element) against the two-logarithm
+    form of rounds 1-5 (logit - ln(-ln u)) and against the f32 oracle on the noise the general kernel dumps for the same seed
+    (gumbel_sampler.py:30-36): same index sets (32 x 1024 x 2000 here; 0 of 131 072 rows differed at 128 pairs on two seeds,
+    scratch/k1_race_check.py); wild logits (one-hot, non-finite, a span beyond 80) keep the two-logarithm form, bit for bit"""
+    from differentiable_ransac_amd import ops, synth
+    P, B, N, k = 32, 1024, 2000, 5
+    d = synth.batch_two_view(P, N, seed0=11)
+    m, lg = d["matches"].to(dev), d["logits"].to(dev)
+    ia, sa = ops.gumbel_topk_gather(m, lg, B, k, 1.0, 99, race=True)
+    ib, sb = ops.gumbel_topk_gather(m, lg, B, k, 1.0, 99, race=False)
+    differ = int((ia != ib).any(-1).sum())
+    assert differ <= 1, differ                                   # (near-ties at rounding level are the only legitimate differences)
+    assert torch.equal(sa[(ia == ib).all(-1)], sb[(ia == ib).all(-1)])
+    r = ops.gumbel_topk(lg[:8], B, k, 1.0, None, 99, want_noise=True)
+    top = torch.topk(lg[:8, None, :] + r["gumbel"], k, dim=-1).indices.sort(-1).values.int()
+    assert int((top != ia[:8]).any(-1).sum()) <= 1
+    # sub-batches (super-rounds) through the race form: row b = row b % sub of the call seeded seed + b // sub
+    isub, _ = ops.gumbel_topk_gather(m, lg, 4 * 64, k, 1.0, 5, sub=64, race=True)
+    for j in range(4):
+        ij, _ = ops.gumbel_topk_gather(m, lg, 64, k, 1.0, 5 + j, race=True)
+        assert torch.equal(isub[:, 64 * j:64 * (j + 1)], ij), j
+    # wild logits: the flagged pairs take the two-logarithm form
+    wild = lg.clone()
+    wild[0] = -1000.0
+    wild[0, 17] = 0.0                                             # one-hot: span 1000
+    wild[1, 5] = float("-inf")
+    wild[2, 7] = float("nan")
+    wild[3] = torch.linspace(-100.0, 0.0, N, device=dev)          # span 100 > 80
+    iw, _ = ops.gumbel_topk_gather(m, wild, B, k, 1.0, 3, race=True)
+    ix, _ = ops.gumbel_topk_gather(m, wild, B, k, 1.0, 3, race=False)
+    assert torch.equal(iw[:4], ix[:4])
+    assert int((iw[4:] != ix[4:]).any(-1).sum()) <= 1
+    assert (iw[0] == 17).any(-1).all() and not (iw[1] == 5).any() and not (iw[2] == 7).any()
