@@ -430,8 +430,13 @@ int stewenius_launch(const T *samples, int Bt, T *models, uint8_t *valid, hipStr
 // ---- test hook: the real-root search of the two-lanes-per-sample kernels on given degree-10 polynomials -------------------
 // One lane pair per polynomial (even lane: |z| <= 1, odd lane: |z| > 1 through the reversed polynomial), exactly as the solver
 // kernels call it.  method 0 = derivative chain (real_roots_half_wave), 1 = Sturm isolation (real_roots_half_sturm).
+// DR_DBG_ROOTS_WAVES (round 6 experiment): waves per SIMD the standalone root-search kernel is compiled for -- what a separate
+// root-search LAUNCH between a front and a finish kernel would run at (scratch/roots_occupancy.py)
+#ifndef DR_DBG_ROOTS_WAVES
+#define DR_DBG_ROOTS_WAVES 1
+#endif
 template <int kMethod>
-__global__ __launch_bounds__(64) void debug_roots10_kernel(const double *__restrict__ coef, int n, double *__restrict__ roots,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DR_DBG_ROOTS_WAVES, DR_DBG_ROOTS_WAVES))) void debug_roots10_kernel(const double *__restrict__ coef, int n, double *__restrict__ roots,
                                                            int32_t *__restrict__ counts) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x, half = lane & 1;
@@ -482,8 +487,9 @@ int dr_debug_real_roots10(const double *coef, int n, int method, double *roots, 
   DR_REQUIRE(n > 0 && (method == 0 || method == 1), "need n > 0 and method 0 (derivative chain) or 1 (Sturm)");
   constexpr int kD = dr::RootWs<10>::kDoubles > dr::SturmWs<10>::kDoubles ? dr::RootWs<10>::kDoubles : dr::SturmWs<10>::kDoubles;
   const size_t smem = sizeof(double) * kD;
-  if (method == 1)
-    hipLaunchKernelGGL((dr::debug_roots10_kernel<1>), dim3((n + 31) / 32), dim3(64), smem, (hipStream_t)stream, coef, n, roots, counts);
+  if (method == 1)   // (the Sturm search's own workspace, 19.7 KB: eight blocks per CU fit when the kernel is built for two waves per SIMD)
+    hipLaunchKernelGGL((dr::debug_roots10_kernel<1>), dim3((n + 31) / 32), dim3(64), sizeof(double) * dr::SturmWs<10>::kDoubles,
+                       (hipStream_t)stream, coef, n, roots, counts);
   else
     hipLaunchKernelGGL((dr::debug_roots10_kernel<0>), dim3((n + 31) / 32), dim3(64), smem, (hipStream_t)stream, coef, n, roots, counts);
   return dr::check_launch("debug_roots10_kernel");
