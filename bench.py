@@ -329,7 +329,7 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
            "reference_import_hypotheses_per_s": REFERENCE_IMPORT.get(key)}
     score_call = "dr_msac_score_f32"
     if w["solver"] == "rigid":
-        score_call = "dr_rigid_residual_acc_f32" if "dr_rigid_residual_acc_f32" in calls else "dr_rigid_residual_f32"
+        score_call = "dr_rigid_residual_f32"
     if score_call in calls:
         nbytes = k4r_bytes(P, N, M) if w["solver"] == "rigid" else k4_bytes(P, N, M)
         ach = nbytes / (calls[score_call] * 1e-3) / 1e9
@@ -852,7 +852,7 @@ def main():
     rn, matches, logits, S = info["rn"], info["matches"], info["logits"], info["S"]
     K1, K2 = info["K"]
     M = w["hyps"] * S
-    score_prefix = "dr_rigid_residual_" if w["solver"] == "rigid" else "dr_msac_score_f"   # (..._acc_f32 in the 3-D driver)
+    score_prefix = "dr_rigid_residual_" if w["solver"] == "rigid" else "dr_msac_score_f"
     n_seg = max(1, args.segments)
     timer = CallTimer((score_prefix,), args.steps * n_seg)
 

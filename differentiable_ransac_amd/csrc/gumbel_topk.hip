@@ -1561,26 +1561,34 @@ extern "C" {
   DR_REQUIRE(k >= 1 && k <= dr::kMaxK && k <= N, "k must be in [1, 8] and <= N");  \
   DR_REQUIRE(tau > 0, "tau must be positive")
 
-int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
-                           int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,
+// seed_dev (every sampler entry, round 6: one entry per sampler instead of a `_dseed` twin): != NULL = the Philox key is read from
+// device memory when the kernel starts -- what a captured graph needs (a by-value seed would be frozen into it; dr_seed_next_n
+// advances such a seed on the device); it serves the in-kernel noise of given logits (no explicit noise, no dense outputs)
+#define DR_SEED_DEV_CHECK()                                                                                              \
+  DR_REQUIRE(!seed_dev || (logits && !gumbel && !y_soft && !ret && !gumbel_out), "a device seed serves the in-kernel noise of given logits only")
+int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B,
+                           int N, int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,
                            float *gumbel_out, void *stream) {
   DR_GUMBEL_CHECK();
+  DR_SEED_DEV_CHECK();
   return dr::gumbel_fwd_launch<float>(logits, gumbel, seed, tau, P, B, N, k, idx, y_sel, lse, y_soft, ret, gumbel_out,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, seed_dev);
 }
 
-int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B,
-                           int N, int k, int32_t *idx, double *y_sel, double *lse, double *y_soft, double *ret,
+int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t seed, const uint64_t *seed_dev, double tau, int P,
+                           int B, int N, int k, int32_t *idx, double *y_sel, double *lse, double *y_soft, double *ret,
                            double *gumbel_out, void *stream) {
   DR_GUMBEL_CHECK();
+  DR_SEED_DEV_CHECK();
   return dr::gumbel_fwd_launch<double>(logits, gumbel, seed, tau, P, B, N, k, idx, y_sel, lse, y_soft, ret,
-                                       gumbel_out, (hipStream_t)stream);
+                                       gumbel_out, (hipStream_t)stream, seed_dev);
 }
 
-int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
-                           int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
+int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B,
+                           int N, int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
                            void *stream) {
-  return gumbel_bwd_f32_impl(logits, gumbel, seed, nullptr, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
+  DR_REQUIRE(!seed_dev || (logits && !gumbel), "a device seed serves the in-kernel noise of given logits only");
+  return gumbel_bwd_f32_impl(logits, gumbel, seed, seed_dev, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
 }
 
 // f64 (`-pr 2 -tr 1`, model_cl.py:164-169): the same kernel in double (general form: two logarithms + an exponential per element)
@@ -1590,9 +1598,9 @@ int dr_gumbel_topk_bwd_f64(const double *logits, const double *gumbel, uint64_t 
   return gumbel_bwd_impl<double>(logits, gumbel, seed, nullptr, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
 }
 
-int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
-                          void *stream) {
-  return topdown_impl<float>(logits, seed, nullptr, P, B, N, k, cdf_ws, idx, stream);
+int dr_topdown_sample_f32(const float *logits, uint64_t seed, const uint64_t *seed_dev, int P, int B, int N, int k, double *cdf_ws,
+                          int32_t *idx, void *stream) {
+  return topdown_impl<float>(logits, seed, seed_dev, P, B, N, k, cdf_ws, idx, stream);
 }
 
 int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
@@ -1600,57 +1608,17 @@ int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int
   return topdown_impl<double>(logits, seed, nullptr, P, B, N, k, cdf_ws, idx, stream);
 }
 
-int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream) {
-  return uniform_impl(seed, nullptr, P, B, k, N, idx, stream);
+int dr_uniform_sample(uint64_t seed, const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream) {
+  return uniform_impl(seed, seed_dev, P, B, k, N, idx, stream);
 }
 
 // ---- the same samplers with the Philox key read from device memory (*seed_dev) when the kernel starts: what a captured
 //      graph needs (a by-value seed would be frozen into the graph); dr_seed_next advances such a seed on the device
-int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream) {
-  DR_REQUIRE(state && seed_out, "null pointer");
-  hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seed_out, 1);
-  return dr::check_launch("seed_next_kernel");
-}
 int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream) {
   DR_REQUIRE(state && seeds_out, "null pointer");
   DR_REQUIRE(n >= 1 && n <= 65536, "1 <= n <= 65536 seeds per launch");
   hipLaunchKernelGGL(dr::seed_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, seeds_out, n);
   return dr::check_launch("seed_next_kernel");
-}
-
-int dr_gumbel_topk_fwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
-                                 int32_t *idx, float *y_sel, float *lse, void *stream) {
-  const float *y_soft = nullptr, *ret = nullptr;
-  DR_REQUIRE(seed_dev, "null seed pointer");
-  DR_GUMBEL_CHECK();
-  return dr::gumbel_fwd_launch<float>(logits, nullptr, 0, tau, P, B, N, k, idx, y_sel, lse, nullptr, nullptr, nullptr,
-                                      (hipStream_t)stream, seed_dev);
-}
-
-int dr_gumbel_topk_fwd_f64_dseed(const double *logits, const uint64_t *seed_dev, double tau, int P, int B, int N, int k,
-                                 int32_t *idx, double *y_sel, double *lse, void *stream) {
-  const double *y_soft = nullptr, *ret = nullptr;
-  DR_REQUIRE(seed_dev, "null seed pointer");
-  DR_GUMBEL_CHECK();
-  return dr::gumbel_fwd_launch<double>(logits, nullptr, 0, tau, P, B, N, k, idx, y_sel, lse, nullptr, nullptr, nullptr,
-                                       (hipStream_t)stream, seed_dev);
-}
-
-int dr_gumbel_topk_bwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
-                                 const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits, void *stream) {
-  DR_REQUIRE(seed_dev, "null seed pointer");
-  return gumbel_bwd_f32_impl(logits, nullptr, 0, seed_dev, tau, P, B, N, k, idx, lse, a_sel, grad_logits, stream);
-}
-
-int dr_topdown_sample_f32_dseed(const float *logits, const uint64_t *seed_dev, int P, int B, int N, int k, double *cdf_ws,
-                                int32_t *idx, void *stream) {
-  DR_REQUIRE(seed_dev, "null seed pointer");
-  return topdown_impl<float>(logits, 0, seed_dev, P, B, N, k, cdf_ws, idx, stream);
-}
-
-int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream) {
-  DR_REQUIRE(seed_dev, "null seed pointer");
-  return uniform_impl(0, seed_dev, P, B, k, N, idx, stream);
 }
 
 // K1 (index sets only) + K2 in one call: idx [P,B,k] and samples [P,B,k,4] = matches[p, idx] (test mode: the points themselves,
@@ -1671,11 +1639,6 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
                      (const float *)nullptr, N, B * k, 4, samples);
   return dr::check_launch("gather_fwd_kernel");
-}
-
-int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
-                              int B, int N, int k, int32_t *idx, float *samples, void *stream) {
-  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, dr::PairGate(), stream);
 }
 
 // Train mode (round 5): K1 with the soft-max statistics + K2 in one call -- idx, y_sel [P,B,k], lse [P,B] and samples [P,B,k,4] =
@@ -1709,8 +1672,9 @@ int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uin
                                 grad_samples, grad_w, matches);
 }
 
-// the same for a round > 1 of a multi-round test-mode call: pairs whose iteration counter has reached its bound are skipped
-// (gate_iters [P] int32, gate_max_iters [P] f64: the state dr_ransac_update keeps; the rows of a skipped pair keep their contents).
+// THE test-mode sampler entry (round 6: `_gated` folded in).  gate_iters / gate_max_iters (optional: a round > 1 of a multi-round
+// call): pairs whose iteration counter has reached its bound are skipped (gate_iters [P] int32, gate_max_iters [P] f64: the state
+// dr_ransac_update keeps; the rows of a skipped pair keep their contents).
 // Only the register-resident kernel (N <= 2048, N % 4 == 0, tau = 1) looks at the gate; other shapes simply run.
 // screen_ws (optional, (N + 32) * P words, 16-byte aligned; round 5): short rows (N <= 2048, N % 4 == 0, tau = 1, k <= 5, B >= 64)
 // then take the SCREENED register kernel -- per point the smallest Philox word that can lift it to the score logsumexp - ln(11 + k),
@@ -1718,9 +1682,9 @@ int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uin
 // sub (round 6): > 0 = the B rows are consecutive sub-batches of `sub` rows -- row b draws what row b % sub of a call with the seed
 // (seed | *seed_dev) + b / sub draws: one launch samples what ceil(B / sub) calls of a batch-by-batch loop sample (dr_ransac_update's
 // `sub_models` walks them in order); 0 = one batch.  Soft (train-mode) outputs have no sub-batch form.
-int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
-                                    int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream) {
+int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                              int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
+                              const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream) {
   DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
   DR_REQUIRE(sub >= 0, "sub-batch size");
   DR_REQUIRE(!(race_ws && screen_ws), "one workspace: the screened or the one-logarithm form");

@@ -996,18 +996,12 @@ int msac_score_launch(const T *matches, const T *models, const uint8_t *valid, c
 
 extern "C" {
 
+// gate_iters / gate_max_iters (optional; round 6: the `_gated` twin folded in): a round > 1 of a multi-round test-mode call -- the blocks
+// of pairs whose iteration counter has reached its bound return at once (their scores / masks keep their contents; dr_ransac_update
+// ignores such pairs).  Only the 16-points-per-lane kernel looks at the gate; other shapes simply run.
 int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
-                      int M, int N, float *scores, uint8_t *masks, void *stream) {
-  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  DR_REQUIRE(matches && models && thr && scores, "null pointer");
-  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
-}
-
-// round > 1 of a multi-round test-mode call: the blocks of pairs whose iteration counter has reached its bound return at once
-// (their scores / masks keep their contents; dr_ransac_update ignores such pairs).  Only the 16-points-per-lane kernel looks at
-// the gate; other shapes simply run.
-int dr_msac_score_gated_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P, int M, int N,
-                            float *scores, uint8_t *masks, const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
+                      int M, int N, float *scores, uint8_t *masks, const int32_t *gate_iters, const double *gate_max_iters,
+                      void *stream) {
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
   DR_REQUIRE(matches && models && thr && scores, "null pointer");
   DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
@@ -1015,15 +1009,6 @@ int dr_msac_score_gated_f32(const float *matches, const float *models, const uin
   gate.iters = gate_iters;
   gate.max_iters = gate_max_iters;
   return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream, gate);
-}
-
-int dr_msac_score_path_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
-                           int M, int N, float *scores, uint8_t *masks, int path, void *stream) {
-  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  DR_REQUIRE(matches && models && thr && scores, "null pointer");
-  DR_REQUIRE(path == 0 || path == 1, "path must be 0 or 1 (the general kernels); path 2, the matrix-core candidate filter of "
-                                     "round 2, was measured slower and left the library (scratch/k4_filter_kernel.patch)");
-  return dr::msac_score_launch<float>(matches, models, valid, thr, P, M, N, scores, masks, (hipStream_t)stream);
 }
 
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,

@@ -264,27 +264,14 @@ int dr_refit_essential_f64(const double *matches, const uint8_t *mask, int P, in
   DR_REQUIRE(P > 0 && N >= 5, "bad sizes");
   return dr::refit_launch<double>(false, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
 }
-int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
-                             void *stream) {
-  DR_REQUIRE(matches && models && valid, "null pointer");
-  DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
-  return dr::refit_launch<float>(true, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
-}
-int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
-                             void *stream) {
-  DR_REQUIRE(matches && models && valid, "null pointer");
-  DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
-  return dr::refit_launch<double>(true, matches, mask, nullptr, P, N, models, valid, (hipStream_t)stream);
-}
-
-int dr_refit_fundamental_w_f32(const float *matches, const uint8_t *mask, const float *weights, int P, int N,
-                               float *models, uint8_t *valid, void *stream) {
+int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, const float *weights, int P, int N, float *models,
+                             uint8_t *valid, void *stream) {
   DR_REQUIRE(matches && models && valid, "null pointer");
   DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
   return dr::refit_launch<float>(true, matches, mask, weights, P, N, models, valid, (hipStream_t)stream);
 }
-int dr_refit_fundamental_w_f64(const double *matches, const uint8_t *mask, const double *weights, int P, int N,
-                               double *models, uint8_t *valid, void *stream) {
+int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, const double *weights, int P, int N, double *models,
+                             uint8_t *valid, void *stream) {
   DR_REQUIRE(matches && models && valid, "null pointer");
   DR_REQUIRE(P > 0 && N >= 8, "bad sizes");
   return dr::refit_launch<double>(true, matches, mask, weights, P, N, models, valid, (hipStream_t)stream);

@@ -462,25 +462,33 @@ DR_DEFINE_STAGE_READER(dr_debug_stage_read_fivepoint)
 
 extern "C" {
 
-int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
-                         void *stream) {
+// THE f32 five-point entries (round 6: the `_hp`, `_path_` and `_gated_` twins of rounds 3-5 folded in; every argument after
+// `valid` is optional):
+//   models_f64 (Nister, minimal samples): the f64 models next to the f32 ones from the same launch (train mode);
+//   path (minimal samples): 0 automatic, 1 lane-pair kernel, 2 two-phase kernel;
+//   gate_iters / gate_max_iters + per_pair (rounds > 1 of a multi-round test-mode call; Bt = pairs x per_pair minimal samples):
+//   blocks whose samples all belong to pairs with iters >= max_iters (the state dr_ransac_update keeps) return at once, their
+//   models / valid keep their contents.
+int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, double *models_f64, uint8_t *valid,
+                         int path, int per_pair, const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
   DR_REQUIRE(Bt > 0 && n >= 5, "need Bt > 0 and n >= 5 points per sample");
-  return dr::nister_launch<float>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
+  DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
+  DR_REQUIRE(n == 5 || (!models_f64 && path == 0 && !gate_iters), "f64 models, explicit paths and gates serve minimal samples (n = 5)");
+  DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
+  DR_REQUIRE(!gate_iters || (per_pair > 0 && Bt % per_pair == 0), "gate: need Bt = pairs x per_pair");
+  dr::PairGate gate;
+  gate.iters = gate_iters;
+  gate.max_iters = gate_max_iters;
+  return dr::nister_launch<float>(samples, weights, Bt, n, models, valid, (hipStream_t)stream, models_f64, path, gate,
+                                  gate_iters ? per_pair : 1);
 }
 int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, int n, double *models,
                          uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(Bt > 0 && n >= 5, "need Bt > 0 and n >= 5 points per sample");
   return dr::nister_launch<double>(samples, weights, Bt, n, models, valid, (hipStream_t)stream);
-}
-int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
-                            uint8_t *valid, void *stream) {
-  DR_REQUIRE(samples && models && models_f64 && valid, "null pointer");
-  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
-  DR_REQUIRE(Bt > 0, "need Bt > 0");
-  return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, models_f64);
 }
 int dr_debug_real_roots10(const double *coef, int n, int method, double *roots, int32_t *counts, void *stream) {
   DR_REQUIRE(coef && roots && counts, "null pointer");
@@ -495,55 +503,23 @@ int dr_debug_real_roots10(const double *coef, int n, int method, double *roots, 
   return dr::check_launch("debug_roots10_kernel");
 }
 
-int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream) {
+int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, int per_pair,
+                            const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
   DR_REQUIRE(Bt > 0, "need Bt > 0");
-  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream);
+  DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
+  DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
+  DR_REQUIRE(!gate_iters || (per_pair > 0 && Bt % per_pair == 0), "gate: need Bt = pairs x per_pair");
+  dr::PairGate gate;
+  gate.iters = gate_iters;
+  gate.max_iters = gate_max_iters;
+  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream, path, gate, gate_iters ? per_pair : 1);
 }
 int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream) {
   DR_REQUIRE(samples && models && valid, "null pointer");
   DR_REQUIRE(Bt > 0, "need Bt > 0");
   return dr::stewenius_launch<double>(samples, Bt, models, valid, (hipStream_t)stream);
-}
-
-int dr_solve_nister5_path_f32(const float *samples, const float *weights, int Bt, float *models, double *models_f64, uint8_t *valid,
-                              int path, void *stream) {
-  DR_REQUIRE(samples && models && valid, "null pointer");
-  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
-  DR_REQUIRE(Bt > 0, "need Bt > 0");
-  DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
-  return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, models_f64, path);
-}
-int dr_solve_stewenius5_path_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, void *stream) {
-  DR_REQUIRE(samples && models && valid, "null pointer");
-  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
-  DR_REQUIRE(Bt > 0, "need Bt > 0");
-  DR_REQUIRE(path >= 0 && path <= 2, "path: 0 automatic, 1 lane pairs, 2 two-phase");
-  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream, path);
-}
-
-// rounds > 1 of a multi-round test-mode call (P pairs x per_pair minimal samples each, Bt = P * per_pair): blocks whose samples all
-// belong to pairs with iters >= max_iters (the state dr_ransac_update keeps) return at once; their models / valid keep their contents
-int dr_solve_nister5_gated_f32(const float *samples, const float *weights, int Bt, float *models, uint8_t *valid, int per_pair,
-                               const int32_t *gate_iters, const double *gate_max_iters, void *stream) {
-  DR_REQUIRE(samples && models && valid && gate_iters && gate_max_iters, "null pointer");
-  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
-  DR_REQUIRE(Bt > 0 && per_pair > 0 && Bt % per_pair == 0, "need Bt = pairs x per_pair");
-  dr::PairGate gate;
-  gate.iters = gate_iters;
-  gate.max_iters = gate_max_iters;
-  return dr::nister_launch<float>(samples, weights, Bt, 5, models, valid, (hipStream_t)stream, nullptr, 0, gate, per_pair);
-}
-int dr_solve_stewenius5_gated_f32(const float *samples, int Bt, float *models, uint8_t *valid, int per_pair, const int32_t *gate_iters,
-                                  const double *gate_max_iters, void *stream) {
-  DR_REQUIRE(samples && models && valid && gate_iters && gate_max_iters, "null pointer");
-  DR_REQUIRE(dr::aligned_out(models, valid), "models must be 16-byte aligned and valid 4-byte aligned (whole-line output stores)");
-  DR_REQUIRE(Bt > 0 && per_pair > 0 && Bt % per_pair == 0, "need Bt = pairs x per_pair");
-  dr::PairGate gate;
-  gate.iters = gate_iters;
-  gate.max_iters = gate_max_iters;
-  return dr::stewenius_launch<float>(samples, Bt, models, valid, (hipStream_t)stream, 0, gate, per_pair);
 }
 
 }  // extern "C"

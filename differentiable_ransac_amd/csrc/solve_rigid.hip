@@ -653,18 +653,13 @@ int dr_solve_rigid_gather_f32(const float *matches, const int32_t *idx, int P, i
 }
 
 // dr_rigid_residual_f32 with the sums ADDED to res_sum, which the caller (or dr_solve_rigid_gather_f32) has cleared
-int dr_rigid_residual_acc_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
-                              float *res_sum, uint8_t *masks, void *stream) {
-  DR_REQUIRE(pts && models && res_sum, "null pointer");
-  DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  return dr::rigid_residual_launch<float>(pts, models, threshold, P, M, N, res_sum, masks, (hipStream_t)stream, true);
-}
-
+// accumulate != 0 (round 6: the `_acc` twin folded in): res_sum holds zeros (dr_solve_rigid_gather_f32 clears it) and the sums are
+// ADDED to it -- no memset launch
 int dr_rigid_residual_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
-                          float *res_sum, uint8_t *masks, void *stream) {
+                          float *res_sum, uint8_t *masks, int accumulate, void *stream) {
   DR_REQUIRE(pts && models && res_sum, "null pointer");
   DR_REQUIRE(P > 0 && M > 0 && N > 0 && P <= 65535, "bad sizes");
-  return dr::rigid_residual_launch<float>(pts, models, threshold, P, M, N, res_sum, masks, (hipStream_t)stream);
+  return dr::rigid_residual_launch<float>(pts, models, threshold, P, M, N, res_sum, masks, (hipStream_t)stream, accumulate != 0);
 }
 int dr_rigid_residual_f64(const double *pts, const double *models, double threshold, int P, int M, int N,
                           double *res_sum, uint8_t *masks, void *stream) {
@@ -695,38 +690,21 @@ int dr_ransac3d_update_f64(const double *pts, const double *models, const uint8_
 }
 
 int dr_select_closest_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
-                          float *chosen, int32_t *which, void *stream) {
+                          float *chosen, int32_t *which, uint8_t *keep, void *stream) {
   DR_REQUIRE(models && gt && chosen && which, "null pointer");
-  DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
-  hipLaunchKernelGGL((dr::select_closest_kernel<float>), dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
-                     models, valid, gt, B, S, chosen, which, (uint8_t *)nullptr);
-  return dr::check_launch("select_closest_kernel");
-}
-int dr_select_closest_keep_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
-                               float *chosen, int32_t *which, uint8_t *keep, void *stream) {
-  DR_REQUIRE(models && gt && chosen && which && keep, "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::select_closest_kernel<float>), dim3((B + 255) / 256, P), dim3(256), 0, (hipStream_t)stream,
                      models, valid, gt, B, S, chosen, which, keep);
   return dr::check_launch("select_closest_kernel");
 }
 int dr_select_closest_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
-                          double *chosen, int32_t *which, void *stream) {
+                          double *chosen, int32_t *which, uint8_t *keep, void *stream) {
   DR_REQUIRE(models && gt && chosen && which, "null pointer");
-  DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
-  hipLaunchKernelGGL((dr::select_closest_kernel<double>), dim3((B + 255) / 256, P), dim3(256), 0,
-                     (hipStream_t)stream, models, valid, gt, B, S, chosen, which, (uint8_t *)nullptr);
-  return dr::check_launch("select_closest_kernel");
-}
-int dr_select_closest_keep_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
-                               double *chosen, int32_t *which, uint8_t *keep, void *stream) {
-  DR_REQUIRE(models && gt && chosen && which && keep, "null pointer");
   DR_REQUIRE(P > 0 && B > 0 && S > 0 && P <= 65535, "bad sizes");
   hipLaunchKernelGGL((dr::select_closest_kernel<double>), dim3((B + 255) / 256, P), dim3(256), 0,
                      (hipStream_t)stream, models, valid, gt, B, S, chosen, which, keep);
   return dr::check_launch("select_closest_kernel");
 }
-
 int dr_select_closest_bwd_f32(const float *grad_chosen, const int32_t *which, int P, int B, int S, float *grad_models,
                               void *stream) {
   DR_REQUIRE(P > 0 && B > 0 && S > 0, "bad sizes");

@@ -26,8 +26,8 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
                valid: Optional[torch.Tensor] = None, path: int = 0, gate=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """matches [P,N,4], models [P,M,3,3] (or [P,M,9]) -> scores [P,M], masks [P,M,N] bool | None.
     valid [P,M] bool (optional): invalid slots are skipped (score 0, empty mask row).
-    path (f32 only): 0 = 1 = the general kernels; 2 (the matrix-core candidate filter of round 2, measured slower: DESIGN 2b)
-    left the library in round 4 and is refused (include/dransac.h: dr_msac_score_path_f32)."""
+    path: 0 = 1 = the general kernels; 2 (the matrix-core candidate filter of round 2, measured slower: DESIGN 2b) left the
+    library in round 4 and is refused."""
     P, N, _ = matches.shape
     M = models.shape[1]
     matches = matches.contiguous()
@@ -36,20 +36,17 @@ def msac_score(matches: torch.Tensor, models: torch.Tensor, threshold, want_mask
     scores = torch.empty((P, M), device=matches.device, dtype=matches.dtype)
     masks = torch.empty((P, M, N), device=matches.device, dtype=torch.bool) if want_masks else None
     v = None if valid is None else valid.contiguous().view(torch.uint8)
-    if path != 0:
-        if matches.dtype != torch.float32:
-            raise L.DransacError("msac_score: an explicit kernel path exists for f32 only")
-        L.call("dr_msac_score_path_f32", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N),
-               ptr(scores), ptr(masks), c_int(path), stream())
+    if path not in (0, 1):
+        raise L.DransacError("msac_score: path must be 0 or 1 (the general kernels); path 2, the matrix-core candidate filter of "
+                             "round 2, was measured slower and left the library (scratch/k4_filter_kernel.patch)")
+    if matches.dtype == torch.float32:
+        # gate (a later round of a multi-round call): the blocks of terminated pairs (gate = RansacState) return at once, their
+        # scores are never looked at (dr_ransac_update skips such pairs)
+        L.call("dr_msac_score_f32", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N), ptr(scores),
+               ptr(masks), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters), stream())
         return scores, masks
-    if gate is not None and matches.dtype == torch.float32:
-        # a later round of a multi-round call: the blocks of terminated pairs (gate = RansacState) return at once, their scores
-        # are never looked at (dr_ransac_update skips such pairs)
-        L.call("dr_msac_score_gated_f32", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N), ptr(scores),
-               ptr(masks), ptr(gate.iters), ptr(gate.max_iters), stream())
-        return scores, masks
-    L.call(f"dr_msac_score_{L.suffix(matches.dtype)}", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M),
-           c_int(N), ptr(scores), ptr(masks), stream())
+    L.call(f"dr_msac_score_{L.suffix(matches.dtype)}", ptr(matches), ptr(models), ptr(v), ptr(thr), c_int(P), c_int(M), c_int(N),
+           ptr(scores), ptr(masks), stream())
     return scores, masks
 
 
@@ -128,7 +125,7 @@ def ransac_update(state: RansacState, matches, models, valid, scores, thr, B: in
 # ------------------------------------------------------------------------------------------ K1 / K1u / K2
 class DeviceSeed:
     """The per-call sampler seed of the batched drivers, kept on the device: state = (base, calls) and `next()` launches
-    dr_seed_next -> a one-word tensor holding base * 0x9E3779B97F4A7C15 + calls (mod 2^64), calls += 1.  The samplers
+    dr_seed_next_n -> a one-word tensor holding base * 0x9E3779B97F4A7C15 + calls (mod 2^64), calls += 1.  The samplers
     accept such a tensor wherever they accept an int seed and read it when their kernel starts, so a step captured in a
     HIP graph (torch.cuda.graph) draws fresh hypotheses at every replay -- the same ones an eager driver with the same
     base seed draws at the same call number."""
@@ -141,7 +138,7 @@ class DeviceSeed:
 
     def next(self) -> torch.Tensor:
         out = torch.empty(1, dtype=torch.int64, device=self.state.device)
-        L.call("dr_seed_next", ptr(self.state), ptr(out), stream())
+        L.call("dr_seed_next_n", ptr(self.state), ptr(out), c_int(1), stream())
         return out
 
     def next_block(self, n: int) -> torch.Tensor:
@@ -203,15 +200,12 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
     y_soft = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
     ret = torch.empty((P, B, N), device=device, dtype=dtype) if dense else None
     noise = torch.empty((P, B, N), device=device, dtype=dtype) if want_noise else None
-    if _dev_seed(seed):
-        if gumbel is not None or dense or want_noise or logits is None:
-            raise L.DransacError("a device seed serves the in-kernel noise of given logits only (no explicit noise / dense outputs)")
-        L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}_dseed", ptr(logits), ptr(seed), L.scalar(dtype, tau), c_int(P), c_int(B),
-               c_int(N), c_int(k), ptr(idx), ptr(y_sel), ptr(lse), stream())
-        return dict(idx=idx, y_sel=y_sel, lse=lse)
-    L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", ptr(logits), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
-           L.scalar(dtype, tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(y_sel), ptr(lse), ptr(y_soft),
-           ptr(ret), ptr(noise), stream())
+    ds = _dev_seed(seed)
+    if ds and (gumbel is not None or dense or want_noise or logits is None):
+        raise L.DransacError("a device seed serves the in-kernel noise of given logits only (no explicit noise / dense outputs)")
+    L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", ptr(logits), ptr(gumbel), c_uint64(0 if ds else seed & (2 ** 64 - 1)),
+           ptr(seed if ds else None), L.scalar(dtype, tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(y_sel), ptr(lse),
+           ptr(y_soft), ptr(ret), ptr(noise), stream())
     out = dict(idx=idx, y_sel=y_sel, lse=lse)
     if dense:
         out.update(y_soft=y_soft, ret=ret)
@@ -221,7 +215,7 @@ def gumbel_topk(logits: Optional[torch.Tensor], B: int, k: int, tau: float = 1.0
 
 
 import os as _os
-# Round 5: the screened register kernel for rows of <= 2048 points (dr_gumbel_topk_gather_gated_f32 with a workspace) is built,
+# Round 5: the screened register kernel for rows of <= 2048 points (dr_gumbel_topk_gather_f32 with a screen_ws workspace) is built,
 # bit-identical (tests/test_gpu_round5.py) and SLOWER than the unscreened one at the shapes measured -- 199.5 vs 164.1 us at 128
 # pairs x 1024 rows x 2000 points, 57.4 vs 45.2 at 32 pairs, 25.6 vs 18.2 at one pair (scratch/ab_k1_screen.py), in both of its forms
 # (words parked in LDS + one evaluation per lane and round: 200.8; slot-wise wave masks, no parking, no dependent load: 199.5):
@@ -230,7 +224,7 @@ import os as _os
 SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 
 
-# Round 6: the exponential-race form of the index-only sampler (one logarithm per element; dr_gumbel_topk_gather_gated_f32's race_ws).
+# Round 6: the exponential-race form of the index-only sampler (one logarithm per element; dr_gumbel_topk_gather_f32's race_ws).
 # Same top-k up to the rounding of near-ties; off = the two-logarithm form of rounds 1-5 (A/B runs, tests: DRANSAC_K1_RACE=0).
 K1_RACE = _os.environ.get("DRANSAC_K1_RACE", "1") != "0"
 
@@ -256,14 +250,11 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
           if want_screen and N <= 2048 and N % 4 == 0 and tau == 1.0 and k <= 5 and B >= 64 else None)
     want_race = (K1_RACE if race is None else race) and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
     rws = torch.empty((P, N + 32), device=logits.device, dtype=torch.float32) if want_race else None
-    if gate is not None or ws is not None or sub or rws is not None:     # (gate: a later round of a multi-round call, terminated pairs are skipped)
-        L.call("dr_gumbel_topk_gather_gated_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
-               ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
-               ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters),
-               c_int(0 if sub >= B else int(sub)), ptr(rws), stream())
-        return idx, samples
+    # (gate: a later round of a multi-round call, terminated pairs are skipped)
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
-           ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples), stream())
+           ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
+           ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters),
+           c_int(0 if sub >= B else int(sub)), ptr(rws), stream())
     return idx, samples
 
 
@@ -279,13 +270,10 @@ def gumbel_topk_bwd(logits, gumbel, seed, tau, idx, lse, a_sel):
                L.c_double(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(lse.contiguous()),
                ptr(a_sel.to(torch.float64).contiguous()), ptr(grad), stream())
         return grad
-    if _dev_seed(seed):
-        L.call("dr_gumbel_topk_bwd_f32_dseed", ptr(logits.contiguous()), ptr(seed), L.c_float(tau), c_int(P), c_int(B), c_int(N),
-               c_int(k), ptr(idx), ptr(lse), ptr(a_sel.contiguous()), ptr(grad), stream())
-        return grad
-    L.call("dr_gumbel_topk_bwd_f32", ptr(logits.contiguous()), ptr(gumbel), c_uint64(seed & (2 ** 64 - 1)),
-           L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(lse), ptr(a_sel.contiguous()),
-           ptr(grad), stream())
+    ds = _dev_seed(seed)
+    L.call("dr_gumbel_topk_bwd_f32", ptr(logits.contiguous()), ptr(None if ds else gumbel), c_uint64(0 if ds else seed & (2 ** 64 - 1)),
+           ptr(seed if ds else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(lse),
+           ptr(a_sel.contiguous()), ptr(grad), stream())
     return grad
 
 
@@ -304,13 +292,14 @@ def topdown_sample(logits: Optional[torch.Tensor], B: int, k: int, seed: int = 0
         sfx = "f32"
     ws = torch.empty((P, N), device=device, dtype=torch.float64)
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
-    if _dev_seed(seed):
-        if sfx != "f32":
-            raise L.DransacError("device seeds: f32 logits")
-        L.call("dr_topdown_sample_f32_dseed", ptr(logits), ptr(seed), c_int(P), c_int(B), c_int(N), c_int(k), ptr(ws), ptr(idx),
-               stream())
+    ds = _dev_seed(seed)
+    if sfx == "f32":
+        L.call("dr_topdown_sample_f32", ptr(logits), c_uint64(0 if ds else seed & (2 ** 64 - 1)), ptr(seed if ds else None), c_int(P),
+               c_int(B), c_int(N), c_int(k), ptr(ws), ptr(idx), stream())
         return idx
-    L.call(f"dr_topdown_sample_{sfx}", ptr(logits), c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(N), c_int(k),
+    if ds:
+        raise L.DransacError("device seeds: f32 logits")
+    L.call("dr_topdown_sample_f64", ptr(logits), c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(N), c_int(k),
            ptr(ws), ptr(idx), stream())
     return idx
 
@@ -318,11 +307,9 @@ def topdown_sample(logits: Optional[torch.Tensor], B: int, k: int, seed: int = 0
 def uniform_sample(P: int, B: int, k: int, N: int, seed: int, device) -> torch.Tensor:
     """K1u: idx [P,B,k] int32 ~ U{0..N-2} (uniform_sampler.py:15-19 semantics)."""
     idx = torch.empty((P, B, k), device=device, dtype=torch.int32)
-    if _dev_seed(seed):
-        L.call("dr_uniform_sample_dseed", ptr(seed), c_int(P), c_int(B), c_int(k), c_int(N), ptr(idx), stream())
-        return idx
-    L.call("dr_uniform_sample", c_uint64(seed & (2 ** 64 - 1)), c_int(P), c_int(B), c_int(k), c_int(N), ptr(idx),
-           stream())
+    ds = _dev_seed(seed)
+    L.call("dr_uniform_sample", c_uint64(0 if ds else seed & (2 ** 64 - 1)), ptr(seed if ds else None), c_int(P), c_int(B), c_int(k),
+           c_int(N), ptr(idx), stream())
     return idx
 
 
@@ -423,13 +410,13 @@ def solve_nister5(samples: torch.Tensor, weights: Optional[torch.Tensor] = None,
     models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=s.dtype)
     valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
     w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
-    if path != 0:
-        if n != 5 or s.dtype != torch.float32:
-            raise L.DransacError("an explicit five-point kernel path exists for f32 minimal samples only")
-        L.call("dr_solve_nister5_path_f32", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(None), ptr(valid), c_int(path), stream())
+    if path != 0 and (n != 5 or s.dtype != torch.float32):
+        raise L.DransacError("an explicit five-point kernel path exists for f32 minimal samples only")
+    if s.dtype == torch.float32:
+        L.call("dr_solve_nister5_f32", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(None), ptr(valid), c_int(path), c_int(0),
+               ptr(None), ptr(None), stream())
     else:
-        L.call(f"dr_solve_nister5_{L.suffix(s.dtype)}", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(valid),
-               stream())
+        L.call(f"dr_solve_nister5_{L.suffix(s.dtype)}", ptr(s), ptr(w), c_int(Bt), c_int(n), ptr(models), ptr(valid), stream())
     return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 
@@ -443,26 +430,24 @@ def solve_nister5_hp(samples: torch.Tensor, weights: Optional[torch.Tensor] = No
     m64 = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=torch.float64)
     valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
     w = None if weights is None else weights.reshape(Bt, n).to(s.dtype).contiguous()
-    if path != 0:
-        L.call("dr_solve_nister5_path_f32", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), c_int(path), stream())
-    else:
-        L.call("dr_solve_nister5_f32_hp", ptr(s), ptr(w), c_int(Bt), ptr(models), ptr(m64), ptr(valid), stream())
+    L.call("dr_solve_nister5_f32", ptr(s), ptr(w), c_int(Bt), c_int(5), ptr(models), ptr(m64), ptr(valid), c_int(path), c_int(0),
+           ptr(None), ptr(None), stream())
     return models.reshape(*lead, 10, 3, 3), m64.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
 
 
 def solve_essential_gated(samples: torch.Tensor, which: str, gate):
     """A later round of a multi-round test-mode call: samples [P,B,5,4] f32 -> (models [P,B,10,3,3], valid [P,B,10]); the
     blocks of pairs that have terminated (gate = RansacState: iters >= max_iters) return at once and leave their part of the
-    outputs unwritten -- dr_ransac_update never looks at it (dr_solve_nister5_gated_f32 / dr_solve_stewenius5_gated_f32)."""
+    outputs unwritten -- dr_ransac_update never looks at it (the gate arguments of dr_solve_nister5_f32 / dr_solve_stewenius5_f32)."""
     P, B = samples.shape[0], samples.shape[1]
     s = samples.reshape(P * B, 5, 4).contiguous()
     models = torch.empty((P * B, 10, 3, 3), device=s.device, dtype=torch.float32)
     valid = torch.empty((P * B, 10), device=s.device, dtype=torch.bool)
     if which == "nister":
-        L.call("dr_solve_nister5_gated_f32", ptr(s), ptr(None), c_int(P * B), ptr(models), ptr(valid), c_int(B), ptr(gate.iters),
-               ptr(gate.max_iters), stream())
+        L.call("dr_solve_nister5_f32", ptr(s), ptr(None), c_int(P * B), c_int(5), ptr(models), ptr(None), ptr(valid), c_int(0), c_int(B),
+               ptr(gate.iters), ptr(gate.max_iters), stream())
     else:
-        L.call("dr_solve_stewenius5_gated_f32", ptr(s), c_int(P * B), ptr(models), ptr(valid), c_int(B), ptr(gate.iters),
+        L.call("dr_solve_stewenius5_f32", ptr(s), c_int(P * B), ptr(models), ptr(valid), c_int(0), c_int(B), ptr(gate.iters),
                ptr(gate.max_iters), stream())
     return models.reshape(P, B, 10, 3, 3), valid.reshape(P, B, 10)
 
@@ -486,10 +471,10 @@ def solve_stewenius5(samples: torch.Tensor, path: int = 0):
     lead = samples.shape[:-2]
     models = torch.empty((Bt, 10, 3, 3), device=s.device, dtype=s.dtype)
     valid = torch.empty((Bt, 10), device=s.device, dtype=torch.bool)
-    if path != 0:
-        if s.dtype != torch.float32:
-            raise L.DransacError("an explicit five-point kernel path exists for f32 minimal samples only")
-        L.call("dr_solve_stewenius5_path_f32", ptr(s), c_int(Bt), ptr(models), ptr(valid), c_int(path), stream())
+    if path != 0 and s.dtype != torch.float32:
+        raise L.DransacError("an explicit five-point kernel path exists for f32 minimal samples only")
+    if s.dtype == torch.float32:
+        L.call("dr_solve_stewenius5_f32", ptr(s), c_int(Bt), ptr(models), ptr(valid), c_int(path), c_int(0), ptr(None), ptr(None), stream())
     else:
         L.call(f"dr_solve_stewenius5_{L.suffix(s.dtype)}", ptr(s), c_int(Bt), ptr(models), ptr(valid), stream())
     return models.reshape(*lead, 10, 3, 3), valid.reshape(*lead, 10)
@@ -574,12 +559,16 @@ def rigid_residual(pts: torch.Tensor, models: torch.Tensor, threshold: float = 0
     if res is not None:
         if pts.dtype != torch.float32 or res.shape != (P, M) or res.dtype != torch.float32:
             raise L.DransacError("rigid_residual: res must be an f32 [P,M] tensor of zeros")
-        L.call("dr_rigid_residual_acc_f32", ptr(pts.contiguous()), ptr(models.contiguous()), L.c_float(threshold), c_int(P),
-               c_int(M), c_int(N), ptr(res), ptr(masks), stream())
+        L.call("dr_rigid_residual_f32", ptr(pts.contiguous()), ptr(models.contiguous()), L.c_float(threshold), c_int(P),
+               c_int(M), c_int(N), ptr(res), ptr(masks), c_int(1), stream())
         return res, masks
     res = torch.empty((P, M), device=pts.device, dtype=pts.dtype)
-    L.call(f"dr_rigid_residual_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()),
-           L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(res), ptr(masks), stream())
+    if pts.dtype == torch.float32:
+        L.call("dr_rigid_residual_f32", ptr(pts.contiguous()), ptr(models.contiguous()), L.c_float(threshold), c_int(P), c_int(M),
+               c_int(N), ptr(res), ptr(masks), c_int(0), stream())
+    else:
+        L.call(f"dr_rigid_residual_{L.suffix(pts.dtype)}", ptr(pts.contiguous()), ptr(models.contiguous()),
+               L.scalar(pts.dtype, threshold), c_int(P), c_int(M), c_int(N), ptr(res), ptr(masks), stream())
     return res, masks
 
 
@@ -612,14 +601,10 @@ def select_closest(models: torch.Tensor, valid: Optional[torch.Tensor], gt: torc
     chosen = torch.empty((P, B, 3, 3), device=models.device, dtype=models.dtype)
     which = torch.empty((P, B), device=models.device, dtype=torch.int32)
     v = None if valid is None else valid.contiguous().view(torch.uint8)
-    if want_keep:
-        keep = torch.empty((P, B), device=models.device, dtype=torch.bool)
-        L.call(f"dr_select_closest_keep_{L.suffix(models.dtype)}", ptr(models.contiguous()), ptr(v),
-               ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), ptr(keep), stream())
-        return chosen, which, keep
+    keep = torch.empty((P, B), device=models.device, dtype=torch.bool) if want_keep else None
     L.call(f"dr_select_closest_{L.suffix(models.dtype)}", ptr(models.contiguous()), ptr(v),
-           ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), stream())
-    return chosen, which
+           ptr(gt.to(models.dtype).contiguous()), c_int(P), c_int(B), c_int(S), ptr(chosen), ptr(which), ptr(keep), stream())
+    return (chosen, which, keep) if want_keep else (chosen, which)
 
 
 def refit_essential(matches: torch.Tensor, mask: Optional[torch.Tensor] = None):
@@ -652,14 +637,11 @@ def refit_fundamental(matches: torch.Tensor, mask: Optional[torch.Tensor] = None
     models = torch.empty((P, 3, 3), device=matches.device, dtype=matches.dtype)
     valid = torch.empty((P,), device=matches.device, dtype=torch.bool)
     mk = None if mask is None else mask.contiguous().view(torch.uint8)
-    if weights is not None:
-        if weights.shape != (P, N):
-            raise L.DransacError("refit weights are [P,N], one per point")
-        L.call(f"dr_refit_fundamental_w_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk),
-               ptr(weights.to(matches.dtype).contiguous()), c_int(P), c_int(N), ptr(models), ptr(valid), stream())
-        return models, valid
-    L.call(f"dr_refit_fundamental_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk), c_int(P), c_int(N),
-           ptr(models), ptr(valid), stream())
+    if weights is not None and weights.shape != (P, N):
+        raise L.DransacError("refit weights are [P,N], one per point")
+    L.call(f"dr_refit_fundamental_{L.suffix(matches.dtype)}", ptr(matches.contiguous()), ptr(mk),
+           ptr(None if weights is None else weights.to(matches.dtype).contiguous()), c_int(P), c_int(N), ptr(models), ptr(valid),
+           stream())
     return models, valid
 
 

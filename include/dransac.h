@@ -58,19 +58,24 @@ const char *dr_last_error(void);
  *   y_sel == NULL and lse == NULL (both, and then no dense outputs) -> index sets only: what test mode consumes
  *   (`points[samples != 0]`, ransac.py:65); the same idx, without the soft-max statistics of the rows.
  * ------------------------------------------------------------------------------------------ */
-int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
-                           int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,
+/* seed_dev (every sampler entry; round 6: ONE entry per sampler, the `_dseed` twins of rounds 2-5 are inline wrappers in
+ * dransac_compat.h): NULL = the Philox key is `seed`; != NULL = the key is read from DEVICE memory (`*seed_dev`) when the kernel
+ * starts and `seed` is ignored -- for steps captured in a HIP graph, where a by-value seed would be frozen at capture time.  Same
+ * kernels, same random numbers for equal keys; a device key serves the in-kernel noise of given logits only (no explicit noise,
+ * no dense outputs).  dr_seed_next_n advances such a key on the device. */
+int dr_gumbel_topk_fwd_f32(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B,
+                           int N, int k, int32_t *idx, float *y_sel, float *lse, float *y_soft, float *ret,
                            float *gumbel_out, void *stream);
-int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B,
-                           int N, int k, int32_t *idx, double *y_sel, double *lse, double *y_soft, double *ret,
+int dr_gumbel_topk_fwd_f64(const double *logits, const double *gumbel, uint64_t seed, const uint64_t *seed_dev, double tau, int P,
+                           int B, int N, int k, int32_t *idx, double *y_sel, double *lse, double *y_soft, double *ret,
                            double *gumbel_out, void *stream);
 
 /* Backward of sampler + gather (K1+K2).  a_sel [P,B,k] = dL/d(straight-through value at idx)
  * (= <grad_sample, matches[idx]> + grad_weight, computed by dr_gather_bwd).  grad_logits [P,N] is
  * OVERWRITTEN with (1/tau) * sum_b y*(a - sum_m y_m a_m).  Needs the forward's noise: pass the same
  * gumbel pointer or the same seed. */
-int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, float tau, int P, int B, int N,
-                           int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
+int dr_gumbel_topk_bwd_f32(const float *logits, const float *gumbel, uint64_t seed, const uint64_t *seed_dev, float tau, int P, int B,
+                           int N, int k, const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits,
                            void *stream);
 /* the same in double: `-pr 2 -tr 1` (model_cl.py:164-169; f64 works end to end upstream) */
 int dr_gumbel_topk_bwd_f64(const double *logits, const double *gumbel, uint64_t seed, double tau, int P, int B, int N,
@@ -83,42 +88,27 @@ int dr_gumbel_topk_bwd_f64(const double *logits, const double *gumbel, uint64_t 
  * whole noise row and come from dr_gumbel_topk_fwd.  logits [P,N] or NULL (uniform); cdf_ws [P,N] f64 workspace (the
  * per-pair cumulative soft-max weights, overwritten); idx [P,B,k] ascending.
  * Philox4x32-7(key = seed, counter = (draw / 2, b, p, 2)). */
-int dr_topdown_sample_f32(const float *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
-                          void *stream);
+int dr_topdown_sample_f32(const float *logits, uint64_t seed, const uint64_t *seed_dev, int P, int B, int N, int k, double *cdf_ws,
+                          int32_t *idx, void *stream);
 int dr_topdown_sample_f64(const double *logits, uint64_t seed, int P, int B, int N, int k, double *cdf_ws, int32_t *idx,
                           void *stream);
 
 /* K1u  UniformSampler.batch_generate, samplers/uniform_sampler.py:15-19: idx ~ U{0..N-2}, with replacement.
  * Philox4x32-7(key = seed, counter = (j, b, p, 1)). */
-int dr_uniform_sample(uint64_t seed, int P, int B, int k, int N, int32_t *idx, void *stream);
+int dr_uniform_sample(uint64_t seed, const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream);
 
-/* The samplers with the Philox key in DEVICE memory (`*seed_dev`, read when the kernel starts) -- for steps captured in a
- * HIP graph, where a by-value seed would be frozen at capture time.  Same kernels, same streams of random numbers as the
- * by-value entry points for equal seeds; in-kernel noise only (no explicit-noise / dense-output modes).
- * dr_seed_next: state[0] = base, state[1] = number of calls so far -> *seed_out = base * 0x9E3779B97F4A7C15 + calls
- * (mod 2^64), calls += 1: the per-call seed of the batched drivers (ransac.py of this package: `_next_seed`), advanced on
- * the device so that every replay of a captured step draws fresh hypotheses. */
-int dr_seed_next(uint64_t *state, uint64_t *seed_out, void *stream);
-/* the seeds of the next n (<= 64) calls in one launch: seeds_out[i] = base * 0x9E3779B97F4A7C15 + calls + i, calls += n */
+/* The per-call key of the batched drivers, advanced on the device (every replay of a captured step then draws fresh hypotheses):
+ * state[0] = base, state[1] = number of calls so far -> seeds_out[i] = base * 0x9E3779B97F4A7C15 + calls + i (mod 2^64) for
+ * i < n (<= 65 536), calls += n: CONSECUTIVE integers, one per call (ransac.py of this package: `_next_seed`).  n = 1 is the
+ * `dr_seed_next` of rounds 2-5 (dransac_compat.h). */
 int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream);
-int dr_gumbel_topk_fwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
-                                 int32_t *idx, float *y_sel, float *lse, void *stream);
-int dr_gumbel_topk_fwd_f64_dseed(const double *logits, const uint64_t *seed_dev, double tau, int P, int B, int N, int k,
-                                 int32_t *idx, double *y_sel, double *lse, void *stream);
-int dr_gumbel_topk_bwd_f32_dseed(const float *logits, const uint64_t *seed_dev, float tau, int P, int B, int N, int k,
-                                 const int32_t *idx, const float *lse, const float *a_sel, float *grad_logits, void *stream);
-int dr_topdown_sample_f32_dseed(const float *logits, const uint64_t *seed_dev, int P, int B, int N, int k, double *cdf_ws,
-                                int32_t *idx, void *stream);
-int dr_uniform_sample_dseed(const uint64_t *seed_dev, int P, int B, int k, int N, int32_t *idx, void *stream);
 
 /* K1 in index-only mode + K2 in one call (test mode: `points[samples != 0]`, ransac.py:58-65, with in-kernel noise):
- * idx [P,B,k] ascending and samples [P,B,k,4] = matches[p, idx] (c = 4; 16-byte aligned buffers).  seed_dev != NULL: the seed
- * is read from device memory (see the *_dseed entry points), `seed` is ignored.  One launch when the register-resident
- * sampler kernel serves the shape (N % 4 == 0, N <= 2048, tau == 1), sampler + gather launches otherwise. */
-int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
-                              int B, int N, int k, int32_t *idx, float *samples, void *stream);
-/* the same for a round > 1 of a multi-round test-mode call: pairs with gate_iters[p] >= gate_max_iters[p] are skipped (see the
- * `_gated` solver entries below) */
+ * idx [P,B,k] ascending and samples [P,B,k,4] = matches[p, idx] (c = 4; 16-byte aligned buffers).  One launch when the
+ * register-resident sampler kernel serves the shape (N % 4 == 0, N <= 2048, tau == 1), sampler + gather launches otherwise.
+ * Every argument from screen_ws on is optional (NULL / 0): */
+/* gate_iters / gate_max_iters (a round > 1 of a multi-round test-mode call): pairs with gate_iters[p] >= gate_max_iters[p] are
+ * skipped, their rows keep their contents (see dr_ransac_update and the solver entries below) */
 /* screen_ws (optional; (N + 32) * P words, 16-byte aligned): rows of <= 2048 points then take the screened register kernel -- only
  * the points whose Philox word can lift them to logsumexp(logits) - ln(11 + k) are evaluated (same index sets, bit for bit). */
 /* sub (round 6, super-rounds): > 0 = the B rows are ceil(B / sub) consecutive SUB-BATCHES of `sub` rows, the batches the loop of
@@ -130,9 +120,9 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
  * same top-k (gumbel_sampler.py:30-36), ONE logarithm per element; the per-pair weights are written into the workspace by a
  * prologue launch.  Same index sets up to the rounding of near-ties (measured: tests/test_gpu_round6.py); pairs whose logits are
  * not all finite or span more than 80 keep the two-logarithm form. */
-int dr_gumbel_topk_gather_gated_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
-                                    int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                                    const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream);
+int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
+                              int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
+                              const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream);
 
 /* Train mode (round 5): K1 WITH the soft-max statistics + K2 in one call (GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42,
  * followed by `matches * ret` + the mask gather of ransac.py:58-65): idx, y_sel [P,B,k], lse [P,B] as dr_gumbel_topk_fwd_f32 and
@@ -196,36 +186,30 @@ int dr_gather_bwd_f64(const double *matches, const int32_t *idx, const double *y
  *                        models [Bt,16] = 4x4, also R [Bt,9], t [Bt,3], scale [Bt] (any may be NULL);
  *                        flag != 0 reproduces the reference default (svd of cov^T cov, R ~ I, Q9).
  * ------------------------------------------------------------------------------------------ */
-int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
-                         void *stream);
+/* The f32 five-point entries carry every option of the path (round 6: the `_hp`, `_path_`, `_gated_` twins of rounds 3-5 are
+ * inline wrappers in dransac_compat.h); everything after `valid` is optional (NULL / 0):
+ *   models_f64 (Nister, n = 5): train mode -- the models written BOTH as f32 (what the scoring reads) and as f64 polished to the
+ *     f64 tolerance (what dr_solve_nister5_bwd_f32 wants), from one launch: the models of dr_solve_nister5_f64 on the widened
+ *     samples without the two conversion passes;
+ *   path (n = 5): 0 = automatic, 1 = two lanes per sample from the first instruction (the only kernels until round 4), 2 = the
+ *     two-phase kernels: ONE lane per sample for the part the two lanes of a sample otherwise compute twice (null space, the ten
+ *     constraints, QR, reduced rows, det B(z) of nister.py:117-348 / the action matrix' characteristic polynomial of
+ *     stewenius.py:44-74), handed over in registers to the two-lanes-per-sample root search and final stage (nister.py:355-402,
+ *     stewenius.py:74-78); automatic = two-phase when the grid is at least two rounds of lane-pair blocks.  Same solutions either
+ *     way (Stewenius: bit for bit; Nister: to the rounding of det B(z));
+ *   gate_iters / gate_max_iters + per_pair (n = 5; Bt = pairs x per_pair): device-side termination (ransac.py:135-144:
+ *     `max_iters = min(max_iterations, adaptive_iteration_number(...))` decides per pair when the loop of ransac.py:55 ends).  The
+ *     per-pair counters live on the device (dr_ransac_init / dr_ransac_update: iters [P] int32, max_iters [P] f64); a block all of
+ *     whose samples belong to pairs with iters >= max_iters returns at once, its outputs keep their contents, and dr_ransac_update
+ *     leaves such a pair's state alone.  The driver can therefore ISSUE every round of a call without reading anything back -- one
+ *     HIP graph per call, whatever the data decide. */
+int dr_solve_nister5_f32(const float *samples, const float *weights, int Bt, int n, float *models, double *models_f64, uint8_t *valid,
+                         int path, int per_pair, const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 int dr_solve_nister5_f64(const double *samples, const double *weights, int Bt, int n, double *models,
                          uint8_t *valid, void *stream);
-/* Train-mode variant of the minimal (n = 5) solve: f32 samples, the models written BOTH as f32 (what the scoring reads)
- * and as f64 polished to the f64 tolerance (what dr_solve_nister5_bwd_f32 wants as models_f64).  Same models as
- * dr_solve_nister5_f64 on the widened samples, without the two conversion passes. */
-int dr_solve_nister5_f32_hp(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
-                            uint8_t *valid, void *stream);
-int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, void *stream);
+int dr_solve_stewenius5_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, int per_pair,
+                            const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 int dr_solve_stewenius5_f64(const double *samples, int Bt, double *models, uint8_t *valid, void *stream);
-/* Round 5: the minimal (n = 5) f32 solves with an explicit kernel path (tests, A/B runs).  path 1 = two lanes per sample from
- * the first instruction (the only kernels until round 4), path 2 = the two-phase kernels: ONE lane per sample for the part the two
- * lanes of a sample otherwise compute twice (null space, the ten constraints, QR, reduced rows, det B(z) of nister.py:117-348 / the
- * action matrix' characteristic polynomial of stewenius.py:44-74), handed over in registers to the two-lanes-per-sample root search
- * and final stage (nister.py:355-402, stewenius.py:74-78); path 0 = what dr_solve_nister5_f32 / _f32_hp / dr_solve_stewenius5_f32
- * choose by themselves (two-phase when the grid is at least two rounds of lane-pair blocks).  Same solutions either way
- * (Stewenius: bit for bit; Nister: to the rounding of det B(z)).  models_f64: optional second output as in dr_solve_nister5_f32_hp. */
-int dr_solve_nister5_path_f32(const float *samples, const float *weights, int Bt, float *models, double *models_f64,
-                              uint8_t *valid, int path, void *stream);
-int dr_solve_stewenius5_path_f32(const float *samples, int Bt, float *models, uint8_t *valid, int path, void *stream);
-/* Round 5, device-side termination (ransac.py:135-144: `max_iters = min(max_iterations, adaptive_iteration_number(...))` decides per
- * pair when the loop of ransac.py:55 ends).  The per-pair counters live on the device (dr_ransac_init / dr_ransac_update: iters [P]
- * int32, max_iters [P] f64); the `_gated` forms of the kernels of one round take them as a gate: the blocks of a pair with
- * iters >= max_iters return at once, its outputs keep their contents, and dr_ransac_update leaves its state alone.  The driver can
- * therefore ISSUE every round of a call without reading anything back -- one HIP graph per call, whatever the data decide. */
-int dr_solve_nister5_gated_f32(const float *samples, const float *weights, int Bt, float *models, uint8_t *valid, int per_pair,
-                               const int32_t *gate_iters, const double *gate_max_iters, void *stream);
-int dr_solve_stewenius5_gated_f32(const float *samples, int Bt, float *models, uint8_t *valid, int per_pair,
-                                  const int32_t *gate_iters, const double *gate_max_iters, void *stream);
 int dr_solve_f8_f32(const float *samples, const float *weights, int Bt, int n, float *models, uint8_t *valid,
                     void *stream);
 int dr_solve_f8_f64(const double *samples, const double *weights, int Bt, int n, double *models, uint8_t *valid,
@@ -290,19 +274,18 @@ int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const floa
  *   arithmetic yields for them).  valid [P,M] uint8 (optional, NULL = score everything): slots the solver marked
  *   invalid (eye(3) fillers of non-real roots) get score 0 and an all-false mask row without being evaluated.
  * ------------------------------------------------------------------------------------------ */
+/*   gate_iters / gate_max_iters (f32; optional, NULL = none; round 6: the `_gated` twin of round 5 folded in): a round > 1 of a
+ *   multi-round test-mode call -- the blocks of a pair with gate_iters[p] >= gate_max_iters[p] return at once, its scores / masks
+ *   keep their contents (dr_ransac_update ignores such pairs). */
 int dr_msac_score_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
-                      int M, int N, float *scores, uint8_t *masks, void *stream);
+                      int M, int N, float *scores, uint8_t *masks, const int32_t *gate_iters, const double *gate_max_iters,
+                      void *stream);
 int dr_msac_score_f64(const double *matches, const double *models, const uint8_t *valid, const double *thr, int P,
                       int M, int N, double *scores, uint8_t *masks, void *stream);
-/* The same operation with the kernel family named explicitly (kept for ABI stability):
- *   path 0 = path 1 = what dr_msac_score_f32 runs: every (model, point) through the f32 fma chain on the vector units (any N;
- *           rows of <= 256 points: a wave per model with 1 / 2 / 4 points per lane, longer rows: a lane owns 8 / 16 points);
- *   path 2  (round 2: matrix-core candidate filter + exact evaluation of the candidates; bit-identical masks, measured slower,
- *           DESIGN.md section 2b) left the library in round 4 (scratch/k4_filter_kernel.patch): DR_EINVAL. */
-int dr_msac_score_gated_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P, int M, int N,
-                            float *scores, uint8_t *masks, const int32_t *gate_iters, const double *gate_max_iters, void *stream);
-int dr_msac_score_path_f32(const float *matches, const float *models, const uint8_t *valid, const float *thr, int P,
-                           int M, int N, float *scores, uint8_t *masks, int path, void *stream);
+/* (The explicit-path entry of rounds 2-5, dr_msac_score_path_f32, is gone: path 0 = path 1 = this kernel family -- every (model,
+ * point) through the f32 fma chain on the vector units; rows of <= 256 points: a wave per model with 1 / 2 / 4 points per lane,
+ * longer rows: a lane owns 8 / 16 points -- and path 2, the matrix-core candidate filter of round 2, measured slower, left the
+ * library in round 4: scratch/k4_filter_kernel.patch.) */
 /* dL/dmodels [P,M,9] from dL/dscores [P,M] (flows only through points with d2 < thr2). */
 int dr_msac_score_bwd_f32(const float *matches, const float *models, const float *thr, const float *grad_scores,
                           int P, int M, int N, float *grad_models, void *stream);
@@ -311,20 +294,19 @@ int dr_msac_score_bwd_f32(const float *matches, const float *models, const float
  *   pts [P,N,6] = (p,q); models [P,M,16] (4x4: q_hat = R p + t with the reference's row-vector descriptor
  *   D = model[:3,:]^T, ransac.py:380); res_sum [P,M] = sum_n d2; masks [P,M,N] = d2 < threshold or NULL.
  *   The reference's scalar mean is sum(res_sum)/(M*N), left to the caller. */
+/*   accumulate (f32): != 0 = the sums are ADDED to res_sum, which must hold zeros (dr_solve_rigid_gather_f32 with zero_sums =
+ *   res_sum, M = B, leaves it so): no memset launch (round 6: the `_acc` twin of round 4 folded in) */
 int dr_rigid_residual_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
-                          float *res_sum, uint8_t *masks, void *stream);
+                          float *res_sum, uint8_t *masks, int accumulate, void *stream);
 int dr_rigid_residual_f64(const double *pts, const double *models, double threshold, int P, int M, int N,
                           double *res_sum, uint8_t *masks, void *stream);
 /* Round 4, test mode of the 3-D driver (RANSAC3D.__call__, ransac.py:355-367,380): K2 + K3r in one launch and K4r without its
  * memset launch.
  *   dr_solve_rigid_gather_f32: samples are read straight through the index sets -- matches [P,N,6], idx [P,B,k] ->
  *     models [P*B,16], R / t / scale (may be NULL), valid [P*B]; zero_sums [P*B] (may be NULL) is cleared on the way;
- *   dr_rigid_residual_acc_f32: dr_rigid_residual_f32 with the sums ADDED to res_sum [P,M], which must hold zeros
- *     (dr_solve_rigid_gather_f32 with zero_sums = res_sum, M = B, leaves it so). */
+ *   dr_rigid_residual_f32(accumulate = 1) then adds the sums to it. */
 int dr_solve_rigid_gather_f32(const float *matches, const int32_t *idx, int P, int B, int N, int k, int flag, float *models,
                               float *R, float *t, float *scale, uint8_t *valid, float *zero_sums, void *stream);
-int dr_rigid_residual_acc_f32(const float *pts, const float *models, float threshold, int P, int M, int N,
-                              float *res_sum, uint8_t *masks, void *stream);
 int dr_rigid_residual_bwd_f32(const float *pts, const float *models, const float *grad_res, int P, int M, int N,
                               float *grad_models, void *stream);
 
@@ -348,15 +330,12 @@ int dr_ransac3d_update_f64(const double *pts, const double *models, const uint8_
  *   chosen[p,b] = models[p,b,argmin_s ||models[p,b,s] - gt[p]||_F]; invalid slots (valid == 0) are
  *   skipped; which [P*B] int32 (-1 when no slot is valid; chosen = eye(3) then).
  * ------------------------------------------------------------------------------------------ */
+/* keep [P*B] uint8 (optional, NULL = not wanted) = (which >= 0): the `nan_filter` of ransac.py:104-106 as a flag the loss consumes
+ * (round 6: the `_keep` twin of round 3 folded in). */
 int dr_select_closest_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
-                          float *chosen, int32_t *which, void *stream);
+                          float *chosen, int32_t *which, uint8_t *keep, void *stream);
 int dr_select_closest_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
-                          double *chosen, int32_t *which, void *stream);
-/* the same with keep [P*B] uint8 = (which >= 0): the `nan_filter` of ransac.py:104-106 as a flag the loss consumes. */
-int dr_select_closest_keep_f32(const float *models, const uint8_t *valid, const float *gt, int P, int B, int S,
-                               float *chosen, int32_t *which, uint8_t *keep, void *stream);
-int dr_select_closest_keep_f64(const double *models, const uint8_t *valid, const double *gt, int P, int B, int S,
-                               double *chosen, int32_t *which, uint8_t *keep, void *stream);
+                          double *chosen, int32_t *which, uint8_t *keep, void *stream);
 /* backward: grad_models [P,B,S,9] = grad_chosen [P,B,9] at slot which[p,b], 0 elsewhere (all of it is written). */
 int dr_select_closest_bwd_f32(const float *grad_chosen, const int32_t *which, int P, int B, int S, float *grad_models,
                               void *stream);
@@ -417,23 +396,19 @@ int dr_ransac_update_f64(const double *matches, const double *models, const uint
  *                         f64; models [P,10,9], valid [P,10].
  *   dr_refit_fundamental  Hartley-normalised LSQ 8-point on the selected points (ransac.py:150-155 passes the inliers
  *                         of the best mask); models [P,9], valid [P] (0 when fewer than 8 points are selected).
+ *                         weights [P,N] (NULL = unweighted; round 6: the `_w` twin of round 3 folded in): RANSAC.__call__ with
+ *                         `weighted=1`, ransac.py:151-153 -- `estimate_model(inlier_points, soft_weights[0, inlier_indices[0]])`,
+ *                         the weights multiply the epipolar rows (fundamental_matrix_estimator.py:243-244); the Hartley
+ *                         normalisation of the selected points stays unweighted (:177-228).
  * ------------------------------------------------------------------------------------------ */
 int dr_refit_essential_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
                            void *stream);
 int dr_refit_essential_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
                            void *stream);
-int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, int P, int N, float *models, uint8_t *valid,
-                             void *stream);
-int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, int P, int N, double *models, uint8_t *valid,
-                             void *stream);
-/*   dr_refit_fundamental_w  the same with per-point row weights [P,N] (NULL = unweighted): RANSAC.__call__ with
- *                         `weighted=1`, ransac.py:151-153 -- `estimate_model(inlier_points, soft_weights[0, inlier_indices[0]])`,
- *                         the weights multiply the epipolar rows (fundamental_matrix_estimator.py:243-244); the Hartley
- *                         normalisation of the selected points stays unweighted (:177-228). */
-int dr_refit_fundamental_w_f32(const float *matches, const uint8_t *mask, const float *weights, int P, int N,
-                               float *models, uint8_t *valid, void *stream);
-int dr_refit_fundamental_w_f64(const double *matches, const uint8_t *mask, const double *weights, int P, int N,
-                               double *models, uint8_t *valid, void *stream);
+int dr_refit_fundamental_f32(const float *matches, const uint8_t *mask, const float *weights, int P, int N, float *models,
+                             uint8_t *valid, void *stream);
+int dr_refit_fundamental_f64(const double *matches, const uint8_t *mask, const double *weights, int P, int N, double *models,
+                             uint8_t *valid, void *stream);
 
 /* K7 acceptance (ransac.py:173-185): MSAC scores of the S refit candidates of every pair (cand [P,S,9], cand_valid [P,S]
  * or NULL); where the best candidate scores strictly higher than best_score[p], best_score[p] and best_model[p] ([P,9])

@@ -31,6 +31,6 @@ def test_version_and_error_string():
 def test_bad_arguments_return_einval_without_touching_the_gpu():
     lib = L.lib()
     lib.dr_msac_score_f32.restype = ctypes.c_int
-    rc = lib.dr_msac_score_f32(None, None, None, None, 1, 1, 1, None, None, None)
+    rc = lib.dr_msac_score_f32(None, None, None, None, 1, 1, 1, None, None, None, None, None)
     assert rc == -1
     assert b"null" in lib.dr_last_error()

@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 
 # ---------------------------------------------------------------------------------------------------- K4, explicit path
 def test_msac_explicit_path_is_the_general_kernels_and_path2_is_refused(dev):
-    """dr_msac_score_path_f32: path 1 = path 0 (bit-identical); path 2 (the round-2 matrix-core filter kernel) left the
-    library in round 4 (scratch/k4_filter_kernel.patch) and is refused, as is any path for f64"""
+    """ops.msac_score(path=): path 1 = path 0 (one kernel family since round 4); path 2 (the round-2 matrix-core filter kernel)
+    left the library in round 4 (scratch/k4_filter_kernel.patch) and is refused.  (Round 6: the `_path_` entry point is gone, the
+    argument is checked where it is given.)"""
     from differentiable_ransac_amd import _lib, ops, synth
     b = synth.batch_two_view(2, 2000, seed0=2100)
     gen = torch.Generator().manual_seed(3)
@@ -25,8 +26,6 @@ def test_msac_explicit_path_is_the_general_kernels_and_path2_is_refused(dev):
     assert torch.equal(s0, s1) and torch.equal(k0, k1)
     with pytest.raises(_lib.DransacError):
         ops.msac_score(mt, md, 7.5e-4, path=2)
-    with pytest.raises(_lib.DransacError):
-        ops.msac_score(mt.double(), md.double(), 7.5e-4, path=1)   # f32 only
 
 
 # ---------------------------------------------------------------------------------------------------- C5-size train step

@@ -83,7 +83,7 @@ def test_bench_plain_launch_two_ranks_on_one_gpu():
 # ---------------------------------------------------------------------------------------------------------------------
 # weighted LSQ refit of F (`-fmat 1 -wei 1 -tr 0`, ransac.py:151-153)
 def test_weighted_fundamental_refit_kernel_vs_reference(dev):
-    """dr_refit_fundamental_w on (inliers of the reference run's best mask, the reference run's row-0 soft weights) against the
+    """dr_refit_fundamental (weights given) on (inliers of the reference run's best mask, the reference run's row-0 soft weights) against the
     reference estimator's own output (fixture generated by importing /root/reference) and the f64 oracle."""
     from differentiable_ransac_amd import ops
     from tests.conftest import load_golden

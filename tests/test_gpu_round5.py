@@ -1,5 +1,5 @@
 """Round 5 on the GPU: the two-phase five-point kernels (one lane per sample for the front stage, hand-over in accumulation
-registers: dr_solve_nister5_path_f32 / dr_solve_stewenius5_path_f32 with path = 2) against the f64 CPU oracle and against the
+registers: dr_solve_nister5_f32 / dr_solve_stewenius5_f32 with path = 2) against the f64 CPU oracle and against the
 lane-pair kernels they replace on large grids.  Reference: nister.py:69-408, stewenius.py:20-80."""
 import pytest
 import torch
@@ -319,7 +319,7 @@ def test_screened_sampler_with_large_logit_offsets_equals_the_unscreened_kernel(
 # ------------------------------------------------------------------------------------- K1, short rows: the screened register kernel
 @pytest.mark.parametrize("N,B,k", [(2000, 1024, 5), (2048, 256, 3), (1000, 64, 5), (500, 1024, 1), (2000, 1024, 4)])
 def test_screened_short_row_sampler_equals_the_unscreened_kernel(dev, N, B, k):
-    """dr_gumbel_topk_gather_gated_f32 with a screening workspace (round 5): only the points whose Philox word can lift them to
+    """dr_gumbel_topk_gather_f32 with a screening workspace (round 5): only the points whose Philox word can lift them to
     logsumexp(logits) - ln(11 + k) are evaluated -- index sets and gathered samples equal to the unscreened register kernel's, bit for
     bit, for ordinary, sharply peaked, flat and shifted logits (flat rows: thousands of candidates -> the unscreened path inside)"""
     from differentiable_ransac_amd import ops, synth

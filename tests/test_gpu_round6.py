@@ -41,7 +41,7 @@ def test_super_rounds_equal_the_batch_by_batch_loop(dev, solver, B):
 
 
 def test_super_round_sampler_rows_are_the_batches_rows(dev):
-    """dr_gumbel_topk_gather_gated_f32(sub = B): row b of the super-round = row b % B of the call with seed + b // B, for the
+    """dr_gumbel_topk_gather_f32(sub = B): row b of the super-round = row b % B of the call with seed + b // B, for the
     register kernel (N = 2000), the general kernel (N = 1999: not a multiple of 4) and the streaming kernel (N = 4096)"""
     from differentiable_ransac_amd import ops
     torch.manual_seed(0)

@@ -71,7 +71,7 @@ def test_fivepoint_golden(dev, solver, dtype, path):
 
 
 def test_nister_mixed_precision_entry(dev):
-    """dr_solve_nister5_f32_hp (train mode): f64 models equal to the f64 entry on the widened samples up to the f64
+    """dr_solve_nister5_f32 with models_f64 (train mode): f64 models equal to the f64 entry on the widened samples up to the f64
     polish tolerance (the two instantiations are compiled separately, so not bit-for-bit), f32 models the exact
     rounding of the f64 ones, same valid flags."""
     from differentiable_ransac_amd import ops
