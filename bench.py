@@ -737,10 +737,13 @@ def config_cpu_baselines(budget_s=24.0):
     return out
 
 
+PMC_CAPTURE = "r6_pmc_fetch_write.json"   # the round's rocprofv3 --pmc capture of the headline workload (tools/rocprof_pmc_summary.py)
+
+
 def pmc_traffic(kernel_key, shape):
     """HBM bytes per launch of the scoring kernel from the committed rocprofv3 PMC passes, valid only for the kernel
     source they were collected on: the JSON carries the sha256 of the source files, compared with the tree's."""
-    path = os.path.join(ROOT, "profiles", "r5_pmc_fetch_write.json")
+    path = os.path.join(ROOT, "profiles", PMC_CAPTURE)
     if not os.path.exists(path):
         return None, "no PMC capture committed for this round"
     rec = json.load(open(path))
@@ -748,16 +751,16 @@ def pmc_traffic(kernel_key, shape):
     for rel, sha in srcs.items():
         p = os.path.join(ROOT, rel)
         if not os.path.exists(p) or hashlib.sha256(open(p, "rb").read()).hexdigest() != sha:
-            return None, f"{rel} changed since profiles/r5_pmc_fetch_write.json was collected: traffic not attributable"
+            return None, f"{rel} changed since profiles/{PMC_CAPTURE} was collected: traffic not attributable"
     if rec.get("workload") != shape:
-        return None, f"profiles/r5_pmc_fetch_write.json was collected on {rec.get('workload')}, this run is {shape}"
+        return None, f"profiles/{PMC_CAPTURE} was collected on {rec.get('workload')}, this run is {shape}"
     pmc = rec.get("kernels", {}).get(kernel_key, {})
     if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
-        return None, f"no counters for {kernel_key} in profiles/r5_pmc_fetch_write.json"
+        return None, f"no counters for {kernel_key} in profiles/{PMC_CAPTURE}"
     # gfx950: FETCH_SIZE shows half the bytes of 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled (upper bound:
     # most of this kernel's reads are scalar-cache model loads); WRITE_SIZE taken as is (matches the mask bytes to 0.2 %)
     return ((2.0 * pmc["FETCH_SIZE"]["avg"] + pmc["WRITE_SIZE"]["avg"]) * 1024.0,
-            "NOT measured in this run: read from the builder-run capture profiles/r5_pmc_fetch_write.json ((2*FETCH_SIZE + "
+            f"NOT measured in this run: read from the builder-run capture profiles/{PMC_CAPTURE} ((2*FETCH_SIZE + "
             "WRITE_SIZE) KiB per dispatch), accepted only because the sha256 of the kernel sources it was collected on equals the tree's")
 
 

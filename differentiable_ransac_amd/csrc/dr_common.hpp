@@ -46,6 +46,16 @@ struct PairGate {
   }
 };
 
+// The per-call sampler key of the batched drivers, advanced on the device (dr_seed_next_n; also the tail of dr_ransac_init when it
+// is handed a seed state): state[0] = base, state[1] = calls so far -> out[i] = base * 0x9E3779B97F4A7C15 + calls + i, calls += n.
+// Called by ONE block; returns after a block-level barrier.
+__device__ __forceinline__ void seed_next_block(uint64_t *__restrict__ state, uint64_t *__restrict__ out, int n) {
+  const uint64_t s0 = state[0] * 0x9E3779B97F4A7C15ull + state[1];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = s0 + (uint64_t)i;
+  __syncthreads();
+  if (threadIdx.x == 0) state[1] += (uint64_t)n;
+}
+
 // ---- wave64 reductions (ds_swizzle/DPP chosen by the compiler from the xor pattern) ----
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

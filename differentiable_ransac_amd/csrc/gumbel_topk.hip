@@ -1449,13 +1449,8 @@ __global__ void uniform_sample_kernel(uint64_t seed, int B, int k, int N, int32_
 // ---- seed of the next call, on the device: state = (base, calls) -> out = base * 0x9E3779B97F4A7C15 + calls ; calls += 1
 // (what the drivers compute on the host per call; here a captured graph advances it by itself at every replay)
 __global__ void seed_next_kernel(uint64_t *__restrict__ state, uint64_t *__restrict__ out, int n = 1) {
-  // n > 1: the seeds of the next n calls at once (a multi-round call draws one per round: one launch instead of n)
-  if (blockIdx.x == 0) {
-    const uint64_t s0 = state[0] * 0x9E3779B97F4A7C15ull + state[1];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = s0 + (uint64_t)i;
-  }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) state[1] += (uint64_t)n;
+  // n > 1: the seeds of the next n calls at once (a multi-round call draws one per batch: one launch instead of n)
+  if (blockIdx.x == 0) seed_next_block(state, out, n);
 }
 
 // ---- K2 gather forward / backward

@@ -916,7 +916,8 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
                                                          T *__restrict__ best_score, T *__restrict__ best_model,
                                                          uint8_t *__restrict__ best_mask,
                                                          int32_t *__restrict__ best_inliers, int32_t *__restrict__ iters,
-                                                         double *__restrict__ max_iters) {
+                                                         double *__restrict__ max_iters, uint64_t *__restrict__ seed_state,
+                                                         uint64_t *__restrict__ seeds_out, int n_seeds) {
   const int p = blockIdx.x;
   if (threadIdx.x == 0) {
     T th = threshold;
@@ -935,6 +936,8 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
   }
   if (threadIdx.x < 9) best_model[(size_t)p * 9 + threadIdx.x] = (threadIdx.x % 4 == 0) ? T(1) : T(0);
   for (int n = threadIdx.x; n < N; n += blockDim.x) best_mask[(size_t)p * N + n] = 0;
+  // round 6: the call's sampler keys from the same launch (dr_seed_next_n's work: one node fewer in a replayed call)
+  if (p == 0 && seed_state) seed_next_block(seed_state, seeds_out, n_seeds);
 }
 
 template <typename T>
@@ -1048,25 +1051,29 @@ int dr_refit_accept_f64(const double *matches, const double *cand, const uint8_t
 
 int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, float *thr, float *best_score, float *best_model, uint8_t *best_mask,
-                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
+                       int n_seeds, void *stream) {
   DR_REQUIRE(P > 0 && N > 0 && (k_stride == 0 || k_stride == 9), "bad sizes");
   DR_REQUIRE(thr && best_score && best_model && best_mask && best_inliers && iters && max_iters && (!K1 == !K2),
              "null pointer");
+  DR_REQUIRE(!seed_state || (seeds_out && n_seeds >= 1 && n_seeds <= 65536), "seed state: need seeds_out and 1 <= n_seeds <= 65536");
   hipLaunchKernelGGL((dr::ransac_init_kernel<float>), dim3(P), dim3(256), 0, (hipStream_t)stream, K1, K2, k_stride,
                      (float)threshold, N, max_iterations, thr, best_score, best_model, best_mask, best_inliers, iters,
-                     max_iters);
+                     max_iters, seed_state, seeds_out, n_seeds);
   return dr::check_launch("ransac_init_kernel");
 }
 
 int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, double *thr, double *best_score, double *best_model, uint8_t *best_mask,
-                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream) {
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
+                       int n_seeds, void *stream) {
   DR_REQUIRE(P > 0 && N > 0 && (k_stride == 0 || k_stride == 9), "bad sizes");
   DR_REQUIRE(thr && best_score && best_model && best_mask && best_inliers && iters && max_iters && (!K1 == !K2),
              "null pointer");
+  DR_REQUIRE(!seed_state || (seeds_out && n_seeds >= 1 && n_seeds <= 65536), "seed state: need seeds_out and 1 <= n_seeds <= 65536");
   hipLaunchKernelGGL((dr::ransac_init_kernel<double>), dim3(P), dim3(256), 0, (hipStream_t)stream, K1, K2, k_stride,
                      threshold, N, max_iterations, thr, best_score, best_model, best_mask, best_inliers, iters,
-                     max_iters);
+                     max_iters, seed_state, seeds_out, n_seeds);
   return dr::check_launch("ransac_init_kernel");
 }
 

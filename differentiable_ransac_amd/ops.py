@@ -72,24 +72,42 @@ def select_best(matches: torch.Tensor, models: torch.Tensor, scores: torch.Tenso
 class RansacState:
     """Per-pair test-mode state kept on the device (best score / model / mask / inlier count, iteration counters)."""
 
-    def __init__(self, P: int, N: int, max_iterations: int, device, dtype, _init: bool = True):
+    def __init__(self, P: int, N: int, max_iterations: int, device, dtype, _init: bool = True, packed: bool = False):
         alloc = torch.zeros if _init else torch.empty
-        self.best_score = alloc(P, device=device, dtype=dtype)
-        self.best_model = (torch.eye(3, device=device, dtype=dtype).repeat(P, 1, 1) if _init
-                           else torch.empty(P, 3, 3, device=device, dtype=dtype))
-        self.best_mask = alloc(P, N, device=device, dtype=torch.bool)
+        self.packed = None
+        if packed and P == 1 and dtype == torch.float32 and not _init:
+            # one pair, f32: everything a call hands out in ONE buffer -- model 36 B | score 4 | iterations 4 | mask N -- so that the
+            # replayed drop-in call (ransac._GraphedCall) returns it without a gather launch (round 6)
+            self.packed = torch.empty(44 + N, device=device, dtype=torch.uint8)
+            self.best_model = self.packed[:36].view(torch.float32).view(1, 3, 3)
+            self.best_score = self.packed[36:40].view(torch.float32)
+            self.iters = self.packed[40:44].view(torch.int32)
+            self.best_mask = self.packed[44:].view(torch.bool).view(1, N)
+        else:
+            self.best_score = alloc(P, device=device, dtype=dtype)
+            self.best_model = (torch.eye(3, device=device, dtype=dtype).repeat(P, 1, 1) if _init
+                               else torch.empty(P, 3, 3, device=device, dtype=dtype))
+            self.best_mask = alloc(P, N, device=device, dtype=torch.bool)
+            self.iters = alloc(P, device=device, dtype=torch.int32)
         self.best_inliers = alloc(P, device=device, dtype=torch.int32)
-        self.iters = alloc(P, device=device, dtype=torch.int32)
         self.max_iters = (torch.full((P,), float(max_iterations), device=device, dtype=torch.float64) if _init
                           else torch.empty(P, device=device, dtype=torch.float64))
         self.max_iterations = max_iterations
 
 
 def ransac_init(P: int, N: int, max_iterations: int, threshold: float, K1: Optional[torch.Tensor],
-                K2: Optional[torch.Tensor], device, dtype) -> Tuple[RansacState, torch.Tensor]:
+                K2: Optional[torch.Tensor], device, dtype, seeds=None, packed: bool = False) -> Tuple[RansacState, torch.Tensor]:
     """dr_ransac_init: the per-pair state and the threshold normalised as ransac.py:49-53 (K1/K2 [3,3] or [P,3,3];
-    None = threshold used as is), in ONE launch.  Returns (state, thr [P])."""
-    st = RansacState(P, N, max_iterations, device, dtype, _init=False)
+    None = threshold used as is), in ONE launch.  Returns (state, thr [P]).
+    seeds = (DeviceSeed, n): the same launch also draws the next n sampler keys (DeviceSeed.next_block(n)); they are returned as
+    `state.seeds` ([n] int64).  packed: one pair, f32 -- the state lives in one buffer (RansacState.packed)."""
+    st = RansacState(P, N, max_iterations, device, dtype, _init=False, packed=packed)
+    st.seeds = None
+    seed_state = None
+    n_seeds = 0
+    if seeds is not None:
+        seed_state, n_seeds = seeds[0].state, int(seeds[1])
+        st.seeds = torch.empty(n_seeds, dtype=torch.int64, device=device)
     thr = torch.empty(P, device=device, dtype=dtype)
     k_stride = 0
     if K1 is not None:
@@ -101,7 +119,8 @@ def ransac_init(P: int, N: int, max_iterations: int, threshold: float, K1: Optio
             k_stride = 9
     L.call(f"dr_ransac_init_{L.suffix(dtype)}", ptr(K1), ptr(K2), c_int(k_stride), L.c_double(float(threshold)),
            c_int(P), c_int(N), c_int(max_iterations), ptr(thr), ptr(st.best_score), ptr(st.best_model),
-           ptr(st.best_mask), ptr(st.best_inliers), ptr(st.iters), ptr(st.max_iters), stream())
+           ptr(st.best_mask), ptr(st.best_inliers), ptr(st.iters), ptr(st.max_iters), ptr(seed_state), ptr(st.seeds),
+           c_int(n_seeds), stream())
     return st, thr
 
 
@@ -248,7 +267,9 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
     want_screen = SCREEN_SHORT_ROWS if screen is None else screen
     ws = (torch.empty((P, N + 32), device=logits.device, dtype=torch.int32)
           if want_screen and N <= 2048 and N % 4 == 0 and tau == 1.0 and k <= 5 and B >= 64 else None)
-    want_race = (K1_RACE if race is None else race) and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
+    # (automatic: from 32 pairs of >= 256 rows on -- the prologue launch costs 3-4 us, the form saves ~0.12 us per 1024 rows of 2000 points:
+    #  a one-pair call would lose, scratch/runs/r6_gpu_o.sh)
+    want_race = ((K1_RACE and P * B >= 32768 and P >= 32) if race is None else race) and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
     rws = torch.empty((P, N + 32), device=logits.device, dtype=torch.float32) if want_race else None
     # (gate: a later round of a multi-round call, terminated pairs are skipped)
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),

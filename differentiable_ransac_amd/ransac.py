@@ -17,6 +17,10 @@ import torch
 from . import ops
 
 
+import os as _os
+_FOLD_SETUP = _os.environ.get("DRANSAC_FOLD_SETUP", "1") != "0"   # A/B: 0 = seed launch and result gather as separate nodes (round 5)
+
+
 def adaptive_iteration_number(inlier_number, point_number, sample_size, confidence=0.999, eps=1e-5,
                               max_iterations=5000):
     """ransac.py:202-215."""
@@ -312,8 +316,11 @@ class _GraphedCall(object):
 
     def _run(self):
         out = self.driver(self.matches, self.logits, self.K1, self.K2)
+        # one buffer for everything a call returns: model 36 B | score 4 | iterations 4 | mask N (handed out by ONE copy per call).
+        # Round 6: the one-pair state of a device-terminated f32 call already lives in such a buffer (ops.RansacState.packed)
+        if out.get("packed") is not None:
+            return out["packed"]
         u8 = lambda t: t.contiguous().view(torch.uint8).reshape(-1)
-        # one buffer for everything a call returns: model 36 B | score 4 | iterations 4 | mask N (handed out by ONE copy per call)
         return torch.cat([u8(out["model"][0]), u8(out["score"][:1]), u8(out["iterations"][:1]), u8(out["mask"][0])])
 
     def __call__(self, matches, logits, K1, K2):
@@ -663,8 +670,15 @@ class BatchedRANSAC(object):
                 return out_
             if self.refit and not self.fmat:
                 pre = issue_refit()
+            # (device termination with device seeds: the keys of all batches of the call come out of the set-up launch; one pair in
+            #  f32: the state lives in one buffer, which is what the replayed drop-in call hands out)
+            draw = self.device_termination and self._dev_seed is not None and n_batches > 1 and gumbels is None
+            fold = _FOLD_SETUP and draw
             st, thr = ops.ransac_init(P, N, self.max_iterations, self.threshold, K1 if use_K else None,
-                                      K2 if use_K else None, dev, dt)
+                                      K2 if use_K else None, dev, dt, seeds=(self._dev_seed, n_batches) if fold else None,
+                                      packed=_FOLD_SETUP and self.device_termination and P == 1)
+            if draw and not fold:
+                st.seeds = self._dev_seed.next_block(n_batches)
             if pre is not None and plan and P * self.B * plan[0] >= 65536:
                 # Dispatch order (round 5): a refit block wants a whole SIMD's registers and 38.9 KB of LDS on its CU; once the
                 # sampler's 32 768 light workgroups are in the queue it does not get them until the sampler's grid runs dry.
@@ -702,8 +716,8 @@ class BatchedRANSAC(object):
                     raise ValueError("device_termination issues every round: at most 16 device rounds per call (see super_hypotheses)")
                 want_w = bool(self.weighted and self.solver == "f8" and self.refit)
                 last_w = torch.zeros((P, N), device=dev, dtype=dt) if want_w else None
-                if self._dev_seed is not None and n_batches > 1 and gumbels is None:
-                    self._seed_queue = (self._dev_seed.next_block(n_batches), 0)    # consecutive seeds, one per BATCH
+                if draw:
+                    self._seed_queue = (st.seeds, 0)    # consecutive seeds, one per BATCH (drawn by dr_ransac_init)
                 for r in range(rounds):
                     gate = st if r > 0 else None
                     models, valid, _, row0 = self._hypotheses(matches, logits, noise_of(r), gate=gate, R=plan[r])
@@ -785,7 +799,7 @@ class BatchedRANSAC(object):
             # score the candidates and keep the best one where it beats the RANSAC result: one launch, in place
             ops.refit_accept(matches, cand, cvalid, thr, best_score, best_model)
         return dict(model=best_model, mask=best_mask, score=best_score, iterations=iters, inliers=best_inl,
-                    masks=all_masks)
+                    masks=all_masks, packed=st.packed)
 
 
 class BatchedRANSAC3D(object):

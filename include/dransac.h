@@ -359,13 +359,17 @@ int dr_select_best_f64(const double *matches, const double *models, const uint8_
  *   K1, K2: calibration matrices, [3,3] shared by all pairs (k_stride 0) or [P,3,3] (k_stride 9), or both NULL
  *   (fundamental-matrix mode / threshold already normalised: thr[p] = threshold).  Otherwise
  *   thr[p] = threshold / ((K1[0,0] + K1[1,1] + K1[0,0] + K2[1,1]) / 4)  -- sic, ransac.py:52.
- *   State: best_score = 0, best_model = eye(3), best_mask = 0, best_inliers = 0, iters = 0, max_iters = max_iterations. */
+ *   State: best_score = 0, best_model = eye(3), best_mask = 0, best_inliers = 0, iters = 0, max_iters = max_iterations.
+ *   seed_state / seeds_out / n_seeds (optional, NULL / 0 = none; round 6): the call's sampler keys from the same launch --
+ *   dr_seed_next_n(seed_state, seeds_out, n_seeds), one node fewer in a replayed call. */
 int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, float *thr, float *best_score, float *best_model, uint8_t *best_mask,
-                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
+                       int n_seeds, void *stream);
 int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, double *thr, double *best_score, double *best_model, uint8_t *best_mask,
-                       int32_t *best_inliers, int32_t *iters, double *max_iters, void *stream);
+                       int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
+                       int n_seeds, void *stream);
 
 /* K6 (batched, state on the device)  RANSAC.__call__ ransac.py:109-144 + adaptive_iteration_number :202-215.
  *   For every pair p with iters[p] < max_iters[p] (the others have terminated and are left untouched):

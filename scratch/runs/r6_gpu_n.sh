@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 6, run n: packed one-pair state + sampler keys out of the set-up launch (two nodes fewer per replayed call): tests, loop timing
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py tests/test_gpu_drivers.py tests/test_gpu_round4.py tests/test_gpu_graphs.py -m gpu -x -q 2>&1 | tail -4
+for rep in 1 2 3; do for rbs in 1024 64; do
+  echo "rbs=$rbs $(DROPIN_RBS=$rbs timeout 300 python scratch/dropin_loop.py 2>&1 | grep 'ms per pair')"
+done; done
