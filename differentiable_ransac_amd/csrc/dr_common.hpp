@@ -56,6 +56,39 @@ __device__ __forceinline__ void seed_next_block(uint64_t *__restrict__ state, ui
   if (threadIdx.x == 0) state[1] += (uint64_t)n;
 }
 
+// Per-pair weights of the exponential-race sampler (gumbel_topk.hip, round 6): w_n = exp(lmax - logit_n) into ws [P,N] and the
+// pair's "tame" flag (all logits finite, span <= 80) into the word ws[P * N + p].  One 256-thread block per pair.
+__device__ __forceinline__ void race_weights_block(const float *__restrict__ logits, int N, int P, int p, float *__restrict__ ws) {
+  __shared__ float s_mx[4], s_mn[4];
+  __shared__ int s_bad[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float *lg = logits + (size_t)p * N;
+  float mx = -INFINITY, mn = INFINITY;
+  int bad = 0;
+  for (int n = tid; n < N; n += 256) {
+    const float l = lg[n];
+    const bool fin = fabsf(l) < INFINITY;   // false for NaN and +-inf
+    bad |= fin ? 0 : 1;
+    mx = fin ? fmaxf(mx, l) : mx;
+    mn = fin ? fminf(mn, l) : mn;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    bad |= __shfl_xor(bad, o, 64);
+  }
+  if (lane == 0) { s_mx[wv] = mx; s_mn[wv] = mn; s_bad[wv] = bad; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+  mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+  bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+  const bool tame = !bad && (mx - mn) <= 80.0f;
+  float *w = ws + (size_t)p * N;
+  for (int n = tid; n < N; n += 256) w[n] = tame ? __builtin_amdgcn_exp2f((mx - lg[n]) * 1.44269504088896340736f) : 0.f;
+  if (tid == 0) reinterpret_cast<int *>(ws + (size_t)P * N)[p] = tame ? 1 : 0;
+}
+
 // ---- wave64 reductions (ds_swizzle/DPP chosen by the compiler from the xor pattern) ----
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

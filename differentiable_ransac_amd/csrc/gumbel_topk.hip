@@ -323,34 +323,7 @@ __device__ __forceinline__ float log2_uniform_from_bits(uint32_t bits) {
 // near-ties).  A pair whose logits are not all finite or span more than 80 (w would overflow for points that can still win when
 // fewer than k others are in range) is flagged and keeps the two-logarithm form.  ws: w [P,N] floats, then one flag word per pair.
 __global__ __launch_bounds__(256) void gumbel_race_weights_kernel(const float *__restrict__ logits, int N, int P, float *__restrict__ ws) {
-  __shared__ float s_mx[4], s_mn[4];
-  __shared__ int s_bad[4];
-  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float *lg = logits + (size_t)p * N;
-  float mx = -INFINITY, mn = INFINITY;
-  int bad = 0;
-  for (int n = tid; n < N; n += 256) {
-    const float l = lg[n];
-    const bool fin = fabsf(l) < INFINITY;   // false for NaN and +-inf
-    bad |= fin ? 0 : 1;
-    mx = fin ? fmaxf(mx, l) : mx;
-    mn = fin ? fminf(mn, l) : mn;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    mn = fminf(mn, __shfl_xor(mn, o, 64));
-    bad |= __shfl_xor(bad, o, 64);
-  }
-  if (lane == 0) { s_mx[wv] = mx; s_mn[wv] = mn; s_bad[wv] = bad; }
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-  mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
-  bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
-  const bool tame = !bad && (mx - mn) <= 80.0f;
-  float *w = ws + (size_t)p * N;
-  for (int n = tid; n < N; n += 256) w[n] = tame ? __builtin_amdgcn_exp2f((mx - lg[n]) * 1.44269504088896340736f) : 0.f;
-  if (tid == 0) reinterpret_cast<int *>(ws + (size_t)P * N)[p] = tame ? 1 : 0;
+  race_weights_block(logits, N, P, blockIdx.x, ws);   // (dr_common.hpp: dr_ransac_init runs the same code when it is handed the logits)
 }
 
 // f32, in-kernel Philox, logits given, tau = 1, N % 4 == 0 and N <= 2048, no dense outputs: what every RANSAC round of the
@@ -1112,8 +1085,9 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
                       int32_t *idx, T *y_sel, T *lse, T *y_soft, T *ret, T *gumbel_out, hipStream_t st,
                       const uint64_t *seed_ptr = nullptr, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr,
                       bool *gathered = nullptr, uint32_t *screen_ws = nullptr, PairGate gate = PairGate(), int sub = 0,
-                      float *race_ws = nullptr) {
-  // race_ws (index-only mode, register kernel, no screen): (N + 32) * P floats -- the one-logarithm form
+                      float *race_ws = nullptr, bool race_ready = false) {
+  // race_ws (index-only mode, register kernel, no screen): (N + 32) * P floats -- the one-logarithm form; race_ready: the weights are
+  // already in it (dr_ransac_init wrote them for the whole call): no prologue launch
   // sub (index-only mode, in-kernel noise): rows per sub-batch of a super-round (GumbelArgs::sub); 0 = one batch
   if (gathered) *gathered = false;
   GumbelArgs<T> a{logits, gumbel, seed, tau, P, B, N, k, seed_ptr, sub};
@@ -1141,7 +1115,7 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
       }
       else
       {
-        if (race_ws)
+        if (race_ws && !race_ready)
           hipLaunchKernelGGL(gumbel_race_weights_kernel, dim3(P), dim3(256), 0, st, (const float *)logits, N, P, race_ws);
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<false>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
                            (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, gate, (const uint32_t *)nullptr,
@@ -1620,7 +1594,7 @@ int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream) {
 // ransac.py:65).  One launch when the register kernel serves the shape, sampler + gather launches otherwise.
 static int gumbel_topk_gather_impl(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau, int P,
                                    int B, int N, int k, int32_t *idx, float *samples, dr::PairGate gate, void *stream,
-                                   uint32_t *screen_ws = nullptr, int sub = 0, float *race_ws = nullptr) {
+                                   uint32_t *screen_ws = nullptr, int sub = 0, float *race_ws = nullptr, bool race_ready = false) {
   const float *y_sel = nullptr, *lse = nullptr, *y_soft = nullptr, *ret = nullptr;
   DR_REQUIRE(logits && matches && samples, "null pointer");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
@@ -1628,7 +1602,7 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
   bool gathered = false;
   if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, nullptr, nullptr, nullptr, nullptr, nullptr,
                                             (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
-                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate, sub, race_ws))
+                                            reinterpret_cast<float4 *>(samples), &gathered, screen_ws, gate, sub, race_ws, race_ready))
     return rc;
   if (gathered) return 0;
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,
@@ -1679,7 +1653,8 @@ int dr_gumbel_topk_gather_bwd_f32(const float *logits, const float *matches, uin
 // `sub_models` walks them in order); 0 = one batch.  Soft (train-mode) outputs have no sub-batch form.
 int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                               int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                              const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream) {
+                              const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, int race_ready,
+                              void *stream) {
   DR_REQUIRE((gate_iters == nullptr) == (gate_max_iters == nullptr), "gate: both pointers or neither");
   DR_REQUIRE(sub >= 0, "sub-batch size");
   DR_REQUIRE(!(race_ws && screen_ws), "one workspace: the screened or the one-logarithm form");
@@ -1688,7 +1663,8 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
   dr::PairGate gate;
   gate.iters = gate_iters;
   gate.max_iters = gate_max_iters;
-  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws, sub, race_ws);
+  return gumbel_topk_gather_impl(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, gate, stream, screen_ws, sub, race_ws,
+                                 race_ready != 0);
 }
 
 // K1, index sets only, in-kernel noise, with an optional screening workspace ((N + 32) * P words, 16-byte aligned): long rows

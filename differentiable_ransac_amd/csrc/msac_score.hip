@@ -792,6 +792,8 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
   const int msub = (sub_models > 0 && sub_models < M) ? sub_models : M;
   const int R = (M + msub - 1) / msub;
   constexpr int kWaves = kUpdThreads / kWave;
+  T one_val = -INFINITY;
+  int one_idx = 0x7fffffff;
   if (R <= kWaves) {
     // few sub-batches (R = 1: the one batch): kWaves / R waves share a sub-batch, every load of the launch in flight at once --
     // two sub-batches of 10 240 scores cost what one costs
@@ -820,7 +822,13 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
     }
     if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
     __syncthreads();
-    if (tid < R) {
+    if (R == 1) {
+      // one batch (the common launch): every thread merges the sixteen wave results itself -- no second barrier (round 5's form)
+      one_val = s_val[0];
+      one_idx = s_idx[0];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) argmax_merge(one_val, one_idx, s_val[w], s_idx[w]);
+    } else if (tid < R) {
       bv = s_val[tid * wps]; bi = s_idx[tid * wps];
       for (int w = 1; w < wps; ++w) argmax_merge(bv, bi, s_val[tid * wps + w], s_idx[tid * wps + w]);
       s_sub_val[tid] = bv;
@@ -852,14 +860,14 @@ __global__ __launch_bounds__(kUpdThreads) void ransac_update_kernel(
       if (lane == 0) { s_sub_val[j] = bv; s_sub_idx[j] = bi; }
     }
   }
-  __syncthreads();
+  if (R > 1) __syncthreads();
   T bs = best_score[p];
   const T t = T(1.5) * thr[p];
   const T inv_thr2 = T(1) / (t * t);
   for (int j = 0; j < R; ++j) {
     if ((double)it >= mi) break;                                 // ransac.py:55 (block-uniform: every thread holds the same it / mi)
-    const T bv = s_sub_val[j];
-    const int bi = s_sub_idx[j];
+    const T bv = R == 1 ? one_val : s_sub_val[j];
+    const int bi = R == 1 ? one_idx : s_sub_idx[j];
     const bool have = bi != 0x7fffffff;
     const bool better = have && (bv > bs || it == 0);           // ransac.py:116
     if (better) {
@@ -917,7 +925,8 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
                                                          uint8_t *__restrict__ best_mask,
                                                          int32_t *__restrict__ best_inliers, int32_t *__restrict__ iters,
                                                          double *__restrict__ max_iters, uint64_t *__restrict__ seed_state,
-                                                         uint64_t *__restrict__ seeds_out, int n_seeds) {
+                                                         uint64_t *__restrict__ seeds_out, int n_seeds,
+                                                         const float *__restrict__ race_logits, float *__restrict__ race_ws, int P) {
   const int p = blockIdx.x;
   if (threadIdx.x == 0) {
     T th = threshold;
@@ -938,6 +947,8 @@ __global__ __launch_bounds__(256) void ransac_init_kernel(const T *__restrict__ 
   for (int n = threadIdx.x; n < N; n += blockDim.x) best_mask[(size_t)p * N + n] = 0;
   // round 6: the call's sampler keys from the same launch (dr_seed_next_n's work: one node fewer in a replayed call)
   if (p == 0 && seed_state) seed_next_block(seed_state, seeds_out, n_seeds);
+  // ... and the per-pair weights of the one-logarithm sampler (the logits do not change between the rounds of a call)
+  if (race_ws) race_weights_block(race_logits, N, P, p, race_ws);
 }
 
 template <typename T>
@@ -1052,28 +1063,30 @@ int dr_refit_accept_f64(const double *matches, const double *cand, const uint8_t
 int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, float *thr, float *best_score, float *best_model, uint8_t *best_mask,
                        int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
-                       int n_seeds, void *stream) {
+                       int n_seeds, const float *race_logits, float *race_ws, void *stream) {
   DR_REQUIRE(P > 0 && N > 0 && (k_stride == 0 || k_stride == 9), "bad sizes");
+  DR_REQUIRE((race_logits == nullptr) == (race_ws == nullptr), "race weights: logits and workspace, or neither");
   DR_REQUIRE(thr && best_score && best_model && best_mask && best_inliers && iters && max_iters && (!K1 == !K2),
              "null pointer");
   DR_REQUIRE(!seed_state || (seeds_out && n_seeds >= 1 && n_seeds <= 65536), "seed state: need seeds_out and 1 <= n_seeds <= 65536");
   hipLaunchKernelGGL((dr::ransac_init_kernel<float>), dim3(P), dim3(256), 0, (hipStream_t)stream, K1, K2, k_stride,
                      (float)threshold, N, max_iterations, thr, best_score, best_model, best_mask, best_inliers, iters,
-                     max_iters, seed_state, seeds_out, n_seeds);
+                     max_iters, seed_state, seeds_out, n_seeds, race_logits, race_ws, P);
   return dr::check_launch("ransac_init_kernel");
 }
 
 int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, double *thr, double *best_score, double *best_model, uint8_t *best_mask,
                        int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
-                       int n_seeds, void *stream) {
+                       int n_seeds, const float *race_logits, float *race_ws, void *stream) {
   DR_REQUIRE(P > 0 && N > 0 && (k_stride == 0 || k_stride == 9), "bad sizes");
+  DR_REQUIRE((race_logits == nullptr) == (race_ws == nullptr), "race weights: logits and workspace, or neither");
   DR_REQUIRE(thr && best_score && best_model && best_mask && best_inliers && iters && max_iters && (!K1 == !K2),
              "null pointer");
   DR_REQUIRE(!seed_state || (seeds_out && n_seeds >= 1 && n_seeds <= 65536), "seed state: need seeds_out and 1 <= n_seeds <= 65536");
   hipLaunchKernelGGL((dr::ransac_init_kernel<double>), dim3(P), dim3(256), 0, (hipStream_t)stream, K1, K2, k_stride,
                      threshold, N, max_iterations, thr, best_score, best_model, best_mask, best_inliers, iters,
-                     max_iters, seed_state, seeds_out, n_seeds);
+                     max_iters, seed_state, seeds_out, n_seeds, race_logits, race_ws, P);
   return dr::check_launch("ransac_init_kernel");
 }
 

@@ -96,13 +96,21 @@ class RansacState:
 
 
 def ransac_init(P: int, N: int, max_iterations: int, threshold: float, K1: Optional[torch.Tensor],
-                K2: Optional[torch.Tensor], device, dtype, seeds=None, packed: bool = False) -> Tuple[RansacState, torch.Tensor]:
+                K2: Optional[torch.Tensor], device, dtype, seeds=None, packed: bool = False,
+                race_logits: Optional[torch.Tensor] = None) -> Tuple[RansacState, torch.Tensor]:
     """dr_ransac_init: the per-pair state and the threshold normalised as ransac.py:49-53 (K1/K2 [3,3] or [P,3,3];
     None = threshold used as is), in ONE launch.  Returns (state, thr [P]).
     seeds = (DeviceSeed, n): the same launch also draws the next n sampler keys (DeviceSeed.next_block(n)); they are returned as
-    `state.seeds` ([n] int64).  packed: one pair, f32 -- the state lives in one buffer (RansacState.packed)."""
+    `state.seeds` ([n] int64).  packed: one pair, f32 -- the state lives in one buffer (RansacState.packed).
+    race_logits [P,N] f32: the same launch writes the per-pair weights of the one-logarithm sampler -> `state.race_ws`, to be handed
+    to gumbel_topk_gather(race_ws=...) by every round of the call."""
     st = RansacState(P, N, max_iterations, device, dtype, _init=False, packed=packed)
     st.seeds = None
+    st.race_ws = None
+    if race_logits is not None:
+        if race_logits.dtype != torch.float32 or race_logits.shape != (P, N) or not race_logits.is_contiguous():
+            raise L.DransacError("ransac_init: race_logits must be contiguous f32 [P,N]")
+        st.race_ws = torch.empty((P, N + 32), device=device, dtype=torch.float32)
     seed_state = None
     n_seeds = 0
     if seeds is not None:
@@ -120,7 +128,7 @@ def ransac_init(P: int, N: int, max_iterations: int, threshold: float, K1: Optio
     L.call(f"dr_ransac_init_{L.suffix(dtype)}", ptr(K1), ptr(K2), c_int(k_stride), L.c_double(float(threshold)),
            c_int(P), c_int(N), c_int(max_iterations), ptr(thr), ptr(st.best_score), ptr(st.best_model),
            ptr(st.best_mask), ptr(st.best_inliers), ptr(st.iters), ptr(st.max_iters), ptr(seed_state), ptr(st.seeds),
-           c_int(n_seeds), stream())
+           c_int(n_seeds), ptr(race_logits), ptr(st.race_ws), stream())
     return st, thr
 
 
@@ -248,14 +256,21 @@ SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 K1_RACE = _os.environ.get("DRANSAC_K1_RACE", "1") != "0"
 
 
+def race_form_pays(P: int, B: int, N: int, tau: float) -> bool:
+    """the automatic choice of the one-logarithm sampler: rows the register kernel serves, from 32 pairs / 32 768 rows on (the
+    prologue costs a launch, the form saves ~0.12 us per 1024 rows of 2000 points: scratch/runs/r6_gpu_o.sh)"""
+    return K1_RACE and P * B >= 32768 and P >= 32 and N <= 2048 and N % 4 == 0 and tau == 1.0
+
+
 def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None,
-                       screen: Optional[bool] = None, sub: int = 0, race: Optional[bool] = None):
+                       screen: Optional[bool] = None, sub: int = 0, race: Optional[bool] = None, race_ws: Optional[torch.Tensor] = None):
     """K1 (index sets only, in-kernel noise) + K2 in one call: matches [P,N,4] f32, logits [P,N] f32 ->
     (idx [P,B,k] int32 ascending, samples [P,B,k,4] = matches[p, idx]).  What test mode asks of sampler + gather
     (ransac.py:58-65); `seed`: int or a DeviceSeed.next() tensor.
     sub > 0 (super-rounds): the B rows are consecutive sub-batches of `sub` rows; row b draws what row b % sub of the call with
     seed + b // sub draws (the drivers' per-call seeds are consecutive integers).
-    race (None = the module default K1_RACE): the one-logarithm exponential-race form of the same top-k (rows of <= 2048 points)."""
+    race (None = automatic, race_form_pays): the one-logarithm exponential-race form of the same top-k (rows of <= 2048 points);
+    race_ws: its per-pair weights, already computed for these logits by ransac_init(race_logits=...)."""
     if matches.dtype != torch.float32 or logits.dtype != torch.float32 or matches.shape[-1] != 4:
         raise L.DransacError("gumbel_topk_gather: f32 two-view correspondences [P,N,4]")
     matches, logits = matches.contiguous(), logits.contiguous()
@@ -267,15 +282,15 @@ def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: i
     want_screen = SCREEN_SHORT_ROWS if screen is None else screen
     ws = (torch.empty((P, N + 32), device=logits.device, dtype=torch.int32)
           if want_screen and N <= 2048 and N % 4 == 0 and tau == 1.0 and k <= 5 and B >= 64 else None)
-    # (automatic: from 32 pairs of >= 256 rows on -- the prologue launch costs 3-4 us, the form saves ~0.12 us per 1024 rows of 2000 points:
-    #  a one-pair call would lose, scratch/runs/r6_gpu_o.sh)
-    want_race = ((K1_RACE and P * B >= 32768 and P >= 32) if race is None else race) and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
-    rws = torch.empty((P, N + 32), device=logits.device, dtype=torch.float32) if want_race else None
+    # race_ws: a workspace dr_ransac_init has already filled for these logits (ransac_init(race_logits=...)): no prologue launch
+    ready = race_ws is not None and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
+    want_race = not ready and (race_form_pays(P, B, N, tau) if race is None else race) and ws is None and N <= 2048 and N % 4 == 0 and tau == 1.0
+    rws = race_ws if ready else (torch.empty((P, N + 32), device=logits.device, dtype=torch.float32) if want_race else None)
     # (gate: a later round of a multi-round call, terminated pairs are skipped)
     L.call("dr_gumbel_topk_gather_f32", ptr(logits), ptr(matches), c_uint64(0 if dev_seed else seed & (2 ** 64 - 1)),
            ptr(seed if dev_seed else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(idx), ptr(samples),
            ptr(ws), ptr(None if gate is None else gate.iters), ptr(None if gate is None else gate.max_iters),
-           c_int(0 if sub >= B else int(sub)), ptr(rws), stream())
+           c_int(0 if sub >= B else int(sub)), ptr(rws), c_int(1 if ready else 0), stream())
     return idx, samples
 
 

@@ -464,6 +464,7 @@ class BatchedRANSAC(object):
         self.refit = refit
         self.eps = eps
         self.fmat = solver in ("f8", "f7")
+        self._race_ws = None     # per-call weights of the one-logarithm sampler (written by dr_ransac_init, read by every round)
         self._side = None
         self._gap = None         # scratch word of the one-launch dispatch gap in front of the sampler (see __call__)
         self._dev_seed = None
@@ -550,7 +551,8 @@ class BatchedRANSAC(object):
         if R > 1:
             Bq = R * self.B
             if gumbels is None and matches.dtype == torch.float32 and logits.dtype == torch.float32 and matches.shape[-1] == 4:
-                idx, samples = ops.gumbel_topk_gather(matches, logits, Bq, self.k, self.tau, self._next_seeds(R), gate=gate, sub=self.B)
+                idx, samples = ops.gumbel_topk_gather(matches, logits, Bq, self.k, self.tau, self._next_seeds(R), gate=gate, sub=self.B,
+                                                      race_ws=self._race_ws)
             else:
                 if gumbels is None:
                     raise ValueError("super-rounds with in-kernel noise serve f32 two-view correspondences (plan() says so)")
@@ -590,7 +592,8 @@ class BatchedRANSAC(object):
             # test mode consumes the index sets only (`points[samples != 0]`, ransac.py:65): no soft-max statistics, and
             # the samples are the points themselves (not points x a straight-through value of 1 +- 1 ulp)
             if gumbels is None and matches.dtype == torch.float32 and logits.dtype == torch.float32 and matches.shape[-1] == 4:
-                idx, samples = ops.gumbel_topk_gather(matches, logits, self.B, self.k, self.tau, self._next_seed(), gate=gate)   # one launch
+                idx, samples = ops.gumbel_topk_gather(matches, logits, self.B, self.k, self.tau, self._next_seed(), gate=gate,
+                                                      race_ws=self._race_ws)   # one launch
                 w = None
                 if gate is not None and self.solver in ("nister", "stewenius") and self.k == 5:
                     models, valid = ops.solve_essential_gated(samples, self.solver, gate)
@@ -613,6 +616,7 @@ class BatchedRANSAC(object):
     def __call__(self, matches, logits, K1=None, K2=None, gt_model=None, gumbels=None):
         P, N, _ = matches.shape
         dev, dt = matches.device, matches.dtype
+        self._race_ws = None      # (weights of THIS call's logits only: set by the test-mode set-up below, dropped by _finish)
         rounds = max(1, math.ceil(self.max_iterations / self.B))
         if self.train:
             out = []
@@ -674,9 +678,16 @@ class BatchedRANSAC(object):
             #  f32: the state lives in one buffer, which is what the replayed drop-in call hands out)
             draw = self.device_termination and self._dev_seed is not None and n_batches > 1 and gumbels is None
             fold = _FOLD_SETUP and draw
+            # the weights of the one-logarithm sampler, once per call, out of the same launch (when that form pays: ops.race_form_pays)
+            race_lg = None
+            if (_FOLD_SETUP and plan and gumbels is None and self.sampling == "gumbel" and not self.weighted and dt == torch.float32
+                    and logits.dtype == torch.float32 and matches.shape[-1] == 4
+                    and ops.race_form_pays(P, self.B * plan[0], N, self.tau)):
+                race_lg = logits.contiguous()
             st, thr = ops.ransac_init(P, N, self.max_iterations, self.threshold, K1 if use_K else None,
                                       K2 if use_K else None, dev, dt, seeds=(self._dev_seed, n_batches) if fold else None,
-                                      packed=_FOLD_SETUP and self.device_termination and P == 1)
+                                      packed=_FOLD_SETUP and self.device_termination and P == 1, race_logits=race_lg)
+            self._race_ws = st.race_ws
             if draw and not fold:
                 st.seeds = self._dev_seed.next_block(n_batches)
             if pre is not None and plan and P * self.B * plan[0] >= 65536:
@@ -784,6 +795,7 @@ class BatchedRANSAC(object):
 
     def _finish(self, st, matches, thr, pre, last_w, all_masks):
         """final refit on the inliers of the best model (ransac.py:148-195) and the result dictionary"""
+        self._race_ws = None
         best_score, best_model, best_mask, best_inl, iters = (st.best_score, st.best_model, st.best_mask,
                                                               st.best_inliers, st.iters)
         if self.refit:

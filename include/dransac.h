@@ -119,10 +119,12 @@ int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream);
  * tau == 1) then rank key_n = exp(lmax - logit_n) * log2 u_n instead of logit_n - ln(-ln u_n) -- the exponential-race form of the
  * same top-k (gumbel_sampler.py:30-36), ONE logarithm per element; the per-pair weights are written into the workspace by a
  * prologue launch.  Same index sets up to the rounding of near-ties (measured: tests/test_gpu_round6.py); pairs whose logits are
- * not all finite or span more than 80 keep the two-logarithm form. */
+ * not all finite or span more than 80 keep the two-logarithm form.  race_ready != 0: the workspace already holds the weights of
+ * these logits (dr_ransac_init wrote them, once for all rounds of the call): no prologue launch. */
 int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                               int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
-                              const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, void *stream);
+                              const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, int race_ready,
+                              void *stream);
 
 /* Train mode (round 5): K1 WITH the soft-max statistics + K2 in one call (GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42,
  * followed by `matches * ret` + the mask gather of ransac.py:58-65): idx, y_sel [P,B,k], lse [P,B] as dr_gumbel_topk_fwd_f32 and
@@ -361,15 +363,18 @@ int dr_select_best_f64(const double *matches, const double *models, const uint8_
  *   thr[p] = threshold / ((K1[0,0] + K1[1,1] + K1[0,0] + K2[1,1]) / 4)  -- sic, ransac.py:52.
  *   State: best_score = 0, best_model = eye(3), best_mask = 0, best_inliers = 0, iters = 0, max_iters = max_iterations.
  *   seed_state / seeds_out / n_seeds (optional, NULL / 0 = none; round 6): the call's sampler keys from the same launch --
- *   dr_seed_next_n(seed_state, seeds_out, n_seeds), one node fewer in a replayed call. */
+ *   dr_seed_next_n(seed_state, seeds_out, n_seeds), one node fewer in a replayed call.
+ *   race_logits [P,N] f32 / race_ws ((N + 32) * P floats; optional, both or neither): the per-pair weights of the one-logarithm
+ *   sampler (dr_gumbel_topk_gather_f32's race_ws) from the same launch, once per call: pass the workspace to the sampler with
+ *   race_ready = 1. */
 int dr_ransac_init_f32(const float *K1, const float *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, float *thr, float *best_score, float *best_model, uint8_t *best_mask,
                        int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
-                       int n_seeds, void *stream);
+                       int n_seeds, const float *race_logits, float *race_ws, void *stream);
 int dr_ransac_init_f64(const double *K1, const double *K2, int k_stride, double threshold, int P, int N,
                        int max_iterations, double *thr, double *best_score, double *best_model, uint8_t *best_mask,
                        int32_t *best_inliers, int32_t *iters, double *max_iters, uint64_t *seed_state, uint64_t *seeds_out,
-                       int n_seeds, void *stream);
+                       int n_seeds, const float *race_logits, float *race_ws, void *stream);
 
 /* K6 (batched, state on the device)  RANSAC.__call__ ransac.py:109-144 + adaptive_iteration_number :202-215.
  *   For every pair p with iters[p] < max_iters[p] (the others have terminated and are left untouched):

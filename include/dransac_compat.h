@@ -40,7 +40,7 @@ static inline int dr_gumbel_topk_gather_gated_f32(const float *logits, const flo
                                                   uint32_t *screen_ws, const int32_t *gate_iters, const double *gate_max_iters,
                                                   void *stream) {
   return dr_gumbel_topk_gather_f32(logits, matches, seed, seed_dev, tau, P, B, N, k, idx, samples, screen_ws, gate_iters,
-                                   gate_max_iters, 0, 0, stream);
+                                   gate_max_iters, 0, 0, 0, stream);
 }
 
 /* ---- five-point solvers ---- */
