@@ -286,13 +286,15 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
     for _ in range(max(warmup, 20)):
         step()
     torch.cuda.synchronize()
-    # three equal segments, the median one is reported (a sub-record shares the process with everything measured before
+    # equal segments, the median one is reported (a sub-record shares the process with everything measured before
     # it -- allocator state, clocks -- and one slow segment should not stand for the config)
     seg = max(1, steps // 3)
 
     def segments(fn):
+        # five segments, median reported (round 6: three were not enough for config 3 -- a step allocates 2.6 GB of masks and one
+        # allocator stall of ~40 ms inside a 20-step segment moved two of the three)
         out = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             run_bounded(lambda i: fn() and None, seg)
             torch.cuda.synchronize()
@@ -315,7 +317,7 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
         # the one-pair call of c2, the eager issue for the device-bound others
         if key == "c1" or (key == "c2" and w["pairs"] == 1):
             seg_ms, issue = graph_ms, "HIP graph replay of the whole step (differentiable_ransac_amd.graphs.GraphedStep)"
-    el, steps = sorted(seg_ms)[1] * 1e-3 * seg, seg
+    el, steps = sorted(seg_ms)[len(seg_ms) // 2] * 1e-3 * seg, seg
     calls = per_call_breakdown(step)
     dom = max(calls, key=calls.get)
     P, N, B = w["pairs"], w["points"], w["hyps"]
@@ -323,7 +325,7 @@ def config_record(key, dev, steps, warmup, pairs=None, graph=True):
     rec = {"baseline_config_index": w["baseline_config"], "workload": f"{w['text']}, {P} pair(s) per step",
            "steps": steps, "issue": issue, "segments_ms_per_step": [round(x, 5) for x in seg_ms],
            "ms_per_step": el / steps * 1e3, "hypotheses_per_s": P * B * steps / el,
-           "eager_ms_per_step": sorted(eager_ms)[1], "graph_replay_ms_per_step": sorted(graph_ms)[1] if graph else None,
+           "eager_ms_per_step": sorted(eager_ms)[len(eager_ms) // 2], "graph_replay_ms_per_step": sorted(graph_ms)[len(graph_ms) // 2] if graph else None,
            "pairs_per_s": P * steps / el, "launch_ms": {k: round(v, 5) for k, v in sorted(calls.items(), key=lambda kv: -kv[1])},
            "dominant_launch": dom, "dominant_ms": calls[dom],
            "reference_import_hypotheses_per_s": REFERENCE_IMPORT.get(key)}

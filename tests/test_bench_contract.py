@@ -51,10 +51,10 @@ def test_algorithmic_bytes_match_the_survey():
     assert bench.HBM_PEAK_GBS == 8000.0
 
 
-def test_committed_bench_line_carries_the_contract_fields_and_the_round5_records():
-    """the line the end-of-round script stored (profiles/r5_bench_line.json = `python bench.py` on the GPU box): every field the
-    driver's contract names, the roofline / cpu_baseline objects, and the sub-records the round-4 review asked for"""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")))
+def test_committed_bench_line_carries_the_contract_fields_and_the_round6_records():
+    """the line the end-of-round script stored (profiles/r6_bench_line.json = `python bench.py` on the GPU box): every field the
+    driver's contract names, the roofline / cpu_baseline objects, and the sub-records the reviews of rounds 4 and 5 asked for"""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r6_bench_line.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -71,6 +71,10 @@ def test_committed_bench_line_carries_the_contract_fields_and_the_round5_records
     assert "NOT measured in this run" in r["traffic_source"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["single_thread_value"] > 0
+    # round 6: the best MEDIAN over 1 / 8 / 32 threads, with its thread count and spread; never below the single-thread figure
+    assert c["threads"] == c["cores"] and set(c["by_threads"]) <= {"1", "8", "32"}
+    assert abs(c["value"] - max(c["by_threads"].values())) < 0.1        # (the per-thread-count figures are rounded to 0.1)
+    assert c["value"] >= c["single_thread_value"] and c["spread"] >= 0
     cfg = d["configs"]
     for k in ("c1", "c3", "c4", "c2_p32", "c2_p1", "c5_train_p32", "dropin_layer_loop"):
         assert k in cfg, k
@@ -79,6 +83,7 @@ def test_committed_bench_line_carries_the_contract_fields_and_the_round5_records
     for k in ("c1", "c3", "c4", "c5_train_p32"):       # review item 5: a measured CPU baseline next to every config
         b = cfg[k]["cpu_baseline"]
         assert b["kind"] == "port" and b["value"] > 0 and b["single_thread_value"] > 0 and b["cores"] >= 1, k
+        assert b["value"] >= b["single_thread_value"] and "by_threads" in b and "spread" in b, k
     assert cfg["c2_p1"]["ms_per_step"] <= 0.12                      # the round-3 review's bar for the one-pair call (replayed)
     # round 5: the train step's MatchLoss is one pass (value + unscaled gradient), sampler + gather one launch each way
     launches = set(cfg["c5_train_p32"]["launch_ms"])
@@ -87,6 +92,13 @@ def test_committed_bench_line_carries_the_contract_fields_and_the_round5_records
     assert not ({"dr_episym_fwd_f32", "dr_episym_bwd_mean_f32", "dr_gather_fwd_f32", "dr_gather_bwd_f32"} & launches)
     loop = cfg["dropin_layer_loop"]
     assert loop["test_mode"]["ms_per_pair"] < loop["test_mode_eager"]["ms_per_pair"] and loop["batched_forward_ms_per_pair"] > 0
+    # round 6 (review item 2): the reference's per-pair call <= 0.15 ms at -rbs 1024, <= 0.30 ms at the reference's default -rbs 64
+    # (two device rounds in one replayed graph), and the wall-time semantics of the layer's second return value beside it
+    assert loop["test_mode"]["ms_per_pair"] <= 0.15 and loop["dropin_layer_loop_rbs64"]["ms_per_pair"] <= 0.30
+    assert loop["dropin_layer_loop_rbs64"]["device_rounds"] == 2 and loop["test_mode_sync_timing"]["ms_per_pair"] > 0
+    # c4: the residual launch timed back to back beside the single-launch figure (review item 3: 43.2 vs 49.7 us)
+    b2b = cfg["c4"]["scoring_roofline"]["back_to_back"]
+    assert b2b["launches"] == 50 and 0 < b2b["avg_launch_ms"] <= cfg["c4"]["scoring_roofline"]["avg_launch_ms"] * 1.05
     f = d["fused_driver"]["scoring_roofline"]
     assert f["bytes_formula"] == "P (16 N + 40 M + N)" and f["algorithmic_bytes_per_launch"] == 128 * (16 * 2000 + 40 * 10240 + 2000)
     a = d["k4_all_valid"]
