@@ -516,8 +516,10 @@ class BatchedRANSAC(object):
         one = [1] * n_batches
         if sh is False or self.train or self.sampling != "gumbel" or self.keep_masks or dtype != torch.float32:
             return one
-        if self.weighted and self.solver == "f8" and self.refit:
-            return one          # the weighted refit wants the row-0 soft weights of the LAST batch a pair ran: batch by batch
+        if self.weighted:
+            # weighted rows in the minimal solves (ransac.py:70-74) need the soft weights of every batch, and the weighted refit wants
+            # the row-0 soft weights of the LAST batch a pair ran: batch by batch (a super-round samples index sets only)
+            return one
         if sh is None:
             if self.B >= 1024:
                 return one

@@ -52,6 +52,7 @@ def test_batched_ransac_configuration_errors():
     assert rn.plan() == [1] * 79
     assert BatchedRANSAC("nister", ransac_batch_size=1024).plan() == [1] * 5
     assert BatchedRANSAC("f8", ransac_batch_size=64, weighted=1).plan() == [1] * 79       # weighted refit: batch by batch
+    assert BatchedRANSAC("nister", ransac_batch_size=64, weighted=1).plan() == [1] * 79   # weighted minimal solves need every batch's soft weights
     assert BatchedRANSAC("nister", ransac_batch_size=1, max_iterations=5000).plan()[0] == 512   # dr_ransac_update's cap
     assert BatchedRANSAC("nister", ransac_batch_size=1024).sync_every is None      # = max(1, 256 // hypotheses per device round)
 
