@@ -266,3 +266,26 @@ def test_one_logarithm_sampler_draws_the_same_index_sets(dev):
     assert torch.equal(iw[:4], ix[:4])
     assert int((iw[4:] != ix[4:]).any(-1).sum()) <= 1
     assert (iw[0] == 17).any(-1).all() and not (iw[1] == 5).any() and not (iw[2] == 7).any()
+
+
+@pytest.mark.parametrize("rbs", [64, 1024])
+def test_dropin_fundamental_call_as_a_graph_equals_the_batch_by_batch_driver(dev, rbs):
+    """`-fmat 1 -sam 3 -tr 0` through the replayed call (packed one-pair state, LSQ refit on the inliers of the best mask that lives in
+    that buffer): pair after pair the results of the eager batch-by-batch driver with the same base seed"""
+    from differentiable_ransac_amd import estimators, samplers, scorings
+    from differentiable_ransac_amd.ransac import RANSAC, BatchedRANSAC
+    m, lg, K1, K2 = _hard_pairs(dev, 3, pixel=True)
+    n_batches = -(-1000 // rbs)
+    rn = RANSAC(estimators.FundamentalMatrixEstimatorNew(dev), samplers.GumbelSoftmaxSampler(rbs, 8, device=dev, seed=5),
+                scorings.MSACScore(dev), fmat=True, train=False, ransac_batch_size=rbs, sampler_id=3, threshold=0.75,
+                max_iterations=1000)
+    base = (5 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    ref = BatchedRANSAC("f8", ransac_batch_size=rbs, threshold=0.75, max_iterations=1000, seed=base, refit=True)
+    ref.super_hypotheses = False
+    for p in range(3):
+        ref.calls = (2 + p) * n_batches               # two warm-up calls of the capture, then one call per pair, n_batches seeds each
+        model, mask, score, iters = rn(m[p], lg[p], K1[p], K2[p], None)
+        want = ref(m[p:p + 1], lg[p:p + 1], K1[p:p + 1], K2[p:p + 1])
+        assert torch.equal(mask, want["mask"][0]) and int(iters) == int(want["iterations"][0]), p
+        assert torch.equal(score, want["score"][0]) and torch.equal(model, want["model"][0]), p
+    assert len(rn._graphs) == 1
