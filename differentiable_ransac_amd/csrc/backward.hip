@@ -192,18 +192,20 @@ __global__ __launch_bounds__(64) void fivepoint_bwd_kernel(const T *__restrict__
 // and rho_bar_r = -w_r^2 sum_j [p_j (q_j . rho_r) + q_j (p_j . rho_r)],  w_bar_r = -2 w_r sum_j (p_j . rho_r)(q_j . rho_r).
 // One lane per sample; M and its eigenvectors (cyclic Jacobi) live in LDS (162 doubles per lane), in the forward's entry
 // order rho[3a + b] = x1_a x2_b, so a stored model E[i][j] (x2^T E x1) is the vector e[3j + i].
-template <typename MT>
-__global__ __launch_bounds__(64) void fivepoint_nm_bwd_kernel(const float *__restrict__ samples, const float *__restrict__ weights,
+// T = type of samples / weights / gradients in memory (f32: the training path; f64: `-pr 2 -tr 1 -sam 3`, round 6 -- the arithmetic
+// is f64 either way)
+template <typename MT, typename T = float>
+__global__ __launch_bounds__(64) void fivepoint_nm_bwd_kernel(const T *__restrict__ samples, const T *__restrict__ weights,
                                                               const MT *__restrict__ models, const uint8_t *__restrict__ valid,
-                                                              const float *__restrict__ grad_models, int Bt, int n,
-                                                              float *__restrict__ grad_samples, float *__restrict__ grad_weights) {
+                                                              const T *__restrict__ grad_models, int Bt, int n,
+                                                              T *__restrict__ grad_samples, T *__restrict__ grad_weights) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   const int s = blockIdx.x * 64 + lane;
   const bool active = s < Bt;
   const int sc = active ? s : Bt - 1;
-  const float *pts = samples + (size_t)sc * n * 4;
-  const float *wts = weights ? weights + (size_t)sc * n : nullptr;
+  const T *pts = samples + (size_t)sc * n * 4;
+  const T *wts = weights ? weights + (size_t)sc * n : nullptr;
   LaneWs A{lds + lane}, V{lds + lane + 81 * 64};
   for (int e = 0; e < 81; ++e) A[e] = 0.0;
   for (int r = 0; r < n; ++r) {
@@ -248,15 +250,15 @@ __global__ __launch_bounds__(64) void fivepoint_nm_bwd_kernel(const float *__res
   for (int slot = 0; slot < 10; ++slot) {
     bool has = active && valid[(size_t)sc * 10 + slot];
     double E[3][3], g[3][3];
-    float gn = 0.f;
+    double gn = 0.0;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       E[q / 3][q % 3] = (double)models[((size_t)sc * 10 + slot) * 9 + q];
-      const float gv = grad_models[((size_t)sc * 10 + slot) * 9 + q];
+      const double gv = (double)grad_models[((size_t)sc * 10 + slot) * 9 + q];
       g[q / 3][q % 3] = gv;
-      gn += fabsf(gv);
+      gn += fabs(gv);
     }
-    has = has && gn > 0.f;
+    has = has && gn > 0.0;
     if (!__any(has)) continue;
     double J[6][3][3];
 #pragma unroll
@@ -360,11 +362,11 @@ __global__ __launch_bounds__(64) void fivepoint_nm_bwd_kernel(const float *__res
     }
     const double w2 = w * w;
     // rho = (x1 x2, x1 y2, x1, y1 x2, y1 y2, y1, x2, y2, 1)
-    grad_samples[((size_t)s * n + r) * 4 + 0] = (float)(w2 * (gr[0] * x2 + gr[1] * y2 + gr[2]));
-    grad_samples[((size_t)s * n + r) * 4 + 1] = (float)(w2 * (gr[3] * x2 + gr[4] * y2 + gr[5]));
-    grad_samples[((size_t)s * n + r) * 4 + 2] = (float)(w2 * (gr[0] * x1 + gr[3] * y1 + gr[6]));
-    grad_samples[((size_t)s * n + r) * 4 + 3] = (float)(w2 * (gr[1] * x1 + gr[4] * y1 + gr[7]));
-    if (grad_weights) grad_weights[(size_t)s * n + r] = (float)(-2.0 * w * gw);
+    grad_samples[((size_t)s * n + r) * 4 + 0] = (T)(w2 * (gr[0] * x2 + gr[1] * y2 + gr[2]));
+    grad_samples[((size_t)s * n + r) * 4 + 1] = (T)(w2 * (gr[3] * x2 + gr[4] * y2 + gr[5]));
+    grad_samples[((size_t)s * n + r) * 4 + 2] = (T)(w2 * (gr[0] * x1 + gr[3] * y1 + gr[6]));
+    grad_samples[((size_t)s * n + r) * 4 + 3] = (T)(w2 * (gr[1] * x1 + gr[4] * y1 + gr[7]));
+    if (grad_weights) grad_weights[(size_t)s * n + r] = (T)(-2.0 * w * gw);
   }
 }
 
@@ -848,6 +850,25 @@ int dr_solve_nister5_nm_bwd_f32(const float *samples, const float *weights, cons
   else
     hipLaunchKernelGGL((dr::fivepoint_nm_bwd_kernel<float>), dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream,
                        samples, weights, models, valid, grad_models, Bt, n, grad_samples, grad_weights);
+  return dr::check_launch("fivepoint_nm_bwd_kernel");
+}
+
+/* the same with everything f64 in memory (`-sam 3 -fmat 0 -tr 1 -pr 2`; round 6: the f32-I/O kernel rounded samples and gradients) */
+int dr_solve_nister5_nm_bwd_f64(const double *samples, const double *weights, const double *models, const uint8_t *valid,
+                                const double *grad_models, int Bt, int n, double *grad_samples, double *grad_weights, void *stream) {
+  DR_REQUIRE(samples && models && valid && grad_models && grad_samples, "null pointer");
+  DR_REQUIRE(Bt > 0 && n > 5, "need Bt > 0 and n > 5 points per sample (minimal samples: dr_solve_nister5_bwd_f64)");
+  const size_t smem = sizeof(double) * 162 * 64;
+  static bool attr_set[64] = {false};   // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dr::fivepoint_nm_bwd_kernel<double, double>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((dr::fivepoint_nm_bwd_kernel<double, double>), dim3((Bt + 63) / 64), dim3(64), smem, (hipStream_t)stream, samples,
+                     weights, models, valid, grad_models, Bt, n, grad_samples, grad_weights);
   return dr::check_launch("fivepoint_nm_bwd_kernel");
 }
 

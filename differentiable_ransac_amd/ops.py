@@ -729,9 +729,16 @@ class _SolveEssential(torch.autograd.Function):
                    ptr(g_models.to(torch.float64).contiguous()), c_int(Bt), ptr(gs), stream())
             return gs.reshape(samples.shape), None, None
         if f64:
-            # n > 5 rows per sample in f64: that kernel reads f32 samples / gradients but takes the f64 models and computes in
-            # f64 (its tangent-space system is what needs the precision): inputs rounded once, gradient returned as f64
-            m64, models, samples, g_models = models, models.float(), samples.float(), g_models.float()
+            # n > 5 rows per sample in f64 (`-sam 3 -fmat 0 -tr 1 -pr 2`), round 6: f64 samples, weights, models and gradients straight
+            # through (dr_solve_nister5_nm_bwd_f64; rounds 3-5 rounded samples and gradients to f32 on the way in)
+            s, Bt, n = _flat_samples(samples, 4)
+            gs = torch.empty_like(s)
+            w = ctx.weights
+            gw = None if w is None or not ctx.needs_input_grad[1] else torch.empty((Bt, n), device=s.device, dtype=torch.float64)
+            L.call("dr_solve_nister5_nm_bwd_f64", ptr(s), ptr(None if w is None else w.reshape(Bt, n).double().contiguous()),
+                   ptr(models.contiguous()), ptr(valid.contiguous().view(torch.uint8)), ptr(g_models.to(torch.float64).contiguous()),
+                   c_int(Bt), c_int(n), ptr(gs), ptr(gw), stream())
+            return gs.reshape(samples.shape), (None if gw is None else gw.reshape(w.shape).to(w.dtype)), None
         s, Bt, n = _flat_samples(samples, 4)
         gs = torch.empty_like(s)
         if not ctx.minimal:

@@ -263,6 +263,9 @@ int dr_solve_f8_bwd_f64(const double *samples, const double *weights, const doub
 int dr_solve_nister5_nm_bwd_f32(const float *samples, const float *weights, const float *models, const double *models_f64,
                                 const uint8_t *valid, const float *grad_models, int Bt, int n, float *grad_samples,
                                 float *grad_weights, void *stream);
+/* the same with samples, weights, models and gradients f64 in memory (`-sam 3 -fmat 0 -tr 1 -pr 2`, model_cl.py:164-169; round 6) */
+int dr_solve_nister5_nm_bwd_f64(const double *samples, const double *weights, const double *models, const uint8_t *valid,
+                                const double *grad_models, int Bt, int n, double *grad_samples, double *grad_weights, void *stream);
 int dr_solve_f8_bwd_f32(const float *samples, const float *weights, const float *models, const float *grad_models,
                         int Bt, int n, float *grad_samples, float *grad_weights, void *stream);
 int dr_solve_rigid_bwd_f32(const float *samples, const float *models, const float *grad_models, int Bt, int n,

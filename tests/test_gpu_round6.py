@@ -284,3 +284,57 @@ def test_dropin_fundamental_call_as_a_graph_equals_the_batch_by_batch_driver(dev
         assert torch.equal(mask, want["mask"][0]) and int(iters) == int(want["iterations"][0]), p
         assert torch.equal(score, want["score"][0]) and torch.equal(model, want["model"][0]), p
     assert len(rn._graphs) == 1
+
+
+def test_f64_nonminimal_fivepoint_backward(dev):
+    """`-sam 3 -fmat 0 -tr 1 -pr 2` (nister.py:64-65, model_cl.py:164-169): the backward of the NON-minimal five-point solve with
+    samples, weights, models and gradients f64 in memory (dr_solve_nister5_nm_bwd_f64; rounds 3-5 went through the f32-I/O kernel)
+    against central differences of the f64 forward itself (1e-6 steps) and against the f32-I/O kernel's gradient"""
+    from differentiable_ransac_amd import ops, synth
+    pair = synth.two_view_pair(91, 200, inlier_ratio=1.0, noise=2e-3, dtype=torch.float64)
+    B, n = 8, 8
+    smp = pair["matches"][: n * B].reshape(B, n, 4).contiguous().to(dev)
+    gen = torch.Generator().manual_seed(5)
+    wts = (0.5 + torch.rand(B, n, generator=gen, dtype=torch.float64)).to(dev)
+    W = torch.randn(B, 10, 3, 3, generator=gen, dtype=torch.float64).to(dev)
+    s64 = smp.clone().requires_grad_(True)
+    w64 = wts.clone().requires_grad_(True)
+    E, valid = ops.solve_essential(s64, w64, "nister")
+    assert E.dtype == torch.float64 and int(valid.sum()) >= B
+    (E * W * valid[..., None, None]).sum().backward()
+    g, gw = s64.grad.clone(), w64.grad.clone()
+    assert g.dtype == torch.float64 and gw.dtype == torch.float64
+    E0, v0 = E.detach(), valid
+
+    def loss(x, w):
+        Ep, vp = ops.solve_essential(x, w, "nister")
+        # slots are ordered by root: a step of 1e-6 keeps the order; sign-align every slot with the unperturbed model
+        sgn = torch.sign((Ep * E0).sum((-1, -2), keepdim=True))
+        return ((sgn * Ep) * W * (v0 & vp)[..., None, None]).sum((1, 2, 3))      # per sample
+
+    eps = 1e-6
+    num = torch.zeros_like(smp)
+    numw = torch.zeros_like(wts)
+    with torch.no_grad():
+        for k in range(n):
+            for d in range(4):
+                xp, xm = smp.clone(), smp.clone()
+                xp[:, k, d] += eps
+                xm[:, k, d] -= eps
+                num[:, k, d] = (loss(xp, wts) - loss(xm, wts)) / (2 * eps)
+            wp, wm = wts.clone(), wts.clone()
+            wp[:, k] += eps
+            wm[:, k] -= eps
+            numw[:, k] = (loss(smp, wp) - loss(smp, wm)) / (2 * eps)
+    rel = (g - num).abs().amax((-1, -2)) / num.abs().amax((-1, -2)).clamp(min=1e-9)
+    relw = (gw - numw).abs().amax(-1) / numw.abs().amax(-1).clamp(min=1e-9)
+    assert rel.median() < 1e-5 and rel.max() < 1e-3, (rel.median(), rel.max())
+    assert relw.median() < 1e-5 and relw.max() < 1e-3, (relw.median(), relw.max())
+    # the f32-I/O kernel on the same (rounded) inputs: the same gradient to f32 rounding of inputs and outputs
+    s32 = smp.float().requires_grad_(True)
+    w32 = wts.float().requires_grad_(True)
+    E32, v32 = ops.solve_essential(s32, w32, "nister")
+    (E32 * W.float() * v32[..., None, None]).sum().backward()
+    if torch.equal(v32, valid):
+        r32 = (s32.grad.double() - g).abs().amax((-1, -2)) / g.abs().amax((-1, -2)).clamp(min=1e-9)
+        assert r32.median() < 1e-2, r32.median()
