@@ -21,7 +21,7 @@ for name in names:
     lib = ctypes.CDLL(os.path.abspath(f'scratch/libk1_{name}.so'))
     cp = lambda t: ctypes.c_void_p(t.data_ptr())
     for mode, (a_y, a_l) in (('index sets only (test mode)', (None, None)), ('with soft-max statistics (train mode)', (cp(ys), cp(lse)))):
-        f = lambda: lib.dr_gumbel_topk_fwd_f32(cp(lg), None, ctypes.c_uint64(7), ctypes.c_float(1.0), P, B, N, k, cp(idx), a_y, a_l, None, None, None, None)
+        f = lambda: lib.dr_gumbel_topk_fwd_f32(cp(lg), None, ctypes.c_uint64(7), None, ctypes.c_float(1.0), P, B, N, k, cp(idx), a_y, a_l, None, None, None, None)
         assert f() == 0; torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()

@@ -35,12 +35,12 @@ for P in (32, 128):
             models = torch.empty(Bt, 10, 9, device=dev); valid = torch.empty(Bt, 10, device=dev, dtype=torch.uint8)
             cp = lambda t: ctypes.c_void_p(t.data_ptr())
             if solver == 'nister5':
-                f = lambda: lib.dr_solve_nister5_f32(cp(smp), None, Bt, 5, cp(models), cp(valid), None)
+                f = lambda: lib.dr_solve_nister5_f32(cp(smp), None, Bt, 5, cp(models), None, cp(valid), 0, 0, None, None, None)
             elif solver == 'nister5_split':
                 wsb = torch.empty(Bt * 88, device=dev, dtype=torch.float64)
                 f = lambda: lib.dr_solve_nister5_f32_split(cp(smp), None, Bt, cp(models), None, cp(valid), cp(wsb), None)
             else:
-                f = lambda: lib.dr_solve_stewenius5_f32(cp(smp), Bt, cp(models), cp(valid), None)
+                f = lambda: lib.dr_solve_stewenius5_f32(cp(smp), Bt, cp(models), cp(valid), 0, 0, None, None, None)
             assert f() == 0; torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()

@@ -23,7 +23,7 @@ Eo, oko, _ = O.nister_5pt(sub)
 for name in variants:
     lib = ctypes.CDLL(os.path.abspath(f'scratch/libk3_{name}.so'))
     models = torch.empty(Bt, 10, 9, device=dev); valid = torch.empty(Bt, 10, device=dev, dtype=torch.uint8)
-    f = lambda: lib.dr_solve_nister5_f32(ctypes.c_void_p(smp.data_ptr()), None, Bt, 5, ctypes.c_void_p(models.data_ptr()), ctypes.c_void_p(valid.data_ptr()), None)
+    f = lambda: lib.dr_solve_nister5_f32(ctypes.c_void_p(smp.data_ptr()), None, Bt, 5, ctypes.c_void_p(models.data_ptr()), None, ctypes.c_void_p(valid.data_ptr()), 0, 0, None, None, None)
     assert f() == 0; torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

@@ -17,7 +17,7 @@ for name in sys.argv[1:]:
     lib = ctypes.CDLL(f'{ROOT}/differentiable_ransac_amd/libdransac.so' if name == 'cur' else f'{ROOT}/scratch/libdransac_{name}.so')
     sc = torch.empty(P, M, device=dev); mk = torch.empty(P, M, N, device=dev, dtype=torch.uint8)
     cp = lambda t: ctypes.c_void_p(t.data_ptr())
-    assert lib.dr_msac_score_f32(cp(mt), cp(flat), cp(v), cp(thr), P, M, N, cp(sc), cp(mk), None) == 0
+    assert lib.dr_msac_score_f32(cp(mt), cp(flat), cp(v), cp(thr), P, M, N, cp(sc), cp(mk), None, None, None) == 0
     torch.cuda.synchronize(); out.append((sc, mk))
 (s0, m0), (s1, m1) = out
 print('mask bytes differing:', int((m0 != m1).sum()), 'of', m0.numel(), ' max |dscore|:', float((s0.nan_to_num() - s1.nan_to_num()).abs().max()), ' nan pattern equal:', bool(torch.equal(s0.isnan(), s1.isnan())))

@@ -66,7 +66,7 @@ def test_gumbel_index_only_mode(dev, N, B, k, dtype):
     idx = torch.empty(P, B, k, dtype=torch.int32, device=dev)
     ysel = torch.empty(P, B, k, dtype=dtype, device=dev)
     with pytest.raises(L.DransacError):     # y_sel without lse
-        L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", L.ptr(logits), None, L.c_uint64(1), L.scalar(dtype, 1.0), L.c_int(P),
+        L.call(f"dr_gumbel_topk_fwd_{L.suffix(dtype)}", L.ptr(logits), None, L.c_uint64(1), None, L.scalar(dtype, 1.0), L.c_int(P),
                L.c_int(B), L.c_int(N), L.c_int(k), L.ptr(idx), L.ptr(ysel), None, None, None, None, L.stream())
 
 
