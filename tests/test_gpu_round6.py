@@ -338,3 +338,37 @@ def test_f64_nonminimal_fivepoint_backward(dev):
     if torch.equal(v32, valid):
         r32 = (s32.grad.double() - g).abs().amax((-1, -2)) / g.abs().amax((-1, -2)).clamp(min=1e-9)
         assert r32.median() < 1e-2, r32.median()
+
+
+def test_super_rounds_equal_the_loop_on_random_configurations(dev):
+    """random (solver, ransac_batch_size, max_iterations, N, pairs, plan): device rounds of several batches against one batch per
+    round -- incl. batch sizes that do not divide 1024 or max_iterations, short rows (the wave-per-model scoring kernel), rows that are
+    not a multiple of four points (the general sampler kernel), more than 16 sub-batches per round (a wave per sub-batch in
+    dr_ransac_update) and a plan whose last round is partial"""
+    import random
+    from differentiable_ransac_amd import synth
+    from differentiable_ransac_amd.ransac import BatchedRANSAC
+    rng = random.Random(1234)
+    seen_wave_per_sub = False
+    for trial in range(10):
+        solver = rng.choice(["nister", "stewenius", "f8", "nister"])
+        B = rng.choice([8, 24, 50, 64, 100, 128, 200])
+        max_it = rng.choice([300, 777, 1500, 2600])
+        N = rng.choice([64, 200, 513, 1000, 2000])
+        P = rng.choice([1, 3, 6])
+        plan = rng.choice([None, (512, 512), (1024, 4096), (256, 1024, 2048), (4096,)])
+        ratio = rng.choice([0.25, 0.4, 0.6])
+        items = [synth.two_view_pair(700 + 10 * trial + p, N, inlier_ratio=ratio, pixel=solver == "f8") for p in range(P)]
+        st = lambda k: torch.stack([it[k] for it in items]).to(dev)
+        m, lg, K1, K2 = st("matches"), st("logits"), st("K1"), st("K2")
+        kw = dict(ransac_batch_size=B, threshold=0.75, max_iterations=max_it, seed=100 + trial, refit=bool(trial % 2))
+        loop = BatchedRANSAC(solver, **kw)
+        loop.super_hypotheses = False
+        sup = BatchedRANSAC(solver, **kw)
+        sup.super_hypotheses = plan
+        sup.device_termination = bool(trial % 3) and len(sup.plan()) <= 16
+        seen_wave_per_sub = seen_wave_per_sub or max(sup.plan()) > 16
+        a, b = loop(m, lg, K1, K2), sup(m, lg, K1, K2)
+        for key in KEYS:
+            assert torch.equal(a[key], b[key]), (trial, solver, B, max_it, N, P, plan, key)
+    assert seen_wave_per_sub
