@@ -60,6 +60,11 @@ class RANSACLayer(torch.nn.Module):
         # test-mode call returns before the device has finished (nothing is read back), so by default it is the ENQUEUE time of the
         # call; "sync" waits for the pair's result first -- the reference's meaning, at the price of the host running ahead.
         self.timing = "enqueue"
+        # The reference drops NaN models from what the layer returns (model_cl.py:240-242).  This package's estimators never return
+        # one -- a failed hypothesis comes back as eye(3) with valid = 0 and is dropped by the driver -- so for them the filter is the
+        # identity, and running it costs three launches and a host synchronisation (the boolean-mask index) per pair: skipped.
+        # Third-party estimators keep it.
+        self._finite_models = hasattr(solver, "estimate_model_slots")
 
     def forward(self, points, weights, K1, K2, im_size1, im_size2, ground_truth=None, gumbels=None):
         """points [N,4], weights (logits) [N] -> (Es, seconds).  Train: Es [n_batches * B', 3, 3] with autograd to
@@ -73,8 +78,13 @@ class RANSACLayer(torch.nn.Module):
         if self.timing == "sync" and points_.is_cuda:
             torch.cuda.current_stream(points_.device).synchronize()
         dt = time.time() - t0
-        Es = torch.cat(list(models.values())) if self.opt.tr else models
-        return _drop_nan(Es), dt
+        if self.opt.tr:
+            vals = list(models.values())
+            Es = vals[0] if len(vals) == 1 else torch.cat(vals)      # (one batch, the reference's training setting: nothing to copy)
+        else:
+            Es = models
+        own = self._finite_models and hasattr(self.estimator.estimator, "estimate_model_slots")   # (the plugin may have been swapped)
+        return (Es if own else _drop_nan(Es)), dt
 
 
 class RANSACLayer3D(torch.nn.Module):
