@@ -1471,6 +1471,9 @@ __device__ __forceinline__ void smallest_eigvec9_invit(const double (&A)[9][9], 
 }
 
 // symmetric 3x3 Jacobi in registers; eigenvalues in d[], eigenvectors = columns of V
+#ifndef DR_JACOBI3_FAST
+#define DR_JACOBI3_FAST 1
+#endif
 __device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3], double (&d)[3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -1488,10 +1491,24 @@ __device__ __forceinline__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3]
         const double apq = A[p][q];
         double c = 1.0, s = 0.0;
         if (fabs(apq) > 1e-300 && !done) {
+#if DR_JACOBI3_FAST
+          // round 6: t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) with theta = h / (2 apq) is sgn(h) 2 apq / (|h| + sqrt(h^2 + 4 apq^2)):
+          // one reciprocal square root for the root, one reciprocal, one reciprocal square root for c (rsq / rcp + two Newton steps
+          // each) instead of three IEEE divisions and two square roots -- the rotation is a dependent chain one lane waits for
+          const double h = A[q][q] - A[p][p];
+          const double x = __builtin_fma(h, h, 4.0 * apq * apq);
+          if (x > 1e-280) {
+            const double root = x * rsqrt_nr(x);
+            const double t = (h >= 0 ? 2.0 * apq : -2.0 * apq) * rcp_nr(fabs(h) + root);   // sgn(h) with sgn(0) = +1, as dsign(1, theta)
+            c = rsqrt_nr(__builtin_fma(t, t, 1.0));
+            s = t * c;
+          }
+#else
           const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
           const double t = dsign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
           c = 1.0 / sqrt(t * t + 1.0);
           s = t * c;
+#endif
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
