@@ -282,7 +282,7 @@ __device__ __forceinline__ void polish_step(const double (&nb)[4][9], const doub
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const double inv = 1.0 / a[c][c];
+    const double inv = frcp(a[c][c]);
 #pragma unroll
     for (int rr = c + 1; rr < 4; ++rr) {
       const double f = a[rr][c] * inv;
@@ -297,12 +297,12 @@ __device__ __forceinline__ void polish_step(const double (&nb)[4][9], const doub
     double acc = g[c];
 #pragma unroll
     for (int k = c + 1; k < 4; ++k) acc -= a[c][k] * d[k];
-    d[c] = acc / a[c][c];
+    d[c] = fdiv(acc, a[c][c]);
   }
   double nn = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { un[k] = u[k] - d[k]; nn += un[k] * un[k]; }
-  const double sc = 1.0 / sqrt(nn);
+  const double sc = frsqrt(nn);
 #pragma unroll
   for (int k = 0; k < 4; ++k) un[k] *= sc;
   double E2[9], n1 = 0;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void polish_homog(const double (&nb)[4][9], double (&
 // core: polish + verification; E = the unit-norm matrix sum_k u_k N_k (row-major in the basis' own entry order)
 __device__ __forceinline__ bool finish_core(const double (&nb)[4][9], double x, double y, double z, bool candidate, double tol2,
                                             double (&E)[9]) {
-  const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+  const double inv = frsqrt(x * x + y * y + z * z + 1.0);
   double u[4] = {x * inv, y * inv, z * inv, inv};
   bool good = candidate && is_finite(u[0]) && is_finite(u[1]) && is_finite(u[2]) && is_finite(u[3]);
   if (!good) { u[0] = 0.5; u[1] = 0.5; u[2] = 0.5; u[3] = 0.5; }
@@ -454,7 +454,7 @@ __device__ __forceinline__ void balanced_finish(const FinishQueue &fq, int lane,
     if (!__any(i < n)) continue;
     // start vector (x, y, z, 1) / |.| ; a non-finite candidate keeps a harmless placeholder and never counts
     const double x = xs[i], y = ys[i], z = zs[i];
-    const double inv = 1.0 / sqrt(x * x + y * y + z * z + 1.0);
+    const double inv = frsqrt(x * x + y * y + z * z + 1.0);
     double u0[4] = {x * inv, y * inv, z * inv, inv};
     const bool good = ((cand >> i) & 1u) && is_finite(u0[0]) && is_finite(u0[1]) && is_finite(u0[2]) && is_finite(u0[3]);
     if (i < n && off + i < 320) {
@@ -803,7 +803,7 @@ __device__ __forceinline__ void nister_finish(const double (&nb)[4][9], const do
         const double nn = cw * cw;  // we divide by the w component: pick the largest
         if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
       }
-    const double x = vx / vw, y = vy / vw;
+    const double rw = frcp(vw), x = vx * rw, y = vy * rw;
     const int dst_slot = (kPair && half) ? 9 - slot : slot;
     const bool good = finish_solution<T>(nb, x, y, z, has_root && is_finite(x) && is_finite(y) && slot < 10,
                                          models + 9 * dst_slot, active, models64 ? models64 + 9 * dst_slot : nullptr);
@@ -909,7 +909,7 @@ __device__ __forceinline__ void nister_xy_of_roots(const double (&bz)[39], const
         const double nn = cw * cw;  // we divide by the w component: pick the largest
         if (nn > bestn) { bestn = nn; vx = cx; vy = cy; vw = cw; }
       }
-    const double x = vx / vw, y = vy / vw;
+    const double rw = frcp(vw), x = vx * rw, y = vy * rw;
     xs[i] = x;
     ys[i] = y;
     if (is_finite(x) && is_finite(y)) cand |= 1u << i;
@@ -1003,10 +1003,10 @@ __device__ __forceinline__ void stewenius_charpoly(const double (&g)[6][10], dou
       nrm2 += v[i] * v[i];
     }
     const double x0 = v[k + 1];
-    const double alpha = -dsign(sqrt(nrm2), x0);
+    const double alpha = -dsign(fsqrt(nrm2), x0);
     const double v0 = x0 - alpha;
     const double vtv = v0 * v0 + (nrm2 - x0 * x0);
-    const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+    const double beta = vtv > 0 ? 2.0 * frcp(vtv) : 0.0;
     v[k + 1] = v0;
     // H <- (I - beta v v^T) H (I - beta v v^T)
 #pragma unroll
@@ -1093,11 +1093,11 @@ __device__ __forceinline__ void stewenius_xyz_of_roots(const double (&g)[6][10],
       double nrm2 = 0;
 #pragma unroll
       for (int r = c; r < 6; ++r) nrm2 += K[r][c] * K[r][c];
-      const double nrm = sqrt(nrm2);
+      const double nrm = fsqrt(nrm2);
       const double alpha = -dsign(nrm, K[c][c]);
       const double v0 = K[c][c] - alpha;
       const double vtv = v0 * v0 + (nrm2 - K[c][c] * K[c][c]);
-      const double beta = vtv > 0 ? 2.0 / vtv : 0.0;
+      const double beta = vtv > 0 ? 2.0 * frcp(vtv) : 0.0;
       if (!(nrm > 0)) solvable = false;
       double v[6];
 #pragma unroll
@@ -1120,7 +1120,7 @@ __device__ __forceinline__ void stewenius_xyz_of_roots(const double (&g)[6][10],
       double acc = K[c][5];
 #pragma unroll
       for (int cc = 4; cc > c; --cc) acc -= K[c][cc] * u[cc];
-      u[c] = acc / K[c][c];
+      u[c] = fdiv(acc, K[c][c]);
     }
     const double x = -lam, y = u[3], z = u[4];
     xs[i] = x; ys[i] = y; zs[i] = z;

@@ -27,6 +27,31 @@ __device__ __forceinline__ void wave_lds_order() {
 
 __device__ __forceinline__ double dsign(double a, double b) { return b >= 0 ? fabs(a) : -fabs(a); }
 
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x, y * y, 1.5);
+  return y * fma(-0.5 * x, y * y, 1.5);
+}
+__device__ __forceinline__ double rcp_nr(double x) {
+  double z = __builtin_amdgcn_rcp(x);
+  z = z * fma(-x, z, 2.0);
+  return z * fma(-x, z, 2.0);
+}
+
+// Round 6 (DR_K3_FAST_DIV): divisions and square roots of the five-point stages by v_rcp_f64 / v_rsq_f64 + two Newton steps (5-6
+// instructions, results within 1-2 ulp) instead of the IEEE sequences (div_scale x 2, rcp, 4-5 fma, div_fmas, div_fixup: 10-12
+// instructions in one dependent chain; sqrt likewise) -- ~110 of them per sample, a tenth of the kernels' instruction stream.
+// Same behaviour at the edges the callers test for: b = 0 or non-finite gives a non-finite quotient (NaN instead of inf: every caller
+// asks is_finite), fsqrt(0) = 0.
+#ifndef DR_K3_FAST_DIV
+#define DR_K3_FAST_DIV 1
+#endif
+__device__ __forceinline__ double frcp(double b) { return DR_K3_FAST_DIV ? rcp_nr(b) : 1.0 / b; }
+__device__ __forceinline__ double fdiv(double a, double b) { return DR_K3_FAST_DIV ? a * rcp_nr(b) : a / b; }
+__device__ __forceinline__ double fsqrt(double x) { return DR_K3_FAST_DIV ? (x > 0 ? x * rsqrt_nr(x) : x) : sqrt(x); }
+__device__ __forceinline__ double frsqrt(double x) { return DR_K3_FAST_DIV ? rsqrt_nr(x) : 1.0 / sqrt(x); }
+
+
 // ------------------------------------------------------------------------------------------------
 // Null space of a K x 9 matrix (rows = equations) by Householder QR of its transpose; registers only.
 // A[r][c] is overwritten.  nb[i] (i < 9-K) are orthonormal vectors spanning null(A) when rank A = K.
@@ -40,12 +65,12 @@ __device__ __forceinline__ void null_space_qr(double (&A)[K][9], double (&nb)[9 
     double nrm2 = 0;
 #pragma unroll
     for (int i = j; i < 9; ++i) nrm2 += A[j][i] * A[j][i];
-    const double nrm = sqrt(nrm2);
+    const double nrm = fsqrt(nrm2);
     const double alpha = -dsign(nrm, A[j][j]);
     const double v0 = A[j][j] - alpha;
     // v = (v0, A[j][j+1..8]);  beta = 2 / v^T v = -1/(alpha*v0)
     const double vtv = v0 * v0 + (nrm2 - A[j][j] * A[j][j]);
-    beta[j] = vtv > 0 ? 2.0 / vtv : 0.0;
+    beta[j] = vtv > 0 ? 2.0 * frcp(vtv) : 0.0;
     A[j][j] = v0;
 #pragma unroll
     for (int c = j + 1; c < K; ++c) {
@@ -807,7 +832,7 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
 #pragma unroll
   for (int i = 0; i <= D; ++i) cmax = fmax(cmax, fabs(c[i]));
   const bool ok = is_finite(cmax) && cmax > 0;
-  const double sc = ok ? 1.0 / cmax : 0.0;
+  const double sc = ok ? frcp(cmax) : 0.0;
   // chain F[k] = polynomial of degree D - k, ascending coefficients F[k][0 .. D - k]
   double F[D + 1][D + 1];
 #pragma unroll
@@ -1063,7 +1088,7 @@ __device__ __forceinline__ void real_roots_half_sturm(const double (&c)[D + 1], 
     const double xk = ws.lo[k * 64 + lane];
     const bool take = ((has_mask >> k) & 1u) && (!outer || (fabs(xk) > 1e-9 && fabs(xk) < 1.0));
     if (__any(take)) {
-      const double vv_ = outer ? 1.0 / xk : xk;
+      const double vv_ = outer ? frcp(xk) : xk;
       if (take) ws.lo[count * 64 + lane] = vv_;
     }
     count += take ? 1 : 0;
@@ -1295,17 +1320,6 @@ __device__ __forceinline__ int smallest_eigvec9(const double (&A)[9][9], const d
 // of A holds the eigenvalues and the columns of V the eigenvectors.  `cs` = 16 doubles of LDS scratch.
 // f64 reciprocal square root / reciprocal from the hardware estimates (v_rsq_f64 / v_rcp_f64, ~26 bits) + two Newton steps: what the
 // rotation angles below need -- finite, well-scaled, positive arguments; none of the scaling / special-case code of sqrt() and "/"
-__device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x, y * y, 1.5);
-  return y * fma(-0.5 * x, y * y, 1.5);
-}
-__device__ __forceinline__ double rcp_nr(double x) {
-  double z = __builtin_amdgcn_rcp(x);
-  z = z * fma(-x, z, 2.0);
-  return z * fma(-x, z, 2.0);
-}
-
 // Round 5: one parallel-order round (four disjoint rotations; index r rests) is TWO phases instead of four: (0) lanes 0..8 work
 // out the rotation of the pair their index belongs to -- partner i' = (2 r - i) mod 9 -- as (C[i], S[i]) with the sign of "p or q"
 // folded into S, by rsq / rcp + Newton instead of three divisions and two square roots; (1) every lane forms its elements of
@@ -1713,11 +1727,11 @@ __device__ __forceinline__ bool householder_qr10(double (&A)[10][10], double (&b
     double nrm2 = 0;
 #pragma unroll
     for (int i = j; i < 10; ++i) nrm2 += A[i][j] * A[i][j];
-    const double nrm = sqrt(nrm2);
+    const double nrm = fsqrt(nrm2);
     const double alpha = -dsign(nrm, A[j][j]);
     const double v0 = A[j][j] - alpha;
     const double vtv = v0 * v0 + (nrm2 - A[j][j] * A[j][j]);
-    beta[j] = vtv > 0 ? 2.0 / vtv : 0.0;
+    beta[j] = vtv > 0 ? 2.0 * frcp(vtv) : 0.0;
     rdiag[j] = alpha;
     A[j][j] = v0;
     amax = fmax(amax, fabs(alpha));
@@ -1735,7 +1749,7 @@ __device__ __forceinline__ bool householder_qr10(double (&A)[10][10], double (&b
   for (int j = 0; j < 10; ++j) ok = ok && (fabs(rdiag[j]) > 1e-13 * amax);
   ok = ok && is_finite(amax) && amax > 0;
 #pragma unroll
-  for (int j = 0; j < 10; ++j) rinv[j] = ok ? 1.0 / rdiag[j] : 0.0;
+  for (int j = 0; j < 10; ++j) rinv[j] = ok ? frcp(rdiag[j]) : 0.0;
   return ok;
 }
 
@@ -1778,11 +1792,11 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
     double nrm2 = 0;
 #pragma unroll
     for (int i = j; i < 10; ++i) nrm2 += A[i][j] * A[i][j];
-    const double nrm = sqrt(nrm2);
+    const double nrm = fsqrt(nrm2);
     const double alpha = -dsign(nrm, A[j][j]);
     const double v0 = A[j][j] - alpha;
     const double vtv = v0 * v0 + (nrm2 - A[j][j] * A[j][j]);
-    beta[j] = vtv > 0 ? 2.0 / vtv : 0.0;
+    beta[j] = vtv > 0 ? 2.0 * frcp(vtv) : 0.0;
     rdiag[j] = alpha;
     A[j][j] = v0;
     amax = fmax(amax, fabs(alpha));
@@ -1801,7 +1815,7 @@ __device__ __forceinline__ bool constraints_reduce(const double (&e)[3][3][4], c
   ok = ok && is_finite(amax) && amax > 0;
   double rinv[10];
 #pragma unroll
-  for (int j = 0; j < 10; ++j) rinv[j] = ok ? 1.0 / rdiag[j] : 0.0;
+  for (int j = 0; j < 10; ++j) rinv[j] = ok ? frcp(rdiag[j]) : 0.0;
   // ---- one right-hand-side column at a time
   if (kSplit) wave_lds_order();
 #pragma unroll 1
