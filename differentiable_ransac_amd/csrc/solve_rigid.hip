@@ -28,8 +28,9 @@ __global__ __launch_bounds__(64) void rigid_kernel(const T *__restrict__ samples
 #pragma unroll
     for (int d = 0; d < 6; ++d) c[d] += (double)pts[d];
   }
+  const double rn = frcp((double)n);   // (round 6: rcp / rsq + Newton for this kernel's divisions and square roots -- one lane's dependent chain)
 #pragma unroll
-  for (int d = 0; d < 6; ++d) c[d] /= (double)n;
+  for (int d = 0; d < 6; ++d) c[d] *= rn;
   double a0 = 0, a1 = 0;
   double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   for (int r = 0; r < n; ++r) {
@@ -40,8 +41,8 @@ __global__ __launch_bounds__(64) void rigid_kernel(const T *__restrict__ samples
       dp[d] = (double)pts[d] - c[d];
       dq[d] = (double)pts[3 + d] - c[3 + d];
     }
-    a0 += sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
-    a1 += sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
+    a0 += fsqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
+    a1 += fsqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]);
     const double w = wts ? (double)wts[r] : 1.0;
     const double w2 = w * w;  // the reference scales both coordinate blocks by the weight (:34-35)
 #pragma unroll
@@ -49,9 +50,9 @@ __global__ __launch_bounds__(64) void rigid_kernel(const T *__restrict__ samples
 #pragma unroll
       for (int j = 0; j < 3; ++j) cov[i][j] += w2 * dp[i] * dq[j];
   }
-  a0 /= (double)n;
-  a1 /= (double)n;
-  const double sc = (sqrt(3.0) / a0) * (sqrt(3.0) / a1);  // both sides scaled to mean distance sqrt(3) (:37-41)
+  a0 *= rn;
+  a1 *= rn;
+  const double sc = 3.0 * frcp(a0 * a1);  // both sides scaled to mean distance sqrt(3) (:37-41): (sqrt 3 / a0)(sqrt 3 / a1)
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -97,15 +98,15 @@ __global__ __launch_bounds__(64) void rigid_kernel(const T *__restrict__ samples
     u0[k] = tg[k][0] * v0[0] + tg[k][1] * v0[1] + tg[k][2] * v0[2];
     u1[k] = tg[k][0] * v1[0] + tg[k][1] * v1[1] + tg[k][2] * v1[2];
   }
-  double n0 = sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+  const double n0 = frsqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) u0[k] /= n0;
+  for (int k = 0; k < 3; ++k) u0[k] *= n0;
   const double dt = u0[0] * u1[0] + u0[1] * u1[1] + u0[2] * u1[2];
 #pragma unroll
   for (int k = 0; k < 3; ++k) u1[k] -= dt * u0[k];
-  double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+  const double n1 = frsqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) u1[k] /= n1;
+  for (int k = 0; k < 3; ++k) u1[k] *= n1;
   // third vectors by cross product: V' = [v0 v1 v0xv1], U' = [u0 u1 u0xu1]  => R = V' U'^T is a proper rotation,
   // identical to the reference's V U^T after its det(R) < 0 column flip (:59-62)
   const double v2[3] = {v0[1] * v1[2] - v0[2] * v1[1], v0[2] * v1[0] - v0[0] * v1[2], v0[0] * v1[1] - v0[1] * v1[0]};
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64) void rigid_kernel(const T *__restrict__ samples
   if (tout)
 #pragma unroll
     for (int i = 0; i < 3; ++i) tout[(size_t)s * 3 + i] = (T)t[i];
-  if (sout) sout[s] = (T)(a1 / a0);
+  if (sout) sout[s] = (T)fdiv(a1, a0);
   valid[s] = ok;
 }
 
