@@ -57,7 +57,8 @@ __device__ __forceinline__ void seed_next_block(uint64_t *__restrict__ state, ui
 }
 
 // Per-pair weights of the exponential-race sampler (gumbel_topk.hip, round 6): w_n = exp(lmax - logit_n) into ws [P,N] and the
-// pair's "tame" flag (all logits finite, span <= 80) into the word ws[P * N + p].  One 256-thread block per pair.
+// pair's "tame" flag (all logits finite, span <= 80) into the word ws[P * N + p]; -1 / c_p, c_p = ln 2 sum_n 1 / w_n (the expected
+// number of keys >= t is -t c_p: the threshold that one key is expected to reach), into ws[P * N + P + p].  ws holds (N + 32) * P floats.  One 256-thread block per pair.
 __device__ __forceinline__ void race_weights_block(const float *__restrict__ logits, int N, int P, int p, float *__restrict__ ws) {
   __shared__ float s_mx[4], s_mn[4];
   __shared__ int s_bad[4];
@@ -85,8 +86,21 @@ __device__ __forceinline__ void race_weights_block(const float *__restrict__ log
   bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
   const bool tame = !bad && (mx - mn) <= 80.0f;
   float *w = ws + (size_t)p * N;
-  for (int n = tid; n < N; n += 256) w[n] = tame ? __builtin_amdgcn_exp2f((mx - lg[n]) * 1.44269504088896340736f) : 0.f;
-  if (tid == 0) reinterpret_cast<int *>(ws + (size_t)P * N)[p] = tame ? 1 : 0;
+  float rate = 0.f;   // sum_n 1 / w_n: the density of the pair's keys (the sampler's threshold search starts from it)
+  for (int n = tid; n < N; n += 256) {
+    const float d = (mx - lg[n]) * 1.44269504088896340736f;
+    w[n] = tame ? __builtin_amdgcn_exp2f(d) : 0.f;
+    rate += tame ? __builtin_amdgcn_exp2f(-d) : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rate += __shfl_xor(rate, o, 64);
+  __syncthreads();   // (s_mx is read above by every thread)
+  if (lane == 0) s_mx[wv] = rate;
+  __syncthreads();
+  if (tid == 0) {
+    reinterpret_cast<int *>(ws + (size_t)P * N)[p] = tame ? 1 : 0;
+    ws[(size_t)P * N + P + p] = -1.0f / (0.69314718055994530942f * (s_mx[0] + s_mx[1] + s_mx[2] + s_mx[3]));
+  }
 }
 
 // ---- wave64 reductions (ds_swizzle/DPP chosen by the compiler from the xor pattern) ----

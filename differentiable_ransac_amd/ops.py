@@ -254,12 +254,13 @@ SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 # Round 6: the exponential-race form of the index-only sampler (one logarithm per element; dr_gumbel_topk_gather_f32's race_ws).
 # Same top-k up to the rounding of near-ties; off = the two-logarithm form of rounds 1-5 (A/B runs, tests: DRANSAC_K1_RACE=0).
 K1_RACE = _os.environ.get("DRANSAC_K1_RACE", "1") != "0"
+_RACE_MIN = tuple(int(v) for v in _os.environ.get("DRANSAC_K1_RACE_MIN", "32768,32").split(","))   # (rows, pairs) from which it is automatic
 
 
 def race_form_pays(P: int, B: int, N: int, tau: float) -> bool:
     """the automatic choice of the one-logarithm sampler: rows the register kernel serves, from 32 pairs / 32 768 rows on (the
     prologue costs a launch, the form saves ~0.12 us per 1024 rows of 2000 points: scratch/runs/r6_gpu_o.sh)"""
-    return K1_RACE and P * B >= 32768 and P >= 32 and N <= 2048 and N % 4 == 0 and tau == 1.0
+    return K1_RACE and P * B >= _RACE_MIN[0] and P >= _RACE_MIN[1] and N <= 2048 and N % 4 == 0 and tau == 1.0
 
 
 def gumbel_topk_gather(matches: torch.Tensor, logits: torch.Tensor, B: int, k: int, tau: float = 1.0, seed=0, gate=None,

@@ -120,7 +120,9 @@ int dr_seed_next_n(uint64_t *state, uint64_t *seeds_out, int n, void *stream);
  * same top-k (gumbel_sampler.py:30-36), ONE logarithm per element; the per-pair weights are written into the workspace by a
  * prologue launch.  Same index sets up to the rounding of near-ties (measured: tests/test_gpu_round6.py); pairs whose logits are
  * not all finite or span more than 80 keep the two-logarithm form.  race_ready != 0: the workspace already holds the weights of
- * these logits (dr_ransac_init wrote them, once for all rounds of the call): no prologue launch. */
+ * these logits (dr_ransac_init wrote them, once for all rounds of the call): no prologue launch.  The workspace holds w [P,N], then
+ * a flag word and the key density -1 / (ln 2 sum_n 1 / w_n) per pair: this form selects its k winners on wave compare masks, from
+ * a threshold searched on that density (same winners, same order as the candidate list of the other forms). */
 int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
                               int P, int B, int N, int k, int32_t *idx, float *samples, uint32_t *screen_ws,
                               const int32_t *gate_iters, const double *gate_max_iters, int sub, float *race_ws, int race_ready,

@@ -263,6 +263,33 @@ def test_one_logarithm_sampler_draws_the_same_index_sets(dev):
     assert (iw[0] == 17).any(-1).all() and not (iw[1] == 5).any() and not (iw[2] == 7).any()
 
 
+@pytest.mark.parametrize("shape", [(6, 512, 2000, 5), (3, 256, 64, 5), (4, 300, 1000, 8), (2, 1024, 2048, 1), (5, 128, 260, 2)])
+def test_one_logarithm_sampler_selection_on_wave_masks(dev, shape):
+    """The race form selects on compare masks (round 6, gumbel_topk.hip `DR_K1_SALU_SELECT`): a threshold search on the count of lane
+    maxima, candidates dealt to lanes in index order, ranking only when more than k pass.  Every branch of it against the two-logarithm
+    form (whose selection is the candidate list of rounds 2-5; identical to the mask selection on 63 cases, scratch/k1_select_check.py):
+    ordinary logits; flat logits; a few dominant points (the search cannot bracket the count: the row takes the list path);
+    quantised logits; a span of 79 (the largest the form accepts)"""
+    from differentiable_ransac_amd import ops, synth
+    P, B, N, k = shape
+    d = synth.batch_two_view(P, N, seed0=3)
+    m, lg = d["matches"].to(dev), d["logits"].to(dev)
+    dom = lg.clone()
+    dom[:, [3, N // 2, N - 1]] += 30.0
+    cases = {"synthetic": lg, "flat": torch.zeros_like(lg), "dominant": dom, "quantised": torch.round(lg),
+             "span79": lg / lg.abs().max() * 39.5, "peaked": lg * 8.0}
+    for tag, l2 in cases.items():
+        ia, sa = ops.gumbel_topk_gather(m, l2, B, k, 1.0, 21, race=True)
+        ib, sb = ops.gumbel_topk_gather(m, l2, B, k, 1.0, 21, race=False)
+        assert (ia[..., 1:] > ia[..., :-1]).all() and ia.min() >= 0 and ia.max() < N, tag      # k distinct points, ascending
+        same = (ia == ib).all(-1)
+        assert int((~same).sum()) <= max(1, P * B // 20000), (tag, int((~same).sum()))       # (near-ties at rounding level)
+        assert torch.equal(sa[same], sb[same]), tag
+        assert torch.equal(sa, torch.gather(m, 1, ia.reshape(P, B * k, 1).expand(-1, -1, 4).long()).reshape(P, B, k, 4)), tag
+        if tag == "dominant" and k >= 3:
+            assert all((ia == j).any(-1).float().mean() > 0.99 for j in (3, N // 2, N - 1))
+
+
 @pytest.mark.parametrize("rbs", [64, 1024])
 def test_dropin_fundamental_call_as_a_graph_equals_the_batch_by_batch_driver(dev, rbs):
     """`-fmat 1 -sam 3 -tr 0` through the replayed call (packed one-pair state, LSQ refit on the inliers of the best mask that lives in
