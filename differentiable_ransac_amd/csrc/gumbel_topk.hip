@@ -333,13 +333,10 @@ __global__ __launch_bounds__(256) void gumbel_race_weights_kernel(const float *_
 // Measured at 32 x 1024 x 2000 (scratch/ab_k1.py): general kernel 77.7 us in test mode (Philox 29.5, the two logarithms
 // 7.7, everything else 42-48), this kernel 60.0 us (everything else: 29); train mode 88.1 -> 74.4 us.
 #ifndef DR_K1_SALU_SELECT
-#define DR_K1_SALU_SELECT 1   // the race form's selection on wave masks (0 = the list of rounds 2-5: A/B)
-#endif
-#ifndef DR_K1_GROUP_MAX
-#define DR_K1_GROUP_MAX 0     // ... with the group maxima kept from pass A: one compare per group first (step 0.8985-0.8998 vs 0.8963-0.8968 ms without, same box)
+#define DR_K1_SALU_SELECT 1   // the selection on wave compare masks (0 = the LDS list of rounds 2-5: A/B); 2 = the one-logarithm form only
 #endif
 #ifndef DR_K1_WV_SGPR
-#define DR_K1_WV_SGPR 1
+#define DR_K1_WV_SGPR 1     // the wave index through v_readfirstlane (row, seed, Philox round keys in SGPRs); 2 = index-only mode only
 #endif
 #ifndef DR_K1_DBG_SELECT
 #define DR_K1_DBG_SELECT 0
@@ -389,11 +386,9 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 #endif
   if (seed_ptr) seed = *seed_ptr;
   // (the wave index through v_readfirstlane: the row, its seed and the twelve Philox round keys then live in SGPRs)
-#if DR_K1_WV_SGPR
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#else
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#endif
+  const int lane = threadIdx.x & 63;
+  int wv = threadIdx.x >> 6;
+  if (DR_K1_WV_SGPR == 1 || (DR_K1_WV_SGPR == 2 && !kSoft)) wv = __builtin_amdgcn_readfirstlane(wv);
   const int p = blockIdx.y, b = blockIdx.x * kRowsPerBlock + wv;
   if (b >= B) return;   // whole wave exits together (no block-level barrier is used below)
   int bq;
@@ -479,9 +474,6 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
 
   // ---------------- pass A: g into registers, online soft-max, lane maximum
   float g[kFastGroups][4];
-#if DR_K1_SALU_SELECT && DR_K1_GROUP_MAX
-  float gm[kFastGroups];   // race form: the group maxima (one compare per group decides whether its four components are looked at)
-#endif
   float mx = -INFINITY, sm = 0.f, lmax = -INFINITY;
   bool race = false;
   if constexpr (!kSoft && !kScreen) race = race_ws != nullptr && reinterpret_cast<const int *>(race_ws + (size_t)P_race * N)[p] != 0;
@@ -498,18 +490,10 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
         g[i][1] = w4.y * log2_uniform_from_bits(r[1]);
         g[i][2] = w4.z * log2_uniform_from_bits(r[2]);
         g[i][3] = w4.w * log2_uniform_from_bits(r[3]);
-#if DR_K1_SALU_SELECT && DR_K1_GROUP_MAX
-        gm[i] = fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3]));
-        lmax = fmaxf(lmax, gm[i]);
-#else
         lmax = fmaxf(lmax, fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3])));
-#endif
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[i][j] = -INFINITY;
-#if DR_K1_SALU_SELECT && DR_K1_GROUP_MAX
-        gm[i] = -INFINITY;
-#endif
       }
     }
   } else
@@ -549,18 +533,16 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   if (lane < k) idx[row * k + lane] = __float_as_int(lmax);
   return;
 #endif
+  // ---------------- threshold: any t that at least k LANE MAXIMA reach has the k winners among { g >= t }
+  bool settled = false;   // (wave-uniform)
+  float thr = -INFINITY;
 #if DR_K1_SALU_SELECT
   if constexpr (!kSoft && !kScreen) if (race) {
-    // ---------------- round 6: the selection of the one-logarithm form on wave masks (scalar unit), no LDS ------------------------
-    // Any threshold t that at least k LANE MAXIMA reach has the k winners among { key >= t }.  The keys of a pair are a Poisson
-    // process in t: E #{ key >= t } = -t c_p with c_p = ln 2 sum_n 1 / w_n (gumbel_race_weights_kernel), so t is searched as
-    // t = -lam / c_p from lam = 6: a compare + a count per probe (one vector instruction; the k rounds of a wave-wide maximum
-    // were 64), a secant step on the count until the count is bracketed, then bisection; 3.2 probes on average, exactly k lane
-    // maxima in 77 % of the rows (scratch/sim_k1_threshold.py).  The candidates are then read off the compare masks by the scalar
-    // unit in ascending point index -- group, lane, component -- and dealt to lanes 0 .. n-1 (one select per value): n == k needs no
-    // ranking at all; n > k ranks by (value, index) over v_readlane.  Same winners, same output order as the list below (the
-    // total order is the same); a row the search does not settle (no count in k .. 16 after six probes, more than 64
-    // candidates) takes the path below.
+    // Round 6, the one-logarithm form: t by COUNTING.  The keys of a pair are a Poisson process in t: E #{ key >= t } = -t c_p with
+    // c_p = ln 2 sum_n 1 / w_n (gumbel_race_weights_kernel), so t is searched as t = -lam / c_p from lam = 6: a compare + a count per
+    // probe (one vector instruction; the k rounds of a wave-wide maximum below are 64), a secant step on the count until the count
+    // is bracketed, then bisection; 3.2 probes on average, exactly k lane maxima in 77 % of the rows (scratch/sim_k1_threshold.py).
+    // A row the search does not settle (no count in k .. 16 after six probes) takes the exact threshold below.
     const float inv = race_ws[(size_t)P_race * N + P_race + p];   // -1 / c_p
     const float kf = (float)k + 0.5f;
     float t = 6.0f * inv, tlo = 0.f, thi = 0.f;   // tlo: at least k lane maxima reach it; thi: fewer than k do
@@ -573,68 +555,91 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
       else { thi = t; have_hi = true; }
       t = (have_lo && have_hi) ? 0.5f * (tlo + thi) : t * fminf(4.0f, kf * __builtin_amdgcn_rcpf((float)c + 0.5f));
     }
-    if (have_lo && clo <= 16) {
-      const float t = tlo;
-      int n = 0;
-      int cv_i = __float_as_int(-INFINITY), ci = 0x7fffffff;
-#pragma unroll
-      for (int i = 0; i < kFastGroups; ++i) {
-        if (64 * i >= groups) break;   // wave-uniform
-#if DR_K1_GROUP_MAX
-        if (!__builtin_amdgcn_ballot_w64(gm[i] >= t)) continue;
-#endif
-        const unsigned long long c0 = __builtin_amdgcn_ballot_w64(g[i][0] >= t), c1 = __builtin_amdgcn_ballot_w64(g[i][1] >= t),
-                                 c2 = __builtin_amdgcn_ballot_w64(g[i][2] >= t), c3 = __builtin_amdgcn_ballot_w64(g[i][3] >= t);
-        unsigned long long any = c0 | c1 | c2 | c3;
-        while (any) {
-          const int l = __builtin_ctzll(any);
-          any &= any - 1;
-          const unsigned long long cj[4] = {c0, c1, c2, c3};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if ((cj[j] >> l) & 1ull) {
-              const bool mine = __builtin_amdgcn_inverse_ballot_w64(1ull << (n & 63));   // lane n as a scalar mask (a 65th candidate overwrites lane 0: the count below then sends the row to the list path)
-              cv_i = mine ? __builtin_amdgcn_readlane(__float_as_int(g[i][j]), l) : cv_i;
-              ci = mine ? 4 * (l + 64 * i) + j : ci;
-              ++n;
-            }
-          }
-        }
-      }
-      if (n <= 64) {
-        const float cv = __int_as_float(cv_i);
-        bool win = lane < n;
-        int pos = lane;
-        if (n > k) {
-          int rank = 0;
-#pragma unroll 1
-          for (int m = 0; m < n; ++m) {
-            const float ov = __int_as_float(__builtin_amdgcn_readlane(cv_i, m));
-            const int oi = __builtin_amdgcn_readlane(ci, m);
-            rank += (ov > cv) || (ov == cv && oi < ci);
-          }
-          win = win && rank < k;
-          pos = __popcll(__builtin_amdgcn_ballot_w64(win) & ((1ull << lane) - 1ull));   // (the lanes are in index order)
-        }
-        if (win) {
-          idx[row * k + pos] = ci;
-          if (gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + ci];
-        }
-        return;
-      }
-    }
+    if (have_lo && clo <= 16) { settled = true; thr = tlo; }
   }
 #endif
-  // ---------------- threshold: k-th largest lane maximum
-  float v = lmax, thr = -INFINITY;
-  for (int r = 0; r < k; ++r) {
-    thr = row_max(v);
-    const unsigned long long who = __ballot(v == thr);
-    if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
+  if (!settled) {   // the k-th largest lane maximum: k rounds of a wave-wide maximum
+    float v = lmax;
+    for (int r = 0; r < k; ++r) {
+      thr = row_max(v);
+      const unsigned long long who = __ballot(v == thr);
+      if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
+    }
   }
 #if DR_K1_DBG_SELECT == 2   // pass A + threshold
   if (lane < k) idx[row * k + lane] = __float_as_int(thr);
   return;
+#endif
+
+#if DR_K1_SALU_SELECT
+  if constexpr (!kScreen) if (DR_K1_SALU_SELECT == 1 || settled) {
+    // ---------------- round 6: the selection on wave compare masks (scalar unit), no LDS -------------------------------------------
+    // The candidates { g >= thr } are read off 32 compare masks by the scalar unit in ascending point index -- group, lane,
+    // component -- and dealt to lanes 0 .. n-1 (a v_readlane and two selects under the scalar mask of lane n): n == k needs no
+    // ranking at all; n > k ranks by (value, index) over v_readlane.  Same winners, same output order as the list below (the total
+    // order is the same); a row with more than 64 candidates takes the list.  (profiles/r6_k1_selection.md: 789 -> 578 vector
+    // instructions per row in the one-logarithm form, identical outputs on 99 cases, scratch/k1_select_check.py.  Keeping the
+    // group maxima from pass A and testing them first: 0.8985-0.8998 vs 0.8963-0.8968 ms per step without -- not kept.)
+    int n = 0;
+    int cv_i = __float_as_int(-INFINITY), ci = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < kFastGroups; ++i) {
+      if (64 * i >= groups) break;   // wave-uniform
+      const unsigned long long c0 = __builtin_amdgcn_ballot_w64(g[i][0] >= thr), c1 = __builtin_amdgcn_ballot_w64(g[i][1] >= thr),
+                               c2 = __builtin_amdgcn_ballot_w64(g[i][2] >= thr), c3 = __builtin_amdgcn_ballot_w64(g[i][3] >= thr);
+      unsigned long long any = c0 | c1 | c2 | c3;
+      while (any) {
+        const int l = __builtin_ctzll(any);
+        any &= any - 1;
+        const unsigned long long cj[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((cj[j] >> l) & 1ull) {
+            // (a 65th candidate overwrites lane 0: the count below then sends the row to the list)
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(1ull << (n & 63));
+            cv_i = mine ? __builtin_amdgcn_readlane(__float_as_int(g[i][j]), l) : cv_i;
+            ci = mine ? 4 * (l + 64 * i) + j : ci;
+            ++n;
+          }
+        }
+      }
+    }
+    if (n <= 64) {
+      const float cv = __int_as_float(cv_i);
+      bool win = lane < n;
+      int pos = lane;
+      if (n > k) {
+        int rank = 0;
+#pragma unroll 1
+        for (int m = 0; m < n; ++m) {
+          const float ov = __int_as_float(__builtin_amdgcn_readlane(cv_i, m));
+          const int oi = __builtin_amdgcn_readlane(ci, m);
+          rank += (ov > cv) || (ov == cv && oi < ci);
+        }
+        win = win && rank < k;
+        pos = __popcll(__builtin_amdgcn_ballot_w64(win) & ((1ull << lane) - 1ull));   // (the lanes are in index order)
+      }
+      if (win) {
+        idx[row * k + pos] = ci;
+        if (kSoft) {
+          const float y = exp_t<float>(cv - wmx) * inv_sm;
+          y_sel[row * k + pos] = y;
+          if (gather_dst) gather_dst[row * k + pos] = straight_through(gather_src[(size_t)p * N + ci], y);
+        }
+        if (!kSoft && gather_dst) gather_dst[row * k + pos] = gather_src[(size_t)p * N + ci];
+      }
+      if (kSoft && lane == 0) lse_out[row] = lse;
+      return;
+    }
+    if (settled) {   // (more than 64 candidates at a searched threshold: the list wants the exact one)
+      float v = lmax;
+      for (int r = 0; r < k; ++r) {
+        thr = row_max(v);
+        const unsigned long long who = __ballot(v == thr);
+        if (lane == __ffsll((long long)who) - 1) v = -INFINITY;
+      }
+    }
+  }
 #endif
 
   // ---------------- pass B: the candidates { g >= thr } into the wave's LDS list

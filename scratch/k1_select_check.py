@@ -1,5 +1,6 @@
-"""Round 6: the race form's selection on wave masks (DR_K1_SALU_SELECT) against the list selection of rounds 2-5 (a variant library
-built with -DDR_K1_SALU_SELECT=0): index sets and samples must be IDENTICAL; timing of both at the headline shape.
+"""Round 6: the register sampler's selection on wave masks (DR_K1_SALU_SELECT) against the list selection of rounds 2-5 (a variant
+library built with -DDR_K1_SALU_SELECT=0), every mode: index sets, samples, soft-max weights and log-sum-exps must be IDENTICAL; timing
+of both at the headline shape.
    python scratch/build_variant.py k1_oldsel gumbel_topk.hip -DDR_K1_SALU_SELECT=0;  python scratch/k1_select_check.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +38,15 @@ for (P, B, N, k) in cases:
         diff = int((i1 != i0).any(-1).sum())
         assert (i1[..., 1:] > i1[..., :-1]).all() and i1.min() >= 0 and i1.max() < N
         print(f"[{name}] P{P} B{B} N{N} k{k} seed{seed}: rows differing from the two-logarithm form: {diff} of {P * B}")
+    # the other modes of the register kernel: two-logarithm index sets; soft-max statistics (train mode), alone and with the gather
+    i4, s4 = ops.gumbel_topk_gather(m, lg, B, k, 1.0, 13, race=False)
+    res[f"P{P} B{B} N{N} k{k} two-log"] = (i4.cpu(), s4.cpu())
+    r5 = ops.gumbel_topk(lg, B, k, 1.0, None, 13)
+    res[f"P{P} B{B} N{N} k{k} soft"] = (r5["idx"].cpu(), r5["y_sel"].cpu(), r5["lse"].cpu())
+    s6, y6, i6 = ops.SampleGather.apply(m, lg, B, k, 1.0, None, 13)
+    res[f"P{P} B{B} N{N} k{k} soft+gather"] = (i6.cpu(), y6.cpu(), s6.cpu())
+    r7 = ops.gumbel_topk(torch.round(lg), B, k, 1.0, None, 17)
+    res[f"P{P} B{B} N{N} k{k} soft quantised"] = (r7["idx"].cpu(), r7["y_sel"].cpu(), r7["lse"].cpu())
     # sub-batched rows (super-rounds) and peaked / flat / tied logits
     i2, s2 = ops.gumbel_topk_gather(m, lg, B, k, 1.0, 5, race=True, sub=max(1, B // 4))
     res[f"P{P} B{B} N{N} k{k} sub"] = (i2.cpu(), s2.cpu())

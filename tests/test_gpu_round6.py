@@ -267,7 +267,7 @@ def test_one_logarithm_sampler_draws_the_same_index_sets(dev):
 def test_one_logarithm_sampler_selection_on_wave_masks(dev, shape):
     """The race form selects on compare masks (round 6, gumbel_topk.hip `DR_K1_SALU_SELECT`): a threshold search on the count of lane
     maxima, candidates dealt to lanes in index order, ranking only when more than k pass.  Every branch of it against the two-logarithm
-    form (whose selection is the candidate list of rounds 2-5; identical to the mask selection on 63 cases, scratch/k1_select_check.py):
+    form (whose selection is the candidate list of rounds 2-5; identical to the mask selection on 99 cases, scratch/k1_select_check.py):
     ordinary logits; flat logits; a few dominant points (the search cannot bracket the count: the row takes the list path);
     quantised logits; a span of 79 (the largest the form accepts)"""
     from differentiable_ransac_amd import ops, synth
