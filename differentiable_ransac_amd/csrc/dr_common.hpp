@@ -56,22 +56,40 @@ __device__ __forceinline__ void seed_next_block(uint64_t *__restrict__ state, ui
   if (threadIdx.x == 0) state[1] += (uint64_t)n;
 }
 
-// Per-pair weights of the exponential-race sampler (gumbel_topk.hip, round 6): w_n = exp(lmax - logit_n) into ws [P,N] and the
-// pair's "tame" flag (all logits finite, span <= 80) into the word ws[P * N + p]; -1 / c_p, c_p = ln 2 sum_n 1 / w_n (the expected
-// number of keys >= t is -t c_p: the threshold that one key is expected to reach), into ws[P * N + P + p].  ws holds (N + 32) * P floats.  One 256-thread block per pair.
+// Per-pair weights of the exponential-race sampler (gumbel_topk.hip, round 6): w_n = exp(lmax - logit_n) into ws [P,N]; then three words
+// per pair: the "tame" flag (all logits finite, span <= 80) at ws[P * N + p]; -1 / c_p at ws[P * N + P + p], c_p = ln 2 sum_n 1 / w_n
+// (the expected number of keys >= t is -t c_p: the sampler's threshold search starts from it); lmax at ws[P * N + 2 P + p] (train
+// mode's log-sum-exp).  ws holds (N + 32) * P floats.  One 256-thread block per pair.
 __device__ __forceinline__ void race_weights_block(const float *__restrict__ logits, int N, int P, int p, float *__restrict__ ws) {
-  __shared__ float s_mx[4], s_mn[4];
+  __shared__ float s_mx[4], s_mn[4], s_rate[4];
   __shared__ int s_bad[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float *lg = logits + (size_t)p * N;
+  // rows the register sampler serves (N <= 2048): the thread's eight logits stay in registers between the two passes -- one trip to
+  // memory, all loads in flight at once (the launch is a chain of latencies: 6.8 us with the second pass re-reading them)
+  constexpr int kRegs = 8;
+  const bool in_regs = N <= kRegs * 256;
+  float lr[kRegs];
   float mx = -INFINITY, mn = INFINITY;
   int bad = 0;
-  for (int n = tid; n < N; n += 256) {
-    const float l = lg[n];
-    const bool fin = fabsf(l) < INFINITY;   // false for NaN and +-inf
-    bad |= fin ? 0 : 1;
-    mx = fin ? fmaxf(mx, l) : mx;
-    mn = fin ? fminf(mn, l) : mn;
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) lr[u] = (tid + 256 * u < N) ? lg[tid + 256 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+      const bool have = tid + 256 * u < N, fin = fabsf(lr[u]) < INFINITY;   // fin: false for NaN and +-inf
+      bad |= (have && !fin) ? 1 : 0;
+      mx = (have && fin) ? fmaxf(mx, lr[u]) : mx;
+      mn = (have && fin) ? fminf(mn, lr[u]) : mn;
+    }
+  } else {
+    for (int n = tid; n < N; n += 256) {
+      const float l = lg[n];
+      const bool fin = fabsf(l) < INFINITY;
+      bad |= fin ? 0 : 1;
+      mx = fin ? fmaxf(mx, l) : mx;
+      mn = fin ? fminf(mn, l) : mn;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -87,19 +105,30 @@ __device__ __forceinline__ void race_weights_block(const float *__restrict__ log
   const bool tame = !bad && (mx - mn) <= 80.0f;
   float *w = ws + (size_t)p * N;
   float rate = 0.f;   // sum_n 1 / w_n: the density of the pair's keys (the sampler's threshold search starts from it)
-  for (int n = tid; n < N; n += 256) {
-    const float d = (mx - lg[n]) * 1.44269504088896340736f;
-    w[n] = tame ? __builtin_amdgcn_exp2f(d) : 0.f;
-    rate += tame ? __builtin_amdgcn_exp2f(-d) : 0.f;
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < kRegs; ++u) {
+      if (tid + 256 * u < N) {
+        const float d = (mx - lr[u]) * 1.44269504088896340736f;
+        w[tid + 256 * u] = tame ? __builtin_amdgcn_exp2f(d) : 0.f;
+        rate += tame ? __builtin_amdgcn_exp2f(-d) : 0.f;
+      }
+    }
+  } else {
+    for (int n = tid; n < N; n += 256) {
+      const float d = (mx - lg[n]) * 1.44269504088896340736f;
+      w[n] = tame ? __builtin_amdgcn_exp2f(d) : 0.f;
+      rate += tame ? __builtin_amdgcn_exp2f(-d) : 0.f;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) rate += __shfl_xor(rate, o, 64);
-  __syncthreads();   // (s_mx is read above by every thread)
-  if (lane == 0) s_mx[wv] = rate;
+  if (lane == 0) s_rate[wv] = rate;
   __syncthreads();
   if (tid == 0) {
     reinterpret_cast<int *>(ws + (size_t)P * N)[p] = tame ? 1 : 0;
-    ws[(size_t)P * N + P + p] = -1.0f / (0.69314718055994530942f * (s_mx[0] + s_mx[1] + s_mx[2] + s_mx[3]));
+    ws[(size_t)P * N + P + p] = -1.0f / (0.69314718055994530942f * ((s_rate[0] + s_rate[1]) + (s_rate[2] + s_rate[3])));
+    ws[(size_t)P * N + 2 * (size_t)P + p] = mx;   // (train mode: lse = lmax + ln(sum 1 / -key) - ln ln 2)
   }
 }
 

@@ -476,8 +476,11 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   float g[kFastGroups][4];
   float mx = -INFINITY, sm = 0.f, lmax = -INFINITY;
   bool race = false;
-  if constexpr (!kSoft && !kScreen) race = race_ws != nullptr && reinterpret_cast<const int *>(race_ws + (size_t)P_race * N)[p] != 0;
+  if constexpr (!kScreen) race = race_ws != nullptr && reinterpret_cast<const int *>(race_ws + (size_t)P_race * N)[p] != 0;
   if (race) {   // wave-uniform (per pair)
+    // kSoft (train mode): exp(g_n - lmax) = exp(logit_n - lmax) / (-ln u_n) = 1 / (ln 2 (-key_n)) -- the soft-max statistics of the
+    // row from the SAME keys: e_n = 1 / (-key_n), y_n = e_n / sum e, lse = lmax + ln(sum e) - ln ln 2.  A reciprocal and an add per
+    // element instead of the second logarithm, the add, the subtract, the exponential and the running maximum of the form below.
     const float4 *wr = reinterpret_cast<const float4 *>(race_ws + (size_t)p * N);
 #pragma unroll
     for (int i = 0; i < kFastGroups; ++i) {
@@ -491,6 +494,8 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
         g[i][2] = w4.z * log2_uniform_from_bits(r[2]);
         g[i][3] = w4.w * log2_uniform_from_bits(r[3]);
         lmax = fmaxf(lmax, fmaxf(fmaxf(g[i][0], g[i][1]), fmaxf(g[i][2], g[i][3])));
+        if (kSoft) sm += (__builtin_amdgcn_rcpf(-g[i][0]) + __builtin_amdgcn_rcpf(-g[i][1])) +
+                         (__builtin_amdgcn_rcpf(-g[i][2]) + __builtin_amdgcn_rcpf(-g[i][3]));
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[i][j] = -INFINITY;
@@ -522,12 +527,20 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   }
   float wmx = 0.f, lse = 0.f, inv_sm = 0.f;
   if (kSoft) {
-    wmx = row_max(mx);
-    sm *= (mx == -INFINITY) ? 0.f : exp_t<float>(mx - wmx);
-    sm = row_sum(sm);
-    lse = wmx + log_t<float>(sm);
-    inv_sm = 1.0f / sm;
+    if (race) {
+      sm = row_sum(sm);
+      lse = race_ws[(size_t)P_race * N + 2 * (size_t)P_race + p] + (log_t<float>(sm) + 0.36651292058166432701f);   // lmax + ln(sum e) - ln ln 2
+      inv_sm = 1.0f / sm;
+    } else {
+      wmx = row_max(mx);
+      sm *= (mx == -INFINITY) ? 0.f : exp_t<float>(mx - wmx);
+      sm = row_sum(sm);
+      lse = wmx + log_t<float>(sm);
+      inv_sm = 1.0f / sm;
+    }
   }
+  // the soft-max weight of a selected score (kSoft)
+  auto y_of = [&](float score) { return race ? __builtin_amdgcn_rcpf(-score) * inv_sm : exp_t<float>(score - wmx) * inv_sm; };
 
 #if DR_K1_DBG_SELECT == 1   // timing experiments (scratch/ab_k1_sel.py): pass A alone
   if (lane < k) idx[row * k + lane] = __float_as_int(lmax);
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
   bool settled = false;   // (wave-uniform)
   float thr = -INFINITY;
 #if DR_K1_SALU_SELECT
-  if constexpr (!kSoft && !kScreen) if (race) {
+  if constexpr (!kScreen) if (race) {
     // Round 6, the one-logarithm form: t by COUNTING.  The keys of a pair are a Poisson process in t: E #{ key >= t } = -t c_p with
     // c_p = ln 2 sum_n 1 / w_n (gumbel_race_weights_kernel), so t is searched as t = -lam / c_p from lam = 6: a compare + a count per
     // probe (one vector instruction; the k rounds of a wave-wide maximum below are 64), a secant step on the count until the count
@@ -622,7 +635,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
       if (win) {
         idx[row * k + pos] = ci;
         if (kSoft) {
-          const float y = exp_t<float>(cv - wmx) * inv_sm;
+          const float y = y_of(cv);
           y_sel[row * k + pos] = y;
           if (gather_dst) gather_dst[row * k + pos] = straight_through(gather_src[(size_t)p * N + ci], y);
         }
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
     if (win) {
       idx[row * k + pos] = ci;
       if (kSoft) {
-        const float y = exp_t<float>(cv - wmx) * inv_sm;
+        const float y = y_of(cv);
         y_sel[row * k + pos] = y;
         if (gather_dst) gather_dst[row * k + pos] = straight_through(gather_src[(size_t)p * N + ci], y);
       }
@@ -786,7 +799,7 @@ __global__ __launch_bounds__(kRowsPerBlock * 64) void gumbel_topk_fast_kernel(co
       for (int r = 0; r < k; ++r) pos += won[r] < me;
       idx[row * k + pos] = me;
       if (kSoft) {
-        const float y = exp_t<float>(mg - wmx) * inv_sm;
+        const float y = y_of(mg);
         y_sel[row * k + pos] = y;
         if (gather_dst) gather_dst[row * k + pos] = straight_through(gather_src[(size_t)p * N + me], y);
       }
@@ -1217,8 +1230,11 @@ int gumbel_fwd_launch(const T *logits, const T *gumbel, uint64_t seed, T tau, in
   if constexpr (sizeof(T) == 4) {
     if (DR_K1_FAST && logits && !gumbel && tau == T(1) && (N & 3) == 0 && N <= 4 * 64 * kFastGroups && !y_soft && !ret && !gumbel_out) {
       if (soft) {
+        if (race_ws && !race_ready)
+          hipLaunchKernelGGL(gumbel_race_weights_kernel, dim3(P), dim3(256), 0, st, (const float *)logits, N, P, race_ws);
         hipLaunchKernelGGL((gumbel_topk_fast_kernel<true>), grid, block, 0, st, (const float *)logits, seed, B, N, k, idx,
-                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst);
+                           (float *)y_sel, (float *)lse, seed_ptr, gather_src, gather_dst, PairGate(), (const uint32_t *)nullptr,
+                           (const float *)nullptr, 0, (const float *)race_ws, P);
         if (gathered) *gathered = gather_dst != nullptr;
       }
       else if (screen_ws && k <= 5 && B >= 64) {
@@ -1730,16 +1746,21 @@ static int gumbel_topk_gather_impl(const float *logits, const float *matches, ui
 // Train mode (round 5): K1 with the soft-max statistics + K2 in one call -- idx, y_sel [P,B,k], lse [P,B] and samples [P,B,k,4] =
 // matches[p, idx] * ((1 - y_sel) + y_sel), the straight-through weights of gumbel_sampler.py:36-40 applied as ransac.py:58-65 does.
 // One launch when the register kernel serves the shape (N <= 2048, N % 4 == 0, tau = 1), sampler + gather launches otherwise.
+// race_ws (round 6; optional, (N + 32) * P floats, 16-byte aligned): the one-logarithm form of the register kernel in train mode --
+// keys, winners and soft-max statistics from ONE logarithm and one reciprocal per element (weights by a prologue launch); y_sel / lse
+// agree with the two-logarithm form to rounding, the index sets up to the rounding of near-ties.
 int dr_gumbel_topk_gather_soft_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
-                                   int P, int B, int N, int k, int32_t *idx, float *y_sel, float *lse, float *samples, void *stream) {
+                                   int P, int B, int N, int k, int32_t *idx, float *y_sel, float *lse, float *samples, float *race_ws,
+                                   void *stream) {
   const float *y_soft = nullptr, *ret = nullptr;
   DR_REQUIRE(logits && matches && samples && y_sel && lse, "null pointer");
   DR_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 15) == 0 && (reinterpret_cast<uintptr_t>(samples) & 15) == 0, "16-byte alignment");
+  DR_REQUIRE((reinterpret_cast<uintptr_t>(race_ws) & 15) == 0, "workspace alignment");
   DR_GUMBEL_CHECK();
   bool gathered = false;
   if (int rc = dr::gumbel_fwd_launch<float>(logits, nullptr, seed, tau, P, B, N, k, idx, y_sel, lse, nullptr, nullptr, nullptr,
                                             (hipStream_t)stream, seed_dev, reinterpret_cast<const float4 *>(matches),
-                                            reinterpret_cast<float4 *>(samples), &gathered))
+                                            reinterpret_cast<float4 *>(samples), &gathered, nullptr, dr::PairGate(), 0, race_ws, false))
     return rc;
   if (gathered) return 0;
   hipLaunchKernelGGL((dr::gather_fwd_kernel<float>), dim3((B * k + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, matches, idx,

@@ -254,6 +254,7 @@ SCREEN_SHORT_ROWS = _os.environ.get("DRANSAC_SCREEN_SHORT", "0") == "1"
 # Round 6: the exponential-race form of the index-only sampler (one logarithm per element; dr_gumbel_topk_gather_f32's race_ws).
 # Same top-k up to the rounding of near-ties; off = the two-logarithm form of rounds 1-5 (A/B runs, tests: DRANSAC_K1_RACE=0).
 K1_RACE = _os.environ.get("DRANSAC_K1_RACE", "1") != "0"
+K1_RACE_SOFT = _os.environ.get("DRANSAC_K1_RACE_SOFT", "1") != "0"   # ... in train mode (SampleGather's fused launch)
 _RACE_MIN = tuple(int(v) for v in _os.environ.get("DRANSAC_K1_RACE_MIN", "32768,32").split(","))   # (rows, pairs) from which it is automatic
 
 
@@ -399,9 +400,13 @@ class SampleGather(torch.autograd.Function):
                      lse=torch.empty((P, B), device=logits.device, dtype=torch.float32))
             samples = torch.empty((P, B, k, 4), device=logits.device, dtype=torch.float32)
             ds = _dev_seed(seed)
+            # round 6: the one-logarithm form in train mode too (keys, winners and soft-max statistics from one logarithm and one
+            # reciprocal per element), where its weights prologue pays
+            rws = (torch.empty((P, N + 32), device=logits.device, dtype=torch.float32)
+                   if K1_RACE_SOFT and race_form_pays(P, B, N, tau) else None)
             L.call("dr_gumbel_topk_gather_soft_f32", ptr(logits), ptr(matches), c_uint64(0 if ds else seed & (2 ** 64 - 1)),
                    ptr(seed if ds else None), L.c_float(tau), c_int(P), c_int(B), c_int(N), c_int(k), ptr(r["idx"]), ptr(r["y_sel"]),
-                   ptr(r["lse"]), ptr(samples), stream())
+                   ptr(r["lse"]), ptr(samples), ptr(rws), stream())
         else:
             r = gumbel_topk(logits, B, k, tau, gumbel, seed)
             samples = gather(matches, r["idx"], r["y_sel"])

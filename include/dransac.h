@@ -131,9 +131,14 @@ int dr_gumbel_topk_gather_f32(const float *logits, const float *matches, uint64_
 /* Train mode (round 5): K1 WITH the soft-max statistics + K2 in one call (GumbelSoftmaxSampler.sample, samplers/gumbel_sampler.py:25-42,
  * followed by `matches * ret` + the mask gather of ransac.py:58-65): idx, y_sel [P,B,k], lse [P,B] as dr_gumbel_topk_fwd_f32 and
  * samples [P,B,k,4] = matches[p, idx] * ((1 - y_sel) + y_sel) as dr_gather_fwd_f32 (c = 4; 16-byte aligned buffers).  One launch
- * when the register-resident kernel serves the shape, sampler + gather launches otherwise. */
+ * when the register-resident kernel serves the shape, sampler + gather launches otherwise.
+ * race_ws (round 6; optional, (N + 32) * P floats, 16-byte aligned): the one-logarithm form in train mode -- keys, winners AND the
+ * soft-max statistics (y_n = (1 / -key_n) / sum_m (1 / -key_m), lse = lmax + ln sum - ln ln 2) from one logarithm and one reciprocal
+ * per element; y_sel / lse agree with the two-logarithm form to rounding, the index sets up to the rounding of near-ties
+ * (tests/test_gpu_round6.py).  NULL = the two-logarithm form. */
 int dr_gumbel_topk_gather_soft_f32(const float *logits, const float *matches, uint64_t seed, const uint64_t *seed_dev, float tau,
-                                   int P, int B, int N, int k, int32_t *idx, float *y_sel, float *lse, float *samples, void *stream);
+                                   int P, int B, int N, int k, int32_t *idx, float *y_sel, float *lse, float *samples, float *race_ws,
+                                   void *stream);
 /* ... and the backward of the pair in one launch: grad_logits [P,N] from grad_samples [P,B,k,4] and grad_w [P,B,k]
  * (gradient of the y_sel output; NULL = none) -- dr_gather_bwd_f32's a_sel is formed inside dr_gumbel_topk_bwd_f32's row
  * prologue.  The correspondences receive no gradient from this entry. */

@@ -290,6 +290,48 @@ def test_one_logarithm_sampler_selection_on_wave_masks(dev, shape):
             assert all((ia == j).any(-1).float().mean() > 0.99 for j in (3, N // 2, N - 1))
 
 
+def test_one_logarithm_sampler_in_train_mode(dev, monkeypatch):
+    """Train mode through the one-logarithm form (round 6: dr_gumbel_topk_gather_soft_f32's race_ws): the keys w_n log2 u_n give the
+    winners AND the soft-max statistics -- y_n = (1 / -key_n) / sum_m (1 / -key_m), lse = lmax + ln sum - ln ln 2 (gumbel_sampler.py:
+    33-38 restated) -- against the two-logarithm form of the same launch: index sets, weights, log-sum-exps, samples, and the gradient
+    to the logits through the unchanged backward launch; wild pairs (non-finite logits, a span beyond 80) keep the other form, bit
+    for bit"""
+    from differentiable_ransac_amd import ops, synth
+    P, B, N, k = 32, 1024, 2000, 5
+    d = synth.batch_two_view(P, N, seed0=5)
+    m = d["matches"].to(dev)
+    lg0 = d["logits"].to(dev)
+    lg0[1] = torch.linspace(-100.0, 0.0, N, device=dev)           # span 100 > 80: keeps the two-logarithm form
+    lg0[2, 9] = float("-inf")
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "K1_RACE_SOFT", on)
+        lg = lg0.clone().requires_grad_(True)
+        smp, y, idx = ops.SampleGather.apply(m, lg, B, k, 1.0, None, 77)
+        wgt = torch.linspace(0.5, 1.5, P * B * k * 4, device=dev).reshape(P, B, k, 4)
+        (smp * wgt).sum().backward()
+        out[on] = (idx.clone(), y.detach().clone(), smp.detach().clone(), lg.grad.clone())
+    (ia, ya, sa, ga), (ib, yb, sb, gb) = out[True], out[False]
+    same = (ia == ib).all(-1)
+    assert int((~same).sum()) <= 2, int((~same).sum())            # (near-ties at rounding level)
+    assert torch.equal(ia[1:3], ib[1:3]) and torch.equal(ya[1:3], yb[1:3]) and torch.equal(sa[1:3], sb[1:3])
+    rel = ((ya - yb).abs() / yb.abs().clamp_min(1e-30))[same]
+    assert float(rel.max()) < 5e-5, float(rel.max())
+    assert float((sa - sb).abs()[same].max()) < 1e-5
+    fin = torch.isfinite(gb)
+    assert torch.equal(torch.isfinite(ga), fin)
+    assert float((ga - gb)[fin].abs().max()) <= 2e-4 * float(gb[fin].abs().max()), float((ga - gb)[fin].abs().max())
+    # the statistics against their definition: y = softmax(logits + G)[idx] on the noise the general kernel dumps for this seed
+    r = ops.gumbel_topk(lg0[:4], B, k, 1.0, None, 77, want_noise=True)
+    monkeypatch.setattr(ops, "K1_RACE_SOFT", True)
+    _, y4, i4 = ops.SampleGather.apply(m[:4].contiguous(), lg0[:4].contiguous(), B, k, 1.0, None, 77)   # (4 pairs: below the automatic choice)
+    soft = torch.softmax((lg0[:4, None, :] + r["gumbel"]).double(), -1)
+    want = torch.gather(soft, 2, ia[:4].long())
+    ok = (ia[:4] == r["idx"]).all(-1)
+    ok[2] = False                                                    # (the pair with a -inf logit is compared above)
+    assert float(((ya[:4].double() - want).abs() / want)[ok].max()) < 5e-5
+
+
 @pytest.mark.parametrize("rbs", [64, 1024])
 def test_dropin_fundamental_call_as_a_graph_equals_the_batch_by_batch_driver(dev, rbs):
     """`-fmat 1 -sam 3 -tr 0` through the replayed call (packed one-pair state, LSQ refit on the inliers of the best mask that lives in
