@@ -332,6 +332,33 @@ def test_one_logarithm_sampler_in_train_mode(dev, monkeypatch):
     assert float(((ya[:4].double() - want).abs() / want)[ok].max()) < 5e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 256, 64, 5), (4, 300, 1000, 8), (2, 512, 2048, 1), (5, 130, 260, 3)])
+def test_one_logarithm_sampler_in_train_mode_shapes(dev, monkeypatch, shape):
+    """the same through short rows, k = 1 and k = 8, a row count that is no multiple of the block's four rows -- the automatic choice
+    forced on (ops._RACE_MIN), flat / quantised / dominant logits: winners, weights, log-sum-exps and the weights' sum rule"""
+    from differentiable_ransac_amd import ops, synth
+    P, B, N, k = shape
+    monkeypatch.setattr(ops, "_RACE_MIN", (1, 1))
+    d = synth.batch_two_view(P, N, seed0=9)
+    m, lg = d["matches"].to(dev), d["logits"].to(dev)
+    dom = lg.clone()
+    dom[:, [1, N // 2]] += 25.0
+    for tag, l2 in {"synthetic": lg, "flat": torch.zeros_like(lg), "quantised": torch.round(lg), "dominant": dom}.items():
+        out = {}
+        for on in (True, False):
+            monkeypatch.setattr(ops, "K1_RACE_SOFT", on)
+            smp, y, idx = ops.SampleGather.apply(m, l2.contiguous(), B, k, 1.0, None, 31)
+            out[on] = (idx, y, smp)
+        (ia, ya, sa), (ib, yb, sb) = out[True], out[False]
+        same = (ia == ib).all(-1)
+        assert int((~same).sum()) <= max(1, P * B // 10000), (tag, int((~same).sum()))
+        assert (ia[..., 1:] > ia[..., :-1]).all() and ia.min() >= 0 and ia.max() < N, tag
+        rel = ((ya - yb).abs() / yb.abs().clamp_min(1e-30))[same]
+        assert float(rel.max()) < 1e-4, (tag, float(rel.max()))
+        assert float((sa - sb).abs()[same].max()) < 1e-4, tag
+        assert float(ya.sum(-1).max()) <= 1.0 + 1e-5 and float(ya.min()) >= 0.0, tag
+
+
 @pytest.mark.parametrize("rbs", [64, 1024])
 def test_dropin_fundamental_call_as_a_graph_equals_the_batch_by_batch_driver(dev, rbs):
     """`-fmat 1 -sam 3 -tr 0` through the replayed call (packed one-pair state, LSQ refit on the inliers of the best mask that lives in
