@@ -208,6 +208,9 @@ def run_bounded(fn, n, window=32):
         ev[i % window].record(st if isinstance(st, torch.cuda.Stream) else torch.cuda.current_stream())
 
 
+K4_EVENT_EVERY = 4   # the scoring launch's HIP-event pair: every 4th step of the timed region (a pair costs the step ~11 us of idle device)
+
+
 class CallTimer:
     """HIP events around selected libdransac launches (the ctypes call), recorded on the stream the launch goes to."""
 
@@ -216,6 +219,7 @@ class CallTimer:
         self.L, self.prefixes = L, tuple(prefixes)
         self.ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] for _ in range(slots)]
         self.i = -1
+        self.used = set()                 # slots whose pair was recorded (the timed region samples: every K4_EVENT_EVERY-th step)
         self.orig = L.call
         L.call = self._call
 
@@ -225,12 +229,13 @@ class CallTimer:
             self.ev[i][0].record()
             self.orig(name, *a)
             self.ev[i][1].record()
+            self.used.add(i)
         else:
             self.orig(name, *a)
 
     def mean_ms(self, n=None, lo=0):
-        ev = self.ev[lo:] if n is None else self.ev[lo:lo + n]
-        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+        idx = [i for i in range(lo, len(self.ev) if n is None else lo + n) if i in self.used]
+        return sum(self.ev[i][0].elapsed_time(self.ev[i][1]) for i in idx) / max(1, len(idx))
 
     def close(self):
         self.L.call = self.orig
@@ -894,14 +899,20 @@ def main():
     # bounded run-ahead: the host issues a step in ~0.1 ms and would otherwise queue hundreds of steps; the first time the
     # runtime's queue fills it stalls the device for ~40 ms, once (scratch/stall_find.py, stall_find2.py).  Step i is issued
     # when step i - kWindow has finished -- the device always has kWindow steps queued, so it never waits for the host.
+    # Round 6: an event record is a marker packet with a barrier -- 5.6 us of idle device per record in the step's timeline
+    # (profiles/r6_headline_timeline.md: one after every step for this window, two around the scoring launch = 17 us of a 0.905 ms
+    # step were the measurement).  One stream: the window's event after every kStride-th step, the scoring launch's pair in every
+    # K4_EVENT_EVERY-th step; several streams keep one record per step (each stream needs its own).
     kWindow = 32
-    done_ev = [torch.cuda.Event() for _ in range(kWindow)]
+    kStride = 4 if len(streams) == 1 else 1
+    done_ev = [torch.cuda.Event() for _ in range(kWindow // kStride)]
 
     def issue_bounded(i, n_issued):
-        if n_issued >= kWindow:
-            done_ev[n_issued % kWindow].synchronize()
+        if n_issued >= kWindow and n_issued % kStride == 0:
+            done_ev[((n_issued - kWindow) // kStride) % len(done_ev)].synchronize()   # recorded after step n_issued - kWindow + kStride - 1
         issue(i)
-        done_ev[n_issued % kWindow].record(streams[i % len(streams)] if len(streams) > 1 else torch.cuda.current_stream())
+        if (n_issued + 1) % kStride == 0:
+            done_ev[(n_issued // kStride) % len(done_ev)].record(streams[i % len(streams)] if len(streams) > 1 else torch.cuda.current_stream())
 
     # time-based pre-conditioning (not counted in `warmup`): the same step until --prewarm-s of wall time has passed.  The
     # driver's `--steps 20 --warmup 5` is 6 ms + 24 ms of device time: without this the region is the clock ramp of a cold box
@@ -911,7 +922,7 @@ def main():
         for _ in range(8):
             issue_bounded(n_issued, n_issued)
             n_issued += 1
-        done_ev[(n_issued - 1) % kWindow].synchronize()
+        done_ev[((n_issued - 1) // kStride) % len(done_ev)].synchronize()   # (8 steps per chunk: its last step carries a record)
         more = time.perf_counter() - t_pre < args.prewarm_s
         if dist is not None:
             # every rank must issue the SAME number of steps (a train step carries a collective): the ranks agree per chunk
@@ -939,7 +950,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            timer.i = sgi * args.steps + i
+            timer.i = sgi * args.steps + i if i % K4_EVENT_EVERY == 0 else -1
             issue_bounded(i, n_issued)
             n_issued += 1
         if bucket is not None:
@@ -1141,6 +1152,9 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "segments_avg_launch_ms": [round(x, 5) for x in seg_k4],
+                     "event_sampling": (f"HIP-event pair around the scoring launch of every {K4_EVENT_EVERY}th step of the timed region "
+                                        f"({len(timer.used)} launches timed), on the stream the kernel is launched on: a pair is two "
+                                        "marker packets with barriers, ~11 us of idle device in the step that carries it"),
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "isolated": {"avg_launch_ms": iso_ms, "achieved": bytes_per_launch / (iso_ms * 1e-3) / 1e9,
                                   "frac": bytes_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
