@@ -69,7 +69,9 @@ class RANSACLayer(torch.nn.Module):
     def forward(self, points, weights, K1, K2, im_size1, im_size2, ground_truth=None, gumbels=None):
         """points [N,4], weights (logits) [N] -> (Es, seconds).  Train: Es [n_batches * B', 3, 3] with autograd to
         `weights`; test: Es [3,3]."""
-        points_ = points.clone()
+        # (model_cl.py:239 clones because the F branch overwrites the coordinates; nothing below writes to the E branch's input --
+        #  the drivers never mutate theirs -- and the copy was one 5 us launch of the 0.14 ms a test-mode pair costs)
+        points_ = points.clone() if self.opt.fmat else points
         if self.opt.fmat:
             points_[:, 0:2] = denormalize_pts(points[:, 0:2], im_size1)
             points_[:, 2:4] = denormalize_pts(points[:, 2:4], im_size2)

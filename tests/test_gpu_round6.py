@@ -359,6 +359,28 @@ def test_one_logarithm_sampler_in_train_mode_shapes(dev, monkeypatch, shape):
         assert float(ya.sum(-1).max()) <= 1.0 + 1e-5 and float(ya.min()) >= 0.0, tag
 
 
+@pytest.mark.parametrize("tr", [False, True])
+def test_layer_leaves_its_inputs_untouched(dev, tr):
+    """The E branch of RANSACLayer.forward hands its input on without the copy of model_cl.py:239 (round 6): points, logits and the
+    calibration matrices read the same after the call as before, in test mode (replayed graph and eager) and in train mode"""
+    import types
+    from differentiable_ransac_amd import layers, synth
+    d = synth.batch_two_view(2, 2000, seed0=21)
+    m, lg, K1, K2, gt = (d[k].to(dev) for k in ("matches", "logits", "K1", "K2", "gt_E"))
+    im = torch.tensor([1000.0, 1000.0], device=dev)
+    opt = types.SimpleNamespace(fmat=False, sampler=2, ransac_batch_size=1024, tr=tr, weighted=0, threshold=0.75, precision=1,
+                                device=str(dev))
+    layer = layers.RANSACLayer(opt)
+    for graph in ((True, False) if not tr else (False,)):
+        layer.estimator.graph = graph
+        for p in range(2):
+            before = [t.clone() for t in (m[p], lg[p], K1[p], K2[p])]
+            Es, _ = layer(m[p], lg[p], K1[p], K2[p], im, im, gt[p] if tr else None)
+            assert torch.isfinite(Es).all()
+            for was, now in zip(before, (m[p], lg[p], K1[p], K2[p])):
+                assert torch.equal(was, now)
+
+
 @pytest.mark.parametrize("rbs", [64, 1024])
 def test_dropin_fundamental_call_as_a_graph_equals_the_batch_by_batch_driver(dev, rbs):
     """`-fmat 1 -sam 3 -tr 0` through the replayed call (packed one-pair state, LSQ refit on the inliers of the best mask that lives in
