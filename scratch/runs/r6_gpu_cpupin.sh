@@ -1,5 +1,5 @@
 #!/bin/bash
-# (the DRANSAC_CPU_PIN knob existed in bench.py for this measurement only: pinning was worse and was removed again -- docs/LOG.md, round-6 log item 22)
+# (the DRANSAC_CPU_PIN knob existed in bench.py for this measurement only: pinning was worse and was removed again -- docs/LOG.md, round-6 log item 23)
 # round 6: does pinning the CPU legs' threads make the c2 CPU baseline repeat?  alternating runs, one box
 cd $GRAFT_REPO_ROOT
 for rep in 1 2 3 4; do
