@@ -196,16 +196,21 @@ def make_step(w, dev, rank=0, mode="test", seed=1234, keep_masks=True, fixture=F
     return step, dict(rn=rn, matches=matches, logits=logits, S=S, data=data, K=(K1, K2))
 
 
-def run_bounded(fn, n, window=32):
-    """fn(i) for i < n with at most `window` steps queued ahead of the device: step i is issued when step i - window has
-    finished (event recorded on the stream that is current when fn returns...  fn may switch streams itself: it then returns
-    the stream to record on)."""
+def run_bounded(fn, n, window=32, stride=4):
+    """fn(i) for i < n with at most `window` steps queued ahead of the device: step i is issued when step i - window (rounded to the
+    stride) has finished.  Round 6: the event is recorded after every `stride`-th step only -- a record is a marker packet with a
+    barrier, 5.6 us of idle device (profiles/r6_headline_timeline.md): one per step was 16 % of config 1's 35 us step.  fn may switch
+    streams itself: it then returns the stream to record on, and every step carries a record (each stream needs its own)."""
     ev = [torch.cuda.Event() for _ in range(window)]
     for i in range(n):
-        if i >= window:
-            ev[i % window].synchronize()
+        if i >= window and i % stride == 0:
+            ev[((i - window) // stride) % window].synchronize()        # recorded after step i - window + stride - 1
         st = fn(i)
-        ev[i % window].record(st if isinstance(st, torch.cuda.Stream) else torch.cuda.current_stream())
+        own = isinstance(st, torch.cuda.Stream)
+        if own:
+            stride = 1
+        if (i + 1) % stride == 0:
+            ev[(i // stride) % window].record(st if own else torch.cuda.current_stream())
 
 
 K4_EVENT_EVERY = 4   # the scoring launch's HIP-event pair: every 4th step of the timed region (a pair costs the step ~11 us of idle device)
