@@ -1118,6 +1118,18 @@ def main():
         timer.i = -1
         iso_ms = timer.mean_ms(n_iso)
     timer.close()
+    # what an event pair reads with NOTHING between its two records (the second marker packet's own processing): the part of
+    # `avg_launch_ms` that is not the kernel.  `frac` stays the raw figure; `frac_net_of_event_pair` is the one to hold against
+    # rocprofv3's duration of the same kernel (profiles/r6_kernel_stats_c2.md)
+    torch.cuda.synchronize()
+    empty = []
+    for _ in range(40):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        empty.append((e0, e1))
+    torch.cuda.synchronize()
+    empty_pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
     rigid = w["solver"] == "rigid"
     bytes_per_launch = k4r_bytes(P, N, M) if rigid else k4_bytes(P, N, M)
     valid_frac = None
@@ -1157,6 +1169,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note,
                      "avg_launch_ms": k4_ms, "segments_avg_launch_ms": [round(x, 5) for x in seg_k4],
+                     "empty_event_pair_ms": empty_pair_ms,
+                     "frac_net_of_event_pair": bytes_per_launch / (max(k4_ms - empty_pair_ms, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "event_sampling": (f"HIP-event pair around the scoring launch of every {K4_EVENT_EVERY}th step of the timed region "
                                         f"({len(timer.used)} launches timed), on the stream the kernel is launched on: a pair is two "
                                         "marker packets with barriers, ~11 us of idle device in the step that carries it"),

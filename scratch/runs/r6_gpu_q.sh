@@ -1,6 +1,3 @@
 #!/bin/bash
-# round 6, run q: full GPU suite + smoke + build() from scratch on the box (what the driver does at round end)
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python -m pytest tests -q -m "not gpu" 2>&1 | tail -2
+timeout 300 python bench.py --steps 20 --warmup 5 --no-configs --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value']/1e6,2), round(d['ms_per_step'],4), r['avg_launch_ms'], r['frac'], r['empty_event_pair_ms'], r['frac_net_of_event_pair'])"
