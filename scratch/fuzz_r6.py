@@ -25,9 +25,13 @@ def check(name, ok, info=""):
         print("FAIL", name, info)
 
 
-for t in range(T):
-    P, B, k = ri(1, 40), ri(1, 700), ri(1, 8)
-    N = 4 * ri(max(2, (k + 3) // 4 + 1), 512)
+EDGE = [(3, 70, 3, 4), (2, 33, 8, 8), (4, 65, 5, 8), (1, 1, 1, 4), (5, 129, 4, 4), (2, 64, 8, 12), (40, 7, 2, 2048)]   # (P, B, k, N): rows as short as k
+for t in range(T + len(EDGE)):
+    if t >= T:
+        P, B, k, N = EDGE[t - T]
+    else:
+        P, B, k = ri(1, 40), ri(1, 700), ri(1, 8)
+        N = 4 * ri(max(2, (k + 3) // 4 + 1), 512)
     d = synth.batch_two_view(P, N, seed0=100 + t)
     m, lg = d["matches"].to(dev), d["logits"].to(dev)
     style = ri(0, 5)
@@ -62,4 +66,4 @@ for t in range(T):
         check(tag + f" soft weights race={on}", rel.numel() == 0 or float(rel.max()) < 1e-4, float(rel.max()) if rel.numel() else 0)
     r2 = ops.gumbel_topk(lg, B, k, 1.0, None, seed)                           # soft, two-logarithm, no gather: lse
     check(tag + " lse", float((r2["lse"].double() - lse).abs().max()) < 2e-5 * max(1.0, float(lse.abs().max())))
-print("fuzz_r6:", T, "trials,", fails, "failures")
+print("fuzz_r6:", T, "random trials +", len(EDGE), "edge shapes,", fails, "failures")
